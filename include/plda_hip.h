@@ -1,0 +1,149 @@
+/*
+ * include/plda_hip.h -- C ABI of libplda_hip.so, the MI355X (gfx950) PLDA engine.
+ *
+ * This is the drop-in boundary for the reference's native object
+ * `libplda.MPlda` (RicherMans/PLDA src/pldamodule.cpp): every entry point names
+ * the reference interface it replaces.  Plain pointers and sizes only; no
+ * CPython, NumPy or torch types cross this boundary.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns an int status: PLDA_OK (0) or a negative PLDA_E_*;
+ *    the text of the last failure on a handle is plda_last_error(h)
+ *    (plda_last_error(NULL) = last failure of plda_create on this thread).
+ *    Nothing aborts and nothing throws across the ABI (the reference lets Kaldi
+ *    assertions abort the process, pldamodule.cpp has no try/catch).
+ *  - matrices are row-major, C-contiguous, fp64 (the reference reads every
+ *    array as f64: pldamodule.cpp:72, kaldi-utils.hpp:99-111); labels are
+ *    uint64 (npy_long read as 8 bytes, pldamodule.cpp:74).
+ *  - "host" entry points borrow caller memory for the duration of the call and
+ *    write only caller-allocated outputs (ownership: the reference copies its
+ *    inputs immediately, kaldi-utils.hpp:99-122).  "_dev" entry points take
+ *    pointers into this GPU's HBM and enqueue on the handle's stream without
+ *    synchronising.
+ *  - one handle = one GPU + one HIP stream; a handle is not thread-safe.
+ *  - there is NO CPU fallback: without a usable gfx950 device plda_create fails.
+ */
+#ifndef PLDA_HIP_H_
+#define PLDA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLDA_OK 0
+#define PLDA_E_INVAL (-1)     /* bad argument (NULL, non-positive size, dim mismatch) */
+#define PLDA_E_ONE_SPEAKER (-2) /* fit with a single speaker (pldamodule.cpp:83-86) */
+#define PLDA_E_NUMERIC (-3)   /* not positive definite / eigensolver did not converge */
+#define PLDA_E_NOT_FITTED (-4)
+#define PLDA_E_HIP (-5)       /* HIP runtime failure (message has the hipError string) */
+#define PLDA_E_LABELS (-6)    /* fit labels not dense 0..K-1 (pldamodule.cpp:88-92 indexes by value) */
+#define PLDA_E_CAPACITY (-7)  /* caller output too small */
+
+typedef struct plda_handle plda_handle;
+
+/* ---- lifecycle: replaces Plda_new / MPLDA_dealloc (pldamodule.cpp:297-316) and
+ *      the module init initlibplda (pldamodule.cpp:371-384) ---- */
+int plda_create(int device, plda_handle **out);
+int plda_destroy(plda_handle *h);
+const char *plda_last_error(const plda_handle *h);
+int plda_abi_version(void);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = the handle's own */
+int plda_set_stream(plda_handle *h, void *hip_stream);
+int plda_synchronize(plda_handle *h);
+
+/* ---- fit: replaces MPlda_fit (pldamodule.cpp:42-109) ----
+ * labels must be dense 0..K-1 (the Python shim compacts arbitrary unsigned
+ * labels first).  Runs: label counting-sort, per-speaker centroids,
+ * AddSamples(1/n_k) scatter (pldamodule.cpp:94-98), `iters` EM iterations
+ * (Kaldi PldaEstimator::Estimate, :102-106) and GetOutput, all on the GPU in fp64. */
+int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D,
+             const uint64_t *labels, int32_t iters);
+int plda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D,
+                 const uint64_t *dlabels, int64_t K, int32_t iters);
+/* timings of the last fit, milliseconds: [0] statistics pass (sort+centroid+scatter),
+ * [1] EM loop (all iterations), [2] GetOutput; [3] = iterations run */
+int plda_fit_timings(plda_handle *h, double out_ms[4]);
+/* staged access to the fit internals (parity tests of SURVEY.md rows a3-a7):
+ * any pointer may be NULL.  means[K*D] in label order, counts[K], scatter[D*D],
+ * sum[D], W[D*D], B[D*D] (final within/between covariances before GetOutput). */
+int plda_fit_get_stats(plda_handle *h, double *means, int64_t *counts, double *scatter,
+                       double *sum, double *W, double *B);
+int plda_fit_num_classes(plda_handle *h, int64_t *K);
+
+/* ---- model state: the Kaldi `Plda` held at pldamodule.cpp:29 ----
+ * transform is [Dout, Din] row-major; after fit Dout == Din == D. */
+int plda_get_dims(plda_handle *h, int32_t *Dout, int32_t *Din);
+int plda_get_model(plda_handle *h, double *mean /*[Din]*/, double *transform /*[Dout*Din]*/,
+                   double *psi /*[Dout]*/, double *offset /*[Dout]*/);
+int plda_set_model(plda_handle *h, int32_t Dout, int32_t Din, const double *mean,
+                   const double *transform, const double *psi);
+/* build extension ("targetdim"): keep the first
+ * `targetdim` rows of transform / psi (largest between-class variance). */
+int plda_truncate(plda_handle *h, int32_t targetdim);
+/* replaces Plda::SmoothWithinClassCovariance reached at pldamodule.cpp:158-160 */
+int plda_smooth(plda_handle *h, double factor);
+
+/* ---- transform: replaces Mplda_transform (pldamodule.cpp:111-194) ----
+ * groups rows by label (any u64 values), averages, applies
+ * Plda::TransformIvector(mean, n) (:171) incl. length normalisation.  Outputs
+ * ascending by label (std::map order, :164).  *Ku: in = capacity (rows of the
+ * out arrays), out = number of groups. */
+int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Din,
+                          const uint64_t *labels, uint64_t *out_labels,
+                          int64_t *out_counts, double *out_vecs /*[Ku*Dout]*/,
+                          int64_t *Ku);
+/* batched Plda::TransformIvector on R already-averaged rows; num_examples[R]
+ * (int32) or, if NULL, `n_uniform` for every row. */
+int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t Din,
+                        const int32_t *num_examples, int32_t n_uniform, double *out);
+int plda_transform_rows_dev(plda_handle *h, const double *dXbar, int64_t R, int32_t Din,
+                            const int32_t *dnum_examples, int32_t n_uniform, double *dout);
+
+/* ---- score: replaces MPlda_score (pldamodule.cpp:258-277) ----
+ * Trial list: P pairs (enrol row e_idx[p] of U, test row t_idx[p] of V), each
+ * Plda::LogLikelihoodRatio(U[e], n[e], V[t]) (:266) in fp64, then the optional
+ * z-norm (s - zmean[e]) / zstd[e] (:269-273) where zmean/zstd are non-NULL and
+ * zstd[e] != 0.  plda.score() is the P == 1 case. */
+int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, int64_t M,
+                     const double *V, int64_t Nt, const int64_t *e_idx,
+                     const int64_t *t_idx, int64_t P, const double *zmean,
+                     const double *zstd, double *out);
+/* Dense trials matrix out[i*ld_out + j] = LLR(U[i], n[i], V[j]) for the M x Nt
+ * block (the nested Python loop of scoring/scorePLDA.py:302-318 and
+ * tests/pldatest.py:29-33 as one launch): fp64 bias terms + fp32 MFMA GEMM,
+ * fp32 scores.  n_enrol NULL => every row uses n_uniform (GEMM depth Dout);
+ * otherwise depth 2*Dout.  zmean/zstd as above (nullable). */
+int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol,
+                      int32_t n_uniform, int64_t M, const double *V, int64_t Nt,
+                      const double *zmean, const double *zstd, float *out,
+                      int64_t ld_out);
+int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol,
+                          int32_t n_uniform, int64_t M, const double *dV, int64_t Nt,
+                          const double *dzmean, const double *dzstd, float *dout,
+                          int64_t ld_out);
+/* algorithmic work of the last score_matrix call: flop of the trials GEMM and
+ * its depth, for roofline accounting */
+int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k);
+
+/* ---- z-norm: replaces MPlda_norm (pldamodule.cpp:196-256) ----
+ * Every cohort row is transformed with num_examples = Nb (:224) and scored as
+ * the TRAIN side with n = 1 against every model vector (:235); per model the
+ * mean and population std over the cohort (:240-250).  Fused: the Nb x M score
+ * matrix is never materialised.  models are already-transformed vectors. */
+/* num_examples: the count the reference hands to TransformIvector at :224, i.e. the
+ * row count of the FULL background matrix; differs from Nb only when the caller
+ * passes a row subset (numutts > 0, :204-216).  0 means Nb. */
+int plda_znorm_stats(plda_handle *h, const double *bkg, int64_t Nb, int32_t num_examples,
+                     int32_t Din, const double *models, int64_t M, double *out_mean,
+                     double *out_std);
+int plda_znorm_stats_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples,
+                         int32_t Din, const double *dmodels, int64_t M, double *dout_mean,
+                         double *dout_std);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

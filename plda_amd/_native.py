@@ -1,0 +1,89 @@
+"""plda_amd/_native.py -- ctypes binding of libplda_hip.so (include/plda_hip.h).
+
+There is no fallback: if the shared library is missing, or lacks a symbol, or no
+gfx950 device is usable, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libplda_hip.so")
+
+PLDA_OK = 0
+PLDA_E_INVAL = -1
+PLDA_E_ONE_SPEAKER = -2
+PLDA_E_NUMERIC = -3
+PLDA_E_NOT_FITTED = -4
+PLDA_E_HIP = -5
+PLDA_E_LABELS = -6
+PLDA_E_CAPACITY = -7
+
+_vp = C.c_void_p
+_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); pointers are passed as void* (host ndarray.ctypes.data
+# or a device address), exactly the plain-pointer ABI of include/plda_hip.h
+SIGNATURES = {
+    "plda_abi_version": (C.c_int, []),
+    "plda_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "plda_destroy": (C.c_int, [_vp]),
+    "plda_last_error": (C.c_char_p, [_vp]),
+    "plda_set_stream": (C.c_int, [_vp, _vp]),
+    "plda_synchronize": (C.c_int, [_vp]),
+    "plda_fit": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32]),
+    "plda_fit_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),
+    "plda_fit_timings": (C.c_int, [_vp, _vp]),
+    "plda_fit_get_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plda_fit_num_classes": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "plda_get_dims": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "plda_get_model": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "plda_set_model": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "plda_truncate": (C.c_int, [_vp, _i32]),
+    "plda_smooth": (C.c_int, [_vp, _f64]),
+    "plda_transform_groups": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "plda_transform_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "plda_transform_rows_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "plda_score_pairs": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "plda_score_matrix": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "plda_score_matrix_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "plda_score_last_shape": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "plda_znorm_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "plda_znorm_stats_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libplda_hip.so and bind every symbol of include/plda_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "plda_amd: %s not found -- build it with `python -m plda_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class PldaError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libplda_hip error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+def last_error(handle):
+    msg = load().plda_last_error(handle)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(handle, rc):
+    if rc != PLDA_OK:
+        raise PldaError(rc, last_error(handle))

@@ -1,0 +1,440 @@
+// plda_amd/csrc/api.hip -- the C ABI of libplda_hip.so (include/plda_hip.h).
+// Host-pointer entry points stage through device buffers owned by the handle and
+// call the *_device implementations; nothing here computes on the CPU.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <numeric>
+
+namespace plda {
+
+static thread_local std::string g_create_err;
+
+int fail(plda_handle *h, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_err = buf;
+  return code;
+}
+
+int hip_fail(plda_handle *h, hipError_t e, const char *what, const char *file, int line) {
+  return fail(h, PLDA_E_HIP, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+}
+
+int model_to_device(plda_handle *h) {
+  const size_t Dout = h->Dout, Din = h->Din;
+  PLDA_HIP(h, h->d_mean.reserve(Din * 8));
+  PLDA_HIP(h, h->d_transform.reserve(Dout * Din * 8));
+  PLDA_HIP(h, h->d_psi.reserve(Dout * 8));
+  PLDA_HIP(h, h->d_offset.reserve(Dout * 8));
+  PLDA_HIP(h, hipMemcpyAsync(h->d_mean.p, h->h_mean.data(), Din * 8, hipMemcpyHostToDevice, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->d_transform.p, h->h_transform.data(), Dout * Din * 8, hipMemcpyHostToDevice, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->d_psi.p, h->h_psi.data(), Dout * 8, hipMemcpyHostToDevice, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->d_offset.p, h->h_offset.data(), Dout * 8, hipMemcpyHostToDevice, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+// implemented in score.hip / fit.hip
+int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
+                        const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
+                        float *dout, int64_t ld);
+int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,
+                       const int64_t *de, const int64_t *dt, int64_t P, const double *dzmean,
+                       const double *dzstd, double *dout);
+int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
+                       const double *dmodels, int64_t M, double *dmean, double *dstd);
+int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
+                       int64_t Ku, double *dmeans, int32_t *dcounts32);
+int compute_offset_device(plda_handle *h);
+
+// simple RAII device temp for host-pointer entry points
+struct Tmp {
+  void *p = nullptr;
+  ~Tmp() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+static int upload(plda_handle *h, Tmp &t, const void *src, size_t bytes) {
+  PLDA_HIP(h, t.alloc(bytes));
+  if (bytes) PLDA_HIP(h, hipMemcpyAsync(t.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return PLDA_OK;
+}
+
+static int set_device(plda_handle *h) {
+  PLDA_HIP(h, hipSetDevice(h->device));
+  return PLDA_OK;
+}
+
+// Plda::SmoothWithinClassCovariance: psi /= wc, transform rows *= wc^-1/2
+__global__ void smooth_kernel(double *__restrict__ T, double *__restrict__ psi, int Dout, int Din, double f) {
+  const int o = blockIdx.x;
+  const double wc = 1.0 + f * psi[o];
+  const double sc = 1.0 / sqrt(wc);
+  for (int d = threadIdx.x; d < Din; d += blockDim.x) T[(size_t)o * Din + d] *= sc;
+  __syncthreads();
+  if (threadIdx.x == 0) psi[o] = psi[o] / wc;
+}
+
+}  // namespace plda
+
+using namespace plda;
+
+extern "C" {
+
+int plda_abi_version(void) { return 1; }
+
+int plda_create(int device, plda_handle **out) {
+  if (!out) return fail(nullptr, PLDA_E_INVAL, "plda_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, PLDA_E_HIP, "plda_create: no HIP device available (%s); this engine has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= count) return fail(nullptr, PLDA_E_INVAL, "plda_create: device %d out of range [0,%d)", device, count);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, PLDA_E_HIP, "plda_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, PLDA_E_HIP, "plda_create: device %d is %s; libplda_hip is built for gfx950 only", device, prop.gcnArchName);
+  plda_handle *h = new (std::nothrow) plda_handle();
+  if (!h) return fail(nullptr, PLDA_E_HIP, "plda_create: out of host memory");
+  h->device = device;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
+  h->stream = h->own_stream;
+  *out = h;
+  return PLDA_OK;
+}
+
+int plda_destroy(plda_handle *h) {
+  if (!h) return PLDA_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
+                    &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
+                    &h->s_rscale, &h->s_cbias, &h->s_coef};
+  for (DevBuf *b : bufs) b->release();
+  for (auto &b : h->w) b.release();
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return PLDA_OK;
+}
+
+const char *plda_last_error(const plda_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int plda_set_stream(plda_handle *h, void *hip_stream) {
+  if (!h) return PLDA_E_INVAL;
+  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return PLDA_OK;
+}
+
+int plda_synchronize(plda_handle *h) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+// ---------------------------------------------------------------- fit
+int plda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
+                 int32_t iters) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return fit_device(h, dX, N, D, dlabels, K, iters);
+}
+
+int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels, int32_t iters) {
+  if (!h) return PLDA_E_INVAL;
+  if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
+  PLDA_TRY(set_device(h));
+  uint64_t mx = 0;
+  for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
+  if (mx >= (uint64_t)N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  const int64_t K = (int64_t)mx + 1;
+  Tmp dX, dL;
+  PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
+  PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
+  return fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), K, iters);
+}
+
+int plda_fit_timings(plda_handle *h, double out_ms[4]) {
+  if (!h || !out_ms) return PLDA_E_INVAL;
+  for (int i = 0; i < 4; ++i) out_ms[i] = h->fit_ms[i];
+  return PLDA_OK;
+}
+
+int plda_fit_num_classes(plda_handle *h, int64_t *K) {
+  if (!h || !K) return PLDA_E_INVAL;
+  *K = h->fit_K;
+  return PLDA_OK;
+}
+
+int plda_fit_get_stats(plda_handle *h, double *means, int64_t *counts, double *scatter, double *sum,
+                       double *W, double *B) {
+  if (!h) return PLDA_E_INVAL;
+  if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats: no fit has run on this handle");
+  PLDA_TRY(set_device(h));
+  const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
+  if (means) PLDA_HIP(h, hipMemcpyAsync(means, h->f_means.p, K * D * 8, hipMemcpyDeviceToHost, h->stream));
+  if (counts) PLDA_HIP(h, hipMemcpyAsync(counts, h->f_counts.p, K * 8, hipMemcpyDeviceToHost, h->stream));
+  if (scatter) PLDA_HIP(h, hipMemcpyAsync(scatter, h->f_scatter.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
+  if (sum) PLDA_HIP(h, hipMemcpyAsync(sum, h->f_sum.p, D * 8, hipMemcpyDeviceToHost, h->stream));
+  if (W) PLDA_HIP(h, hipMemcpyAsync(W, h->f_W.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
+  if (B) PLDA_HIP(h, hipMemcpyAsync(B, h->f_B.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+// ---------------------------------------------------------------- model
+int plda_get_dims(plda_handle *h, int32_t *Dout, int32_t *Din) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+  if (Dout) *Dout = h->Dout;
+  if (Din) *Din = h->Din;
+  return PLDA_OK;
+}
+
+int plda_get_model(plda_handle *h, double *mean, double *transform, double *psi, double *offset) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+  if (mean) std::memcpy(mean, h->h_mean.data(), h->h_mean.size() * 8);
+  if (transform) std::memcpy(transform, h->h_transform.data(), h->h_transform.size() * 8);
+  if (psi) std::memcpy(psi, h->h_psi.data(), h->h_psi.size() * 8);
+  if (offset) std::memcpy(offset, h->h_offset.data(), h->h_offset.size() * 8);
+  return PLDA_OK;
+}
+
+static int refresh_offset(plda_handle *h) {
+  // offset = -transform . mean on the device (Plda::ComputeDerivedVars), mirrored back to the host
+  PLDA_TRY(compute_offset_device(h));
+  h->h_offset.resize(h->Dout);
+  PLDA_HIP(h, hipMemcpyAsync(h->h_offset.data(), h->d_offset.p, (size_t)h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+int plda_set_model(plda_handle *h, int32_t Dout, int32_t Din, const double *mean, const double *transform,
+                   const double *psi) {
+  if (!h) return PLDA_E_INVAL;
+  if (Dout <= 0 || Din <= 0 || Dout > Din || !mean || !transform || !psi)
+    return fail(h, PLDA_E_INVAL, "set_model: bad argument");
+  PLDA_TRY(set_device(h));
+  h->Dout = Dout; h->Din = Din;
+  h->h_mean.assign(mean, mean + Din);
+  h->h_transform.assign(transform, transform + (size_t)Dout * Din);
+  h->h_psi.assign(psi, psi + Dout);
+  h->h_offset.assign(Dout, 0.0);
+  PLDA_TRY(model_to_device(h));
+  h->fitted = true;
+  return refresh_offset(h);
+}
+
+int plda_truncate(plda_handle *h, int32_t targetdim) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+  if (targetdim <= 0 || targetdim > h->Dout) return fail(h, PLDA_E_INVAL, "truncate: targetdim %d not in [1,%d]", targetdim, h->Dout);
+  PLDA_TRY(set_device(h));
+  h->Dout = targetdim;
+  h->h_transform.resize((size_t)targetdim * h->Din);
+  h->h_psi.resize(targetdim);
+  h->h_offset.resize(targetdim);
+  return PLDA_OK;  // device arrays are row-major prefixes: nothing to move
+}
+
+int plda_smooth(plda_handle *h, double factor) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+  if (!(factor >= 0.0 && factor <= 1.0)) return fail(h, PLDA_E_INVAL, "smooth: factor must be in [0,1]");
+  PLDA_TRY(set_device(h));
+  smooth_kernel<<<h->Dout, 256, 0, h->stream>>>(h->d_transform.as<double>(), h->d_psi.as<double>(), h->Dout, h->Din, factor);
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, (size_t)h->Dout * h->Din * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+  return refresh_offset(h);
+}
+
+// ---------------------------------------------------------------- transform
+int plda_transform_rows_dev(plda_handle *h, const double *dXbar, int64_t R, int32_t Din, const int32_t *dn,
+                            int32_t n_uniform, double *dout) {
+  if (!h) return PLDA_E_INVAL;
+  if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
+  PLDA_TRY(set_device(h));
+  return transform_rows_device(h, dXbar, R, Din, dn, n_uniform, dout);
+}
+
+int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t Din, const int32_t *num_examples,
+                        int32_t n_uniform, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
+  if (R <= 0) return PLDA_OK;
+  if (!Xbar || !out) return fail(h, PLDA_E_INVAL, "transform_rows: bad argument");
+  if (!num_examples && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
+  PLDA_TRY(set_device(h));
+  Tmp dX, dN, dO;
+  PLDA_TRY(upload(h, dX, Xbar, (size_t)R * Din * 8));
+  if (num_examples) PLDA_TRY(upload(h, dN, num_examples, (size_t)R * 4));
+  PLDA_HIP(h, dO.alloc((size_t)R * h->Dout * 8));
+  PLDA_TRY(transform_rows_device(h, dX.as<double>(), R, Din, num_examples ? dN.as<int32_t>() : nullptr, n_uniform, dO.as<double>()));
+  PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)R * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Din, const uint64_t *labels,
+                          uint64_t *out_labels, int64_t *out_counts, double *out_vecs, int64_t *Ku) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
+  if (!Ku) return fail(h, PLDA_E_INVAL, "transform_groups: Ku is NULL");
+  if (N <= 0) { *Ku = 0; return PLDA_OK; }
+  if (!X || !labels || !out_labels || !out_counts || !out_vecs) return fail(h, PLDA_E_INVAL, "transform_groups: bad argument");
+  if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
+  PLDA_TRY(set_device(h));
+  // label compaction (index bookkeeping; the reference does it with std::map, pldamodule.cpp:118,147-156)
+  std::vector<uint64_t> uniq(labels, labels + N);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  const int64_t G = (int64_t)uniq.size();
+  if (G > *Ku) { *Ku = G; return fail(h, PLDA_E_CAPACITY, "transform_groups: %lld groups > capacity", (long long)G); }
+  std::vector<uint64_t> dense((size_t)N);
+  for (int64_t r = 0; r < N; ++r)
+    dense[r] = (uint64_t)(std::lower_bound(uniq.begin(), uniq.end(), labels[r]) - uniq.begin());
+  Tmp dX, dL, dM, dC, dO;
+  PLDA_TRY(upload(h, dX, X, (size_t)N * Din * 8));
+  PLDA_TRY(upload(h, dL, dense.data(), (size_t)N * 8));
+  PLDA_HIP(h, dM.alloc((size_t)G * Din * 8));
+  PLDA_HIP(h, dC.alloc((size_t)G * 4));
+  PLDA_HIP(h, dO.alloc((size_t)G * h->Dout * 8));
+  PLDA_TRY(group_means_device(h, dX.as<double>(), N, Din, dL.as<uint64_t>(), G, dM.as<double>(), dC.as<int32_t>()));
+  PLDA_TRY(transform_rows_device(h, dM.as<double>(), G, Din, dC.as<int32_t>(), 0, dO.as<double>()));
+  std::vector<int32_t> c32((size_t)G);
+  PLDA_HIP(h, hipMemcpyAsync(c32.data(), dC.p, (size_t)G * 4, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(out_vecs, dO.p, (size_t)G * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  for (int64_t g = 0; g < G; ++g) { out_labels[g] = uniq[g]; out_counts[g] = c32[g]; }
+  *Ku = G;
+  return PLDA_OK;
+}
+
+// ---------------------------------------------------------------- score
+int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform, int64_t M,
+                          const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
+                          int64_t ld_out) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return score_matrix_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out);
+}
+
+int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, int32_t n_uniform, int64_t M,
+                      const double *V, int64_t Nt, const double *zmean, const double *zstd, float *out,
+                      int64_t ld_out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
+  if (M <= 0 || Nt <= 0) return PLDA_OK;
+  if (!U || !V || !out || ld_out < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
+  PLDA_TRY(set_device(h));
+  const int D = h->Dout;
+  Tmp dV, dU, dN, dZm, dZs, dO;
+  PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
+  // row slabs so that the device score block stays <= 1 GiB
+  int64_t slab = std::max<int64_t>(128, ((1ll << 30) / 4 / Nt) / 128 * 128);
+  slab = std::min(slab, round_up(M, 128));
+  PLDA_HIP(h, dU.alloc((size_t)slab * D * 8));
+  PLDA_HIP(h, dO.alloc((size_t)slab * Nt * 4));
+  if (n_enrol) PLDA_HIP(h, dN.alloc((size_t)slab * 4));
+  if (zmean && zstd) { PLDA_HIP(h, dZm.alloc((size_t)slab * 8)); PLDA_HIP(h, dZs.alloc((size_t)slab * 8)); }
+  for (int64_t r0 = 0; r0 < M; r0 += slab) {
+    const int64_t m = std::min(slab, M - r0);
+    PLDA_HIP(h, hipMemcpyAsync(dU.p, U + r0 * D, (size_t)m * D * 8, hipMemcpyHostToDevice, h->stream));
+    if (n_enrol) PLDA_HIP(h, hipMemcpyAsync(dN.p, n_enrol + r0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    if (zmean && zstd) {
+      PLDA_HIP(h, hipMemcpyAsync(dZm.p, zmean + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+      PLDA_HIP(h, hipMemcpyAsync(dZs.p, zstd + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
+                                 dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
+                                 (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt));
+    PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
+                                 (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  h->last_M = M;
+  return PLDA_OK;
+}
+
+int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k) {
+  if (!h) return PLDA_E_INVAL;
+  if (M) *M = h->last_M;
+  if (Nt) *Nt = h->last_Nt;
+  if (gemm_k) *gemm_k = h->last_k;
+  return PLDA_OK;
+}
+
+int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, int64_t M, const double *V,
+                     int64_t Nt, const int64_t *e_idx, const int64_t *t_idx, int64_t P, const double *zmean,
+                     const double *zstd, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score: model not fitted");
+  if (P <= 0) return PLDA_OK;
+  if (!U || !n_enrol || !V || !e_idx || !t_idx || !out || M <= 0 || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: bad argument");
+  for (int64_t p = 0; p < P; ++p)
+    if (e_idx[p] < 0 || e_idx[p] >= M || t_idx[p] < 0 || t_idx[p] >= Nt)
+      return fail(h, PLDA_E_INVAL, "score_pairs: trial %lld indexes outside the enrol/test sets", (long long)p);
+  for (int64_t i = 0; i < M; ++i)
+    if (n_enrol[i] <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: num_examples must be > 0");
+  PLDA_TRY(set_device(h));
+  const int D = h->Dout;
+  Tmp dU, dN, dV, dE, dT, dZm, dZs, dO;
+  PLDA_TRY(upload(h, dU, U, (size_t)M * D * 8));
+  PLDA_TRY(upload(h, dN, n_enrol, (size_t)M * 4));
+  PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
+  PLDA_TRY(upload(h, dE, e_idx, (size_t)P * 8));
+  PLDA_TRY(upload(h, dT, t_idx, (size_t)P * 8));
+  const bool zn = zmean && zstd;
+  if (zn) { PLDA_TRY(upload(h, dZm, zmean, (size_t)M * 8)); PLDA_TRY(upload(h, dZs, zstd, (size_t)M * 8)); }
+  PLDA_HIP(h, dO.alloc((size_t)P * 8));
+  PLDA_TRY(score_pairs_device(h, dU.as<double>(), dN.as<int32_t>(), dV.as<double>(), dE.as<int64_t>(),
+                              dT.as<int64_t>(), P, zn ? dZm.as<double>() : nullptr,
+                              zn ? dZs.as<double>() : nullptr, dO.as<double>()));
+  PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+// ---------------------------------------------------------------- z-norm
+int plda_znorm_stats_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples, int32_t Din,
+                         const double *dmodels, int64_t M, double *dout_mean, double *dout_std) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return znorm_stats_device(h, dbkg, Nb, num_examples, Din, dmodels, M, dout_mean, dout_std);
+}
+
+int plda_znorm_stats(plda_handle *h, const double *bkg, int64_t Nb, int32_t num_examples, int32_t Din,
+                     const double *models, int64_t M, double *out_mean, double *out_std) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
+  if (!bkg || !models || !out_mean || !out_std || Nb <= 0 || M <= 0) return fail(h, PLDA_E_INVAL, "norm: bad argument");
+  if (Din != h->Din) return fail(h, PLDA_E_INVAL, "norm: feature dim %d != model dim %d", Din, h->Din);
+  PLDA_TRY(set_device(h));
+  Tmp dB, dM, dMean, dStd;
+  PLDA_TRY(upload(h, dB, bkg, (size_t)Nb * Din * 8));
+  PLDA_TRY(upload(h, dM, models, (size_t)M * h->Dout * 8));
+  PLDA_HIP(h, dMean.alloc((size_t)M * 8));
+  PLDA_HIP(h, dStd.alloc((size_t)M * 8));
+  PLDA_TRY(znorm_stats_device(h, dB.as<double>(), Nb, num_examples, Din, dM.as<double>(), M, dMean.as<double>(),
+                              dStd.as<double>()));
+  PLDA_HIP(h, hipMemcpyAsync(out_mean, dMean.p, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(out_std, dStd.p, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+}  // extern "C"

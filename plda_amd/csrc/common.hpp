@@ -1,0 +1,113 @@
+// plda_amd/csrc/common.hpp -- handle, error plumbing and device buffers shared by
+// the translation units of libplda_hip.so (gfx950 only; no CPU fallback).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/plda_hip.h"
+
+namespace plda {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace plda
+
+struct plda_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- model (Kaldi `Plda`, pldamodule.cpp:29): host mirror + device copies ----
+  bool fitted = false;
+  int Dout = 0, Din = 0;
+  std::vector<double> h_mean, h_transform, h_psi, h_offset;
+  plda::DevBuf d_mean, d_transform, d_psi, d_offset;
+
+  // ---- fit state kept for plda_fit_get_stats ----
+  int64_t fit_K = 0;
+  int fit_D = 0;
+  plda::DevBuf f_means, f_counts, f_scatter, f_sum, f_W, f_B;
+  double fit_ms[4] = {0, 0, 0, 0};
+
+  // ---- scoring workspace ----
+  plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias, s_coef;
+  int64_t last_M = 0, last_Nt = 0;
+  int last_k = 0;
+
+  // ---- general scratch (fit / transform / znorm) ----
+  plda::DevBuf w[16];
+};
+
+namespace plda {
+
+int fail(plda_handle *h, int code, const char *fmt, ...);
+int hip_fail(plda_handle *h, hipError_t e, const char *what, const char *file, int line);
+
+#define PLDA_HIP(h, expr)                                                          \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) return plda::hip_fail((h), _e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define PLDA_TRY(...)             \
+  do {                            \
+    int _rc = (__VA_ARGS__);      \
+    if (_rc != PLDA_OK) return _rc; \
+  } while (0)
+
+#define PLDA_LAUNCH_CHECK(h) PLDA_HIP(h, hipGetLastError())
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// upload model arrays held in h->h_* to the device copies
+int model_to_device(plda_handle *h);
+
+// ---- linalg.hip (fp64 building blocks; all enqueue on h->stream) ----
+// C[M,N] (ldc) = alpha * sum_k A(m,k) * kw[k]? * B(k,n) + beta * C
+// A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; exactly one of (sam,sak)
+// and one of (sbk,sbn) must be 1.  kw nullable.  Uses split-K with a
+// deterministic second-stage reduction when K is long and M*N small.
+int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
+             int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,
+             const double *kw, double beta, double *C, int64_t ldc);
+// in-place lower Cholesky (upper triangle zeroed); *dflag (device int) set to 1 on failure
+int cholesky_f64(plda_handle *h, double *A, int D, int *dflag);
+// X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
+int tri_invert_f64(plda_handle *h, const double *L, double *X, int D);
+// symmetric eigendecomposition of G (row-major, destroyed): eigenvalues sorted
+// descending in s[D] (floored at 0), eigenvectors in the COLUMNS of U (row-major).
+int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *U, int *sweeps_out);
+// simultaneous diagonalisation of (W,B): T W T^T = I, T B T^T = diag(psi);
+// T [D,D], Tinv = T^{-1} (nullable), psi[D].  W,B are not modified.
+int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T,
+                double *Tinv, double *psi);
+
+// ---- fit.hip ----
+int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels,
+               int64_t K, int iters);
+
+// ---- score.hip ----
+int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din,
+                          const int32_t *dn, int n_uniform, double *dout);
+
+}  // namespace plda

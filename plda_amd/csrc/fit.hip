@@ -1,0 +1,442 @@
+// plda_amd/csrc/fit.hip -- PLDA estimation on gfx950, fp64.
+//
+// Replaces MPlda_fit (/root/reference/src/pldamodule.cpp:42-109):
+//   :76-92   label grouping            -> K1a  stable LSD radix sort of (label,row)
+//   :94-98   AddSamples(1/n_k, rows_k) -> K1   segmented centroid accumulation
+//                                         K2   weighted SYRK  X^T diag(1/n_label) X  -  M^T M
+//   :100     stats.Sort()              -> not needed (no per-distinct-n inversions below)
+//   :102-106 Estimate(iters)           -> K3   EM in the simultaneously-diagonalised basis
+//                                              (identical maths to A.2)
+//            GetOutput                 -> K6/K7 Cholesky + triangular inverse + Jacobi eig
+#include "common.hpp"
+
+#include <chrono>
+
+namespace plda {
+
+// ------------------------------------------------------------------------------------
+// K1a: stable LSD radix sort (8-bit digits) of row ids by label
+// ------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;                       // items per thread per block
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;    // 4096 keys per block
+
+__global__ void labels_check_kernel(const uint64_t *__restrict__ labels, int64_t N, int64_t K,
+                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                    int *__restrict__ counts, int *__restrict__ bad) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const uint64_t l = labels[r];
+  if (l >= (uint64_t)K) { *bad = 1; keys[r] = 0; vals[r] = (uint32_t)r; return; }
+  keys[r] = (uint32_t)l;
+  vals[r] = (uint32_t)r;
+  atomicAdd(counts + l, 1);
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t N,
+                                                             int shift, int nblocks,
+                                                             int *__restrict__ hist /*[256][nblocks]*/) {
+  __shared__ int lh[256];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    const int64_t idx = base + it * RS_THREADS + threadIdx.x;
+    if (idx < N) atomicAdd(&lh[(keys[idx] >> shift) & 255], 1);
+  }
+  __syncthreads();
+  hist[threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
+}
+
+// exclusive scan of a flat int array by one workgroup (n up to a few million)
+__global__ __launch_bounds__(1024) void scan_kernel(int *__restrict__ data, int64_t n) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t idx = base + t;
+    const int v = idx < n ? data[idx] : 0;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int carry = carry_s;
+    if (idx < n) data[idx] = carry + woff + x - v;
+    __syncthreads();
+    if (t == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
+    const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t *__restrict__ kout,
+    uint32_t *__restrict__ vout, int64_t N, int shift, int nblocks, const int *__restrict__ hist) {
+  __shared__ int base_s[256];      // running global position of each digit for this block
+  __shared__ int wcount[4][256];   // per-wave digit counts of the current sub-tile
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  base_s[t] = hist[t * nblocks + blockIdx.x];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    const int64_t idx = base + it * RS_THREADS + t;
+    const bool valid = idx < N;
+    const uint32_t key = valid ? kin[idx] : 0u;
+    const int digit = valid ? (int)((key >> shift) & 255) : 256;  // 256 = inactive
+    for (int d = lane; d < 256; d += 64) wcount[wave][d] = 0;
+    __syncthreads();
+    // peers = lanes of this wave with the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long m = __ballot((digit >> bit) & 1);
+      peers &= ((digit >> bit) & 1) ? m : ~m;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int rank_in_wave = __popcll(peers & lt);
+    if (valid && rank_in_wave == 0) wcount[wave][digit] = __popcll(peers);
+    __syncthreads();
+    int pos = 0;
+    if (valid) {
+      int woff = 0;
+      for (int w = 0; w < wave; ++w) woff += wcount[w][digit];
+      pos = base_s[digit] + woff + rank_in_wave;
+    }
+    __syncthreads();
+    {
+      const int tot = wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
+      base_s[t] += tot;
+    }
+    if (valid) { kout[pos] = key; vout[pos] = vin[idx]; }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K1: centroids.  One workgroup per speaker; threads span the feature dimension so
+// every row read is one contiguous D*8-byte burst; rows are summed in ascending row
+// order (deterministic).  Also emits the per-row weight 1/n_label used by K2.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void centroid_kernel(const double *__restrict__ X, int D,
+                                                       const uint32_t *__restrict__ perm,
+                                                       const int *__restrict__ offsets,
+                                                       double *__restrict__ means,
+                                                       double *__restrict__ roww) {
+  const int k = blockIdx.x;
+  const int beg = offsets[k], end = offsets[k + 1];
+  const int n = end - beg;
+  const double inv = 1.0 / (double)n;
+  for (int d0 = threadIdx.x; d0 < D; d0 += blockDim.x) {
+    double acc = 0.0;
+    int r = beg;
+    for (; r + 4 <= end; r += 4) {
+      const double a = X[(int64_t)perm[r] * D + d0], b = X[(int64_t)perm[r + 1] * D + d0];
+      const double c = X[(int64_t)perm[r + 2] * D + d0], e = X[(int64_t)perm[r + 3] * D + d0];
+      acc += a; acc += b; acc += c; acc += e;
+    }
+    for (; r < end; ++r) acc += X[(int64_t)perm[r] * D + d0];
+    means[(int64_t)k * D + d0] = acc * inv;
+  }
+  for (int r = beg + threadIdx.x; r < end; r += blockDim.x) roww[perm[r]] = inv;
+}
+
+// sum_d = sum_k w_k m_kd (w_k = 1/n_k); class_weight = sum_k w_k.  One block, deterministic.
+__global__ __launch_bounds__(256) void class_sum_kernel(const double *__restrict__ means,
+                                                        const int *__restrict__ offsets, int64_t K, int D,
+                                                        double *__restrict__ sum, double *__restrict__ mu,
+                                                        double *__restrict__ scalars /*[0]=class_weight*/) {
+  __shared__ double red[256];
+  double cw = 0.0;
+  for (int64_t k = threadIdx.x; k < K; k += blockDim.x) cw += 1.0 / (double)(offsets[k + 1] - offsets[k]);
+  red[threadIdx.x] = cw;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double class_weight = red[0];
+  if (threadIdx.x == 0) scalars[0] = class_weight;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    double acc = 0.0;
+    for (int64_t k = 0; k < K; ++k) acc += means[k * D + d] / (double)(offsets[k + 1] - offsets[k]);
+    sum[d] = acc;
+    mu[d] = acc / class_weight;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K3 helpers
+// ------------------------------------------------------------------------------------
+// Mc = means - mu
+__global__ void center_kernel(const double *__restrict__ means, const double *__restrict__ mu, int64_t K,
+                              int D, double *__restrict__ Mc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < K * D) Mc[idx] = means[idx] - mu[idx % D];
+}
+
+// Y1 = sqrt(w_k) c_kd p_kd ; Y2 = sqrt(w_k n_k) (1 - c_kd) p_kd   (in place: P -> Y1, Y2)
+__global__ void em_scale_kernel(const double *P, const int *__restrict__ offsets,
+                                const double *__restrict__ psi, int64_t K, int D, double *Y1, double *Y2) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * D) return;
+  const int64_t k = idx / D;
+  const int d = (int)(idx % D);
+  const double n = (double)(offsets[k + 1] - offsets[k]);
+  const double w = 1.0 / n;
+  const double ps = psi[d];
+  const double c = n * ps / (1.0 + n * ps);
+  const double p = P[idx];
+  Y1[idx] = sqrt(w) * c * p;
+  Y2[idx] = sqrt(w * n) * (1.0 - c) * p;
+}
+
+// db_d = sum_k w_k psi_d/(1+n_k psi_d) ; dw_d = sum_k w_k n_k psi_d/(1+n_k psi_d); added to diagonals
+__global__ __launch_bounds__(256) void em_diag_kernel(const int *__restrict__ offsets,
+                                                      const double *__restrict__ psi, int64_t K, int D,
+                                                      double *__restrict__ Bt, double *__restrict__ Wt) {
+  const int d = blockIdx.x;
+  __shared__ double rb[256], rw[256];
+  const double ps = psi[d];
+  double ab = 0.0, aw = 0.0;
+  for (int64_t k = threadIdx.x; k < K; k += blockDim.x) {
+    const double n = (double)(offsets[k + 1] - offsets[k]);
+    const double mx = ps / (1.0 + n * ps);
+    ab += mx / n;
+    aw += mx;
+  }
+  rb[threadIdx.x] = ab; rw[threadIdx.x] = aw;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { rb[threadIdx.x] += rb[threadIdx.x + o]; rw[threadIdx.x] += rw[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Bt[(size_t)d * D + d] += rb[0];
+    Wt[(size_t)d * D + d] += rw[0];
+  }
+}
+
+// W = (S + Wu) / cntW ; B = Bu / cntB, symmetrised
+__global__ void em_mstep_kernel(const double *__restrict__ S, const double *__restrict__ Wu,
+                                const double *__restrict__ Bu, int D, double cntW, double cntB,
+                                double *__restrict__ W, double *__restrict__ B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * D) return;
+  const int i = idx / D, j = idx % D;
+  const size_t a = (size_t)i * D + j, b = (size_t)j * D + i;
+  W[a] = (0.5 * (S[a] + S[b]) + 0.5 * (Wu[a] + Wu[b])) / cntW;
+  B[a] = 0.5 * (Bu[a] + Bu[b]) / cntB;
+}
+
+__global__ void set_identity2_kernel(double *W, double *B, int D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < D * D) { const double v = (idx / D == idx % D) ? 1.0 : 0.0; W[idx] = v; B[idx] = v; }
+}
+
+// offset = -T mean (Plda::ComputeDerivedVars), one wave per output row
+__global__ void offset_kernel(const double *__restrict__ T, const double *__restrict__ mean, int Dout, int Din,
+                              double *__restrict__ offset) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (o >= Dout) return;
+  double acc = 0.0;
+  for (int d = lane; d < Din; d += 64) acc += T[(size_t)o * Din + d] * mean[d];
+  for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+  if (lane == 0) offset[o] = -acc;
+}
+
+__global__ void counts_to_i64_kernel(const int *__restrict__ offsets, int64_t K, int64_t *__restrict__ counts) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) counts[k] = offsets[k + 1] - offsets[k];
+}
+
+__global__ void counts_to_i32_kernel(const int *__restrict__ offsets, int64_t K, int32_t *__restrict__ counts) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) counts[k] = offsets[k + 1] - offsets[k];
+}
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int compute_offset_device(plda_handle *h) {
+  offset_kernel<<<(unsigned)ceil_div(h->Dout, 4), 256, 0, h->stream>>>(
+      h->d_transform.as<double>(), h->d_mean.as<double>(), h->Dout, h->Din, h->d_offset.as<double>());
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// Sort rows by label: outputs perm (row ids grouped by label, ascending row within label)
+// and offsets[K+1] in h->w[0], h->w[1].
+static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int64_t K, uint32_t **perm_out,
+                         int **offsets_out) {
+  if (N >= (1ll << 31)) return fail(h, PLDA_E_INVAL, "fit: N too large");
+  const int nblocks = (int)ceil_div(N, RS_CHUNK);
+  PLDA_HIP(h, h->w[0].reserve((size_t)N * 4 * 4));                  // keys a/b, vals a/b
+  PLDA_HIP(h, h->w[1].reserve((size_t)(K + 2) * 4 + 64));          // counts -> offsets (+ bad flag)
+  PLDA_HIP(h, h->w[2].reserve((size_t)256 * nblocks * 4));          // digit histograms
+  uint32_t *ka = h->w[0].as<uint32_t>(), *va = ka + N, *kb = va + N, *vb = kb + N;
+  int *offsets = h->w[1].as<int>();
+  int *bad = offsets + K + 1;
+  int *hist = h->w[2].as<int>();
+  PLDA_HIP(h, hipMemsetAsync(offsets, 0, (size_t)(K + 2) * 4, h->stream));
+  labels_check_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, h->stream>>>(dlabels, N, K, ka, va, offsets, bad);
+  PLDA_LAUNCH_CHECK(h);
+  int bits = 1;
+  while ((1ll << bits) < K) bits++;
+  for (int shift = 0; shift < bits; shift += 8) {
+    rs_hist_kernel<<<nblocks, RS_THREADS, 0, h->stream>>>(ka, N, shift, nblocks, hist);
+    scan_kernel<<<1, 1024, 0, h->stream>>>(hist, (int64_t)256 * nblocks);
+    rs_scatter_kernel<<<nblocks, RS_THREADS, 0, h->stream>>>(ka, va, kb, vb, N, shift, nblocks, hist);
+    PLDA_LAUNCH_CHECK(h);
+    std::swap(ka, kb);
+    std::swap(va, vb);
+  }
+  int hbad = 0;
+  PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
+  // counts -> exclusive offsets (K+1 entries: the (K+1)-th input is 0 so offsets[K] = N)
+  scan_kernel<<<1, 1024, 0, h->stream>>>(offsets, K + 1);
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (hbad) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  *perm_out = va;
+  *offsets_out = offsets;
+  return PLDA_OK;
+}
+
+int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K,
+               int iters) {
+  if (!dX || !dlabels || N <= 0 || D <= 0 || iters < 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
+  if (K == 1)
+    return fail(h, PLDA_E_ONE_SPEAKER,
+                "Number of speakers is 1. Aborting PLDA esimation, at least two speakers are required!");
+  if (K <= 0 || K > N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
+  const size_t DD = (size_t)D * D;
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const double t0 = now_ms();
+
+  // ---------------- statistics (K1a, K1, K2) ----------------
+  uint32_t *perm = nullptr;
+  int *offsets = nullptr;
+  PLDA_TRY(sort_by_label(h, dlabels, N, K, &perm, &offsets));
+  {
+    // every label 0..K-1 must occur (dense): check min count on host-free path by offsets diff
+    // (an empty class would give n = 0 -> inf weight); verified via counts kernel below.
+  }
+  PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
+  PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
+  PLDA_HIP(h, h->f_scatter.reserve(DD * 8));
+  PLDA_HIP(h, h->f_sum.reserve((size_t)D * 8));
+  PLDA_HIP(h, h->f_W.reserve(DD * 8));
+  PLDA_HIP(h, h->f_B.reserve(DD * 8));
+  PLDA_HIP(h, h->w[3].reserve((size_t)N * 8));               // row weights
+  PLDA_HIP(h, h->w[4].reserve((size_t)D * 8 * 2 + 64));       // mu, scalars
+  double *means = h->f_means.as<double>();
+  double *S = h->f_scatter.as<double>();
+  double *sum = h->f_sum.as<double>();
+  double *W = h->f_W.as<double>(), *B = h->f_B.as<double>();
+  double *roww = h->w[3].as<double>();
+  double *mu = h->w[4].as<double>();
+  double *scalars = mu + D;
+  counts_to_i64_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, h->stream>>>(offsets, K, h->f_counts.as<int64_t>());
+  {
+    std::vector<int> hoff((size_t)K + 1);
+    PLDA_HIP(h, hipMemcpyAsync(hoff.data(), offsets, (size_t)(K + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t k = 0; k < K; ++k)
+      if (hoff[k + 1] == hoff[k]) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1 (label %lld unused)", (long long)k);
+  }
+  centroid_kernel<<<(unsigned)K, 256, 0, h->stream>>>(dX, D, perm, offsets, means, roww);
+  PLDA_LAUNCH_CHECK(h);
+  class_sum_kernel<<<1, 256, 0, h->stream>>>(means, offsets, K, D, sum, mu, scalars);
+  PLDA_LAUNCH_CHECK(h);
+  // offset_scatter = X^T diag(1/n_label) X - sum_k (n_k w_k) m_k m_k^T,  n_k w_k = 1
+  PLDA_TRY(gemm_f64(h, D, D, N, 1.0, dX, 1, D, dX, D, 1, roww, 0.0, S, D));
+  PLDA_TRY(gemm_f64(h, D, D, K, -1.0, means, 1, D, means, D, 1, nullptr, 1.0, S, D));
+  double class_weight = 0.0;
+  PLDA_HIP(h, hipMemcpyAsync(&class_weight, scalars, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const double example_weight = (double)K;  // sum_k w_k n_k with w_k = 1/n_k
+  const double t1 = now_ms();
+
+  // ---------------- EM (K3) ----------------
+  PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3));   // Mc / P, Y1, Y2
+  PLDA_HIP(h, h->w[6].reserve(DD * 8 * 7 + (size_t)D * 8));
+  double *Mc = h->w[5].as<double>(), *Y1 = Mc + (size_t)K * D, *Y2 = Y1 + (size_t)K * D;
+  double *T = h->w[6].as<double>(), *Tinv = T + DD, *Bt = Tinv + DD, *Wt = Bt + DD, *tmp = Wt + DD,
+         *Bu = tmp + DD, *Wu = Bu + DD, *psi = Wu + DD;
+  const unsigned gDD = (unsigned)ceil_div((int64_t)DD, 256);
+  const unsigned gKD = (unsigned)ceil_div(K * (int64_t)D, 256);
+  set_identity2_kernel<<<gDD, 256, 0, h->stream>>>(W, B, D);
+  center_kernel<<<gKD, 256, 0, h->stream>>>(means, mu, K, D, Mc);
+  PLDA_LAUNCH_CHECK(h);
+  const double cntW = (example_weight - class_weight) + class_weight;  // = K
+  const double cntB = class_weight;
+  for (int it = 0; it < iters; ++it) {
+    PLDA_TRY(simdiag_f64(h, W, B, D, T, Tinv, psi));
+    // P = Mc T^T  (reuse Y1 as P, then scale into Y1/Y2)
+    PLDA_TRY(gemm_f64(h, K, D, D, 1.0, Mc, D, 1, T, 1, D, nullptr, 0.0, Y2, D));
+    em_scale_kernel<<<gKD, 256, 0, h->stream>>>(Y2, offsets, psi, K, D, Y1, Y2);
+    PLDA_LAUNCH_CHECK(h);
+    PLDA_TRY(gemm_f64(h, D, D, K, 1.0, Y1, 1, D, Y1, D, 1, nullptr, 0.0, Bt, D));
+    PLDA_TRY(gemm_f64(h, D, D, K, 1.0, Y2, 1, D, Y2, D, 1, nullptr, 0.0, Wt, D));
+    em_diag_kernel<<<D, 256, 0, h->stream>>>(offsets, psi, K, D, Bt, Wt);
+    PLDA_LAUNCH_CHECK(h);
+    // un-project: Bu = Tinv Bt Tinv^T ; Wu = Tinv Wt Tinv^T
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Tinv, D, 1, Bt, D, 1, nullptr, 0.0, tmp, D));
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, Tinv, 1, D, nullptr, 0.0, Bu, D));
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Tinv, D, 1, Wt, D, 1, nullptr, 0.0, tmp, D));
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, Tinv, 1, D, nullptr, 0.0, Wu, D));
+    em_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Wu, Bu, D, cntW, cntB, W, B);
+    PLDA_LAUNCH_CHECK(h);
+  }
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const double t2 = now_ms();
+
+  // ---------------- GetOutput ----------------
+  PLDA_HIP(h, h->d_mean.reserve((size_t)D * 8));
+  PLDA_HIP(h, h->d_transform.reserve(DD * 8));
+  PLDA_HIP(h, h->d_psi.reserve((size_t)D * 8));
+  PLDA_HIP(h, h->d_offset.reserve((size_t)D * 8));
+  PLDA_TRY(simdiag_f64(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>()));
+  PLDA_HIP(h, hipMemcpyAsync(h->d_mean.p, mu, (size_t)D * 8, hipMemcpyDeviceToDevice, h->stream));
+  h->Dout = D; h->Din = D;
+  PLDA_TRY(compute_offset_device(h));
+  h->h_mean.resize(D); h->h_transform.resize(DD); h->h_psi.resize(D); h->h_offset.resize(D);
+  PLDA_HIP(h, hipMemcpyAsync(h->h_mean.data(), h->d_mean.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, DD * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(h->h_offset.data(), h->d_offset.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const double t3 = now_ms();
+  h->fitted = true;
+  h->fit_K = K; h->fit_D = D;
+  h->fit_ms[0] = t1 - t0; h->fit_ms[1] = t2 - t1; h->fit_ms[2] = t3 - t2; h->fit_ms[3] = (double)iters;
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Mplda_transform grouping (pldamodule.cpp:139-168): labels are arbitrary u64 here, so
+// the host compacts them (sorted unique) and the device reuses K1a/K1.
+// ------------------------------------------------------------------------------------
+int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
+                       int64_t Ku, double *dmeans, int32_t *dcounts32) {
+  uint32_t *perm = nullptr;
+  int *offsets = nullptr;
+  PLDA_TRY(sort_by_label(h, ddense, N, Ku, &perm, &offsets));
+  PLDA_HIP(h, h->w[3].reserve((size_t)N * 8));
+  centroid_kernel<<<(unsigned)Ku, 256, 0, h->stream>>>(dX, D, perm, offsets, dmeans, h->w[3].as<double>());
+  PLDA_LAUNCH_CHECK(h);
+  counts_to_i32_kernel<<<(unsigned)ceil_div(Ku, 256), 256, 0, h->stream>>>(offsets, Ku, dcounts32);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+}  // namespace plda

@@ -1,0 +1,421 @@
+// plda_amd/csrc/linalg.hip -- fp64 building blocks of the PLDA estimator on gfx950.
+//
+// These replace the Kaldi matrix-library / ATLAS calls that the reference reaches
+// through PldaStats / PldaEstimator: AddMat2 (syrk), AddMatMat
+// (gemm), AddMat2Sp (congruence), TpMatrix::Cholesky / Invert, SpMatrix::Eig + SortSvd.
+//   gemm_f64      v_mfma_f64_16x16x4_f64, LDS-staged 64x64 tiles, optional per-k
+//                 weights (weighted SYRK X^T diag(w) X), deterministic split-K
+//   cholesky_f64  right-looking, one workgroup, column staged in LDS
+//   tri_invert    forward substitution, one thread per column
+//   sym_eig_f64   one-sided (Hestenes) Jacobi with round-robin pair ordering, one
+//                 wave per row pair, one launch per tournament round
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace plda {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------
+// gemm_f64
+// ------------------------------------------------------------------------------------
+constexpr int GB = 64;    // block tile (square)
+constexpr int GK = 16;    // k per LDS stage
+constexpr int LDK = 17;   // leading dim of an [m][k] tile (k-contiguous source)
+constexpr int LDM = 80;   // leading dim of a  [k][m] tile (m-contiguous source)
+
+template <bool KC>
+__device__ __forceinline__ int tile_idx(int m, int k) { return KC ? m * LDK + k : k * LDM + m; }
+
+// load a 64 (m) x 16 (k) tile of op(A) into LDS; element (m,k) = A[m*sm + k*sk] * kw[k]
+template <bool KC>
+__device__ __forceinline__ void load_tile(double *lds, const double *__restrict__ A, int64_t sm,
+                                          int64_t sk, int64_t m0, int64_t M, int64_t k0, int64_t Kend,
+                                          const double *__restrict__ kw, int t) {
+  if (KC) {
+    const int k = t & 15;
+    const int64_t gk = k0 + k;
+    const double wk = (gk < Kend) ? (kw ? kw[gk] : 1.0) : 0.0;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int m = (t >> 4) + pass * 16;
+      const int64_t gm = m0 + m;
+      double v = 0.0;
+      if (gm < M && gk < Kend) v = A[gm * sm + gk * sk] * wk;
+      lds[tile_idx<true>(m, k)] = v;
+    }
+  } else {
+    const int m = t & 63;
+    const int64_t gm = m0 + m;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int k = (t >> 6) + pass * 4;
+      const int64_t gk = k0 + k;
+      double v = 0.0;
+      if (gm < M && gk < Kend) v = A[gm * sm + gk * sk] * (kw ? kw[gk] : 1.0);
+      lds[tile_idx<false>(m, k)] = v;
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, int64_t kchunk,
+                                                       double alpha, const double *__restrict__ A,
+                                                       int64_t sam, int64_t sak,
+                                                       const double *__restrict__ B, int64_t sbk,
+                                                       int64_t sbn, const double *__restrict__ kw,
+                                                       double beta, double *__restrict__ C, int64_t ldc,
+                                                       double *__restrict__ part) {
+  __shared__ double As[GK * LDM];
+  __shared__ double Bs[GK * LDM];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * GB, n0 = (int64_t)blockIdx.x * GB;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = min(K, kbeg + kchunk);
+
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  const int fi = lane & 15, fk = lane >> 4;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
+    load_tile<AKC>(As, A, sam, sak, m0, M, k0, kend, kw, t);
+    load_tile<BKC>(Bs, B, sbn, sbk, n0, N, k0, kend, nullptr, t);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) a[tm] = As[tile_idx<AKC>(wm * 32 + tm * 16 + fi, kk * 4 + fk)];
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) b[tn] = Bs[tile_idx<BKC>(wn * 32 + tn * 16 + fi, kk * 4 + fk)];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 32 + tm * 16 + (lane >> 4) + 4 * r;
+        const int64_t col = n0 + wn * 32 + tn * 16 + (lane & 15);
+        if (row < M && col < N) {
+          if (part) {
+            part[((int64_t)blockIdx.z * M + row) * N + col] = acc[tm][tn][r];
+          } else {
+            double *c = C + row * ldc + col;
+            *c = alpha * acc[tm][tn][r] + (beta != 0.0 ? beta * *c : 0.0);
+          }
+        }
+      }
+}
+
+__global__ void splitk_reduce_kernel(const double *__restrict__ part, int splits, int64_t M, int64_t N,
+                                     double alpha, double beta, double *__restrict__ C, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * N) return;
+  double s = 0.0;
+  for (int z = 0; z < splits; ++z) s += part[(int64_t)z * M * N + idx];
+  const int64_t row = idx / N, col = idx % N;
+  double *c = C + row * ldc + col;
+  *c = alpha * s + (beta != 0.0 ? beta * *c : 0.0);
+}
+
+int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
+             int64_t sak, const double *B, int64_t sbk, int64_t sbn, const double *kw, double beta,
+             double *C, int64_t ldc) {
+  if (M <= 0 || N <= 0) return PLDA_OK;
+  if (K <= 0) return fail(h, PLDA_E_INVAL, "gemm_f64: K <= 0");
+  const bool akc = (sak == 1), bkc = (sbk == 1);
+  if ((!akc && sam != 1) || (!bkc && sbn != 1))
+    return fail(h, PLDA_E_INVAL, "gemm_f64: operands need one unit stride");
+  const int64_t tiles = ceil_div(M, GB) * ceil_div(N, GB);
+  int splits = 1;
+  if (tiles < 512 && K >= 1024) {
+    splits = (int)std::min<int64_t>(ceil_div(K, 256), std::max<int64_t>(1, 1024 / tiles));
+  }
+  int64_t kchunk = round_up(ceil_div(K, splits), GK);
+  splits = (int)ceil_div(K, kchunk);
+  double *part = nullptr;
+  if (splits > 1) {
+    PLDA_HIP(h, h->w[15].reserve((size_t)splits * M * N * 8));
+    part = h->w[15].as<double>();
+  }
+  const dim3 grid((unsigned)ceil_div(N, GB), (unsigned)ceil_div(M, GB), (unsigned)splits);
+#define GEMM_LAUNCH(AK, BK)                                                                          \
+  gemm_f64_kernel<AK, BK><<<grid, 256, 0, h->stream>>>(M, N, K, kchunk, alpha, A, sam, sak, B, sbk, \
+                                                       sbn, kw, beta, C, ldc, part)
+  if (akc && bkc) GEMM_LAUNCH(true, true);
+  else if (akc && !bkc) GEMM_LAUNCH(true, false);
+  else if (!akc && bkc) GEMM_LAUNCH(false, true);
+  else GEMM_LAUNCH(false, false);
+#undef GEMM_LAUNCH
+  PLDA_LAUNCH_CHECK(h);
+  if (splits > 1) {
+    splitk_reduce_kernel<<<(unsigned)ceil_div(M * N, 256), 256, 0, h->stream>>>(part, splits, M, N, alpha,
+                                                                              beta, C, ldc);
+    PLDA_LAUNCH_CHECK(h);
+  }
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Cholesky (TpMatrix::Cholesky) -- one workgroup of 1024 threads
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void cholesky_kernel(double *__restrict__ A, int D, int *flag) {
+  extern __shared__ __attribute__((aligned(16))) double col[];  // [D]
+  __shared__ double sdiag;
+  const int t = threadIdx.x, nt = blockDim.x;
+  for (int j = 0; j < D; ++j) {
+    if (t == 0) {
+      double d = A[(size_t)j * D + j];
+      if (!(d > 0.0)) { *flag = 1; d = 1.0; }
+      d = sqrt(d);
+      A[(size_t)j * D + j] = d;
+      sdiag = d;
+    }
+    __syncthreads();
+    const double inv = 1.0 / sdiag;
+    for (int i = j + 1 + t; i < D; i += nt) {
+      const double v = A[(size_t)i * D + j] * inv;
+      A[(size_t)i * D + j] = v;
+      col[i] = v;
+    }
+    __syncthreads();
+    // trailing update of the lower triangle: A[i][k] -= col[i] col[k], j < k <= i
+    const int rem = D - j - 1;
+    const int tx = t & 31, ty = t >> 5, ny = nt >> 5;
+    for (int ii = ty; ii < rem; ii += ny) {
+      const int i = j + 1 + ii;
+      const double ci = col[i];
+      double *row = A + (size_t)i * D;
+      for (int k = j + 1 + tx; k <= i; k += 32) row[k] -= ci * col[k];
+    }
+    __syncthreads();
+  }
+  for (int idx = t; idx < D * D; idx += nt) {
+    const int i = idx / D, k = idx % D;
+    if (k > i) A[idx] = 0.0;
+  }
+}
+
+int cholesky_f64(plda_handle *h, double *A, int D, int *dflag) {
+  cholesky_kernel<<<1, 1024, (size_t)D * 8, h->stream>>>(A, D, dflag);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// triangular inverse (TpMatrix::Invert): thread j owns column j of X = L^{-1}
+// ------------------------------------------------------------------------------------
+__global__ void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= D) return;
+  for (int i = 0; i < j; ++i) X[(size_t)i * D + j] = 0.0;
+  for (int i = j; i < D; ++i) {
+    double s = (i == j) ? 1.0 : 0.0;
+    const double *Li = L + (size_t)i * D;
+    for (int k = j; k < i; ++k) s -= Li[k] * X[(size_t)k * D + j];
+    X[(size_t)i * D + j] = s / Li[i];
+  }
+}
+
+int tri_invert_f64(plda_handle *h, const double *L, double *X, int D) {
+  tri_invert_kernel<<<(unsigned)ceil_div(D, 64), 64, 0, h->stream>>>(L, X, D);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// symmetric eigensolver: one-sided Jacobi on the rows of A (= G) with V = I.
+// After convergence A = V G has mutually orthogonal rows, so the rows of V are the
+// eigenvectors of G and lambda_p = a_p . v_p.
+// ------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(64) void jacobi_round_kernel(double *__restrict__ A, double *__restrict__ V,
+                                                          int D, int n_even, int round, double tol,
+                                                          int *__restrict__ rotations) {
+  // round-robin tournament on n_even players: pair b of this round
+  const int b = blockIdx.x;
+  const int nm1 = n_even - 1;
+  int p, q;
+  if (b == 0) { p = nm1; q = round; }
+  else { p = (round + b) % nm1; q = (round - b + nm1) % nm1; }
+  if (p >= D || q >= D) return;  // bye (odd D)
+  if (p > q) { const int tt = p; p = q; q = tt; }
+  const int lane = threadIdx.x;
+  double *ap = A + (size_t)p * D, *aq = A + (size_t)q * D;
+  double x[E], y[E];
+  double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int d = lane + e * 64;
+    x[e] = d < D ? ap[d] : 0.0;
+    y[e] = d < D ? aq[d] : 0.0;
+    alpha += x[e] * x[e];
+    beta += y[e] * y[e];
+    gamma += x[e] * y[e];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    alpha += __shfl_xor(alpha, o);
+    beta += __shfl_xor(beta, o);
+    gamma += __shfl_xor(gamma, o);
+  }
+  if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta)) return;
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int d = lane + e * 64;
+    if (d < D) {
+      ap[d] = c * x[e] - s * y[e];
+      aq[d] = s * x[e] + c * y[e];
+    }
+  }
+  double *vp = V + (size_t)p * D, *vq = V + (size_t)q * D;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int d = lane + e * 64;
+    if (d < D) {
+      const double vx = vp[d], vy = vq[d];
+      vp[d] = c * vx - s * vy;
+      vq[d] = s * vx + c * vy;
+    }
+  }
+  if (lane == 0) atomicAdd(rotations, 1);
+}
+
+__global__ void set_identity_kernel(double *V, int D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < D * D) V[idx] = (idx / D == idx % D) ? 1.0 : 0.0;
+}
+
+// lambda_p = a_p . v_p (one wave per row)
+__global__ void eig_values_kernel(const double *__restrict__ A, const double *__restrict__ V, int D,
+                                  double *__restrict__ lam) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= D) return;
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) acc += A[(size_t)p * D + d] * V[(size_t)p * D + d];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) lam[p] = acc;
+}
+
+// rank sort descending (SortSvd), floor at zero (ApplyFloor), permute eigenvector rows
+__global__ void eig_sort_kernel(const double *__restrict__ lam, const double *__restrict__ V, int D,
+                                double *__restrict__ s, double *__restrict__ Vsorted) {
+  const int p = blockIdx.x;
+  const double lp = lam[p];
+  __shared__ int rank_s;
+  if (threadIdx.x == 0) rank_s = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int q = threadIdx.x; q < D; q += blockDim.x) {
+    const double lq = lam[q];
+    if (lq > lp || (lq == lp && q < p)) cnt++;
+  }
+  if (cnt) atomicAdd(&rank_s, cnt);
+  __syncthreads();
+  const int r = rank_s;
+  if (threadIdx.x == 0) s[r] = lp > 0.0 ? lp : 0.0;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) Vsorted[(size_t)r * D + d] = V[(size_t)p * D + d];
+}
+
+// eigenvectors are returned in the ROWS of Vrows (sorted by descending eigenvalue)
+int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out) {
+  if (D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: D=%d > 1024 unsupported", D);
+  PLDA_HIP(h, h->w[14].reserve((size_t)D * D * 8 + (size_t)D * 8 + 64));
+  double *V = h->w[14].as<double>();
+  double *lam = V + (size_t)D * D;
+  int *drot = reinterpret_cast<int *>(lam + D);
+  set_identity_kernel<<<(unsigned)ceil_div((int64_t)D * D, 256), 256, 0, h->stream>>>(V, D);
+  PLDA_LAUNCH_CHECK(h);
+  const int n_even = D + (D & 1);
+  const int pairs = n_even / 2;
+  const double tol = 2.220446049250313e-16 * 4.0 * sqrt((double)D);
+  const int E = (int)ceil_div(D, 64);
+  int sweeps = 0;
+  const int max_sweeps = 40;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    PLDA_HIP(h, hipMemsetAsync(drot, 0, sizeof(int), h->stream));
+    if (D > 1) {
+      for (int round = 0; round < n_even - 1; ++round) {
+#define JR(EE) jacobi_round_kernel<EE><<<pairs, 64, 0, h->stream>>>(G, V, D, n_even, round, tol, drot)
+        if (E <= 1) JR(1);
+        else if (E <= 2) JR(2);
+        else if (E <= 4) JR(4);
+        else if (E <= 8) JR(8);
+        else JR(16);
+#undef JR
+      }
+      PLDA_LAUNCH_CHECK(h);
+    }
+    int hrot = 0;
+    PLDA_HIP(h, hipMemcpyAsync(&hrot, drot, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (hrot == 0) break;
+  }
+  if (sweeps >= max_sweeps) return fail(h, PLDA_E_NUMERIC, "sym_eig: Jacobi did not converge in %d sweeps", max_sweeps);
+  if (sweeps_out) *sweeps_out = sweeps + 1;
+  eig_values_kernel<<<(unsigned)ceil_div(D, 4), 256, 0, h->stream>>>(G, V, D, lam);
+  eig_sort_kernel<<<D, 64, 0, h->stream>>>(lam, V, D, s, Vrows);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// simultaneous diagonalisation (PldaEstimator::GetOutput's transform)
+// ------------------------------------------------------------------------------------
+__global__ void symmetrize_kernel(double *G, int D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * D) return;
+  const int i = idx / D, j = idx % D;
+  if (j < i) {
+    const double v = 0.5 * (G[(size_t)i * D + j] + G[(size_t)j * D + i]);
+    G[(size_t)i * D + j] = v;
+    G[(size_t)j * D + i] = v;
+  }
+}
+
+int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv,
+                double *psi) {
+  const size_t DD = (size_t)D * D;
+  PLDA_HIP(h, h->w[13].reserve(DD * 8 * 5 + 64));
+  double *Cc = h->w[13].as<double>();
+  double *T1 = Cc + DD, *tmp = T1 + DD, *G = tmp + DD, *Vr = G + DD;
+  int *dflag = reinterpret_cast<int *>(Vr + DD);
+  PLDA_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(Cc, W, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+  PLDA_TRY(cholesky_f64(h, Cc, D, dflag));
+  PLDA_TRY(tri_invert_f64(h, Cc, T1, D));
+  // tmp = T1 B ; G = tmp T1^T
+  PLDA_TRY(gemm_f64(h, D, D, D, 1.0, T1, D, 1, B, D, 1, nullptr, 0.0, tmp, D));
+  PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
+  symmetrize_kernel<<<(unsigned)ceil_div((int64_t)DD, 256), 256, 0, h->stream>>>(G, D);
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_TRY(sym_eig_f64(h, G, D, psi, Vr, nullptr));
+  int hflag = 0;
+  PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
+  // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = C Vr^T
+  PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));
+  if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Cc, D, 1, Vr, 1, D, nullptr, 0.0, Tinv, D));
+  return PLDA_OK;
+}
+
+}  // namespace plda

@@ -1,0 +1,566 @@
+// plda_amd/csrc/score.hip -- batched PLDA log-likelihood-ratio scoring on gfx950.
+//
+// Replaces the per-trial path MPlda_score -> Plda::LogLikelihoodRatio
+// (/root/reference/src/pldamodule.cpp:258-277, driven M x Nt times by the nested
+// Python loop of scoring/scorePLDA.py:302-318) and the z-norm statistics of
+// MPlda_norm (:196-256) with the algebraically identical GEMM form
+// (SURVEY.md Appendix A.5):
+//
+//   S_ij = sum_d A1_id v_jd  [+ sum_d A2_id v_jd^2]  + r_i  [+ q_j]
+//   A1 = c u / var,  A2 = -1/2 (1/var - 1/(1+psi)),  c = n psi/(n psi + 1),
+//   var = 1 + psi/(n psi + 1),
+//   r_i = -1/2 sum_d [log var - log(1+psi) + c^2 u^2 / var]
+//   uniform n:  q_j = -1/2 sum_d (1/var_d - 1/(1+psi_d)) v_jd^2  (GEMM depth D)
+//   mixed   n:  second half of the contraction carries A2 x V*V   (GEMM depth 2D)
+//
+// Bias terms and operand values are computed in fp64 and rounded once to fp32;
+// the contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
+//
+// HBM layout of the GEMM operands ("k-quad packed"): P[kq][row][4] fp32, i.e.
+// for each group of 4 consecutive k the rows are contiguous 16-byte items.  With
+// that layout (1) a wave's global->LDS DMA (global_load_lds_dwordx4) of 64 rows is
+// one contiguous 1 KiB burst and lands lane-linear in LDS, and (2) the MFMA
+// fragment read is one conflict-free ds_read_b128 per lane that feeds 4 MFMAs.
+#include "common.hpp"
+
+namespace plda {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// ------------------------------------------------------------------------------------
+// per-row coefficient helpers (fp64)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void llr_coef(double n, double psi, double &c, double &var) {
+  const double den = n * psi + 1.0;
+  c = n * psi / den;
+  var = 1.0 + psi / den;
+}
+
+// r_i: one wave per enrol row.  Also (optionally) folds the z-norm affine map
+// s -> (s - zmean)/zstd into (rscale, rbias): out = rscale * (acc + q) + rbias.
+__global__ void enrol_bias_kernel(const double *__restrict__ U, const int32_t *__restrict__ n_arr,
+                                  int n_uniform, const double *__restrict__ psi, int D, int64_t M,
+                                  const double *__restrict__ zmean, const double *__restrict__ zstd,
+                                  float *__restrict__ rbias, float *__restrict__ rscale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const double n = n_arr ? (double)n_arr[row] : (double)n_uniform;
+  const double *u = U + row * (int64_t)D;
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    double c, var;
+    const double p = psi[d];
+    llr_coef(n, p, c, var);
+    const double cu = c * u[d];
+    acc += log(var) - log(1.0 + p) + cu * cu / var;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    double r = -0.5 * acc, sc = 1.0;
+    if (zmean && zstd) {
+      const double sd = zstd[row];
+      if (sd != 0.0) { sc = 1.0 / sd; r = (r - zmean[row]) * sc; }
+    }
+    rbias[row] = (float)r;
+    if (rscale) rscale[row] = (float)sc;
+  }
+}
+
+// q_j (uniform n only): one wave per test row.
+__global__ void test_bias_kernel(const double *__restrict__ V, int n_uniform,
+                                 const double *__restrict__ psi, int D, int64_t Nt,
+                                 float *__restrict__ cbias) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= Nt) return;
+  const double *v = V + row * (int64_t)D;
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    double c, var;
+    const double p = psi[d];
+    llr_coef((double)n_uniform, p, c, var);
+    acc += (1.0 / var - 1.0 / (1.0 + p)) * v[d] * v[d];
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) cbias[row] = (float)(-0.5 * acc);
+}
+
+// ------------------------------------------------------------------------------------
+// pack: fp64 [R, D] row-major  ->  fp32 k-quad packed P[kq][Rpad][4], through an LDS
+// transpose so that both the fp64 reads (256 B per half-wave) and the packed
+// writes (1 KiB per wave) are coalesced.
+//   MODE 0: enrol A1 (= c u / var), k in [0, Dp)
+//   MODE 1: enrol [A1 | A2], k in [0, 2 Dp)       (mixed n)
+//   MODE 2: test  V
+//   MODE 3: test  [V | V*V]                        (mixed n)
+//   rs (nullable, MODE 0/1): per-row scale folded into the A operand (z-norm)
+// ------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
+                                                   const int32_t *__restrict__ n_arr,
+                                                   int n_uniform, const double *__restrict__ psi,
+                                                   const float *__restrict__ rs, int D, int Dp,
+                                                   int64_t R, int64_t Rpad, int KQ,
+                                                   float *__restrict__ P) {
+  __shared__ float tile[32][65];
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int k0 = blockIdx.y * 32;
+  const int t = threadIdx.x;
+  {
+    const int c = t & 31;
+    const int k = k0 + c;
+    const bool second = (MODE == 1 || MODE == 3) && k >= Dp;
+    const int d = second ? k - Dp : k;
+    const bool dvalid = d < D && k < ((MODE == 1 || MODE == 3) ? 2 * Dp : Dp);
+    const double p = dvalid ? psi[d] : 0.0;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int r = (t >> 5) + pass * 8;
+      const int64_t row = row0 + r;
+      float val = 0.f;
+      if (dvalid && row < R) {
+        const double x = X[row * (int64_t)D + d];
+        if (MODE == 0 || MODE == 1) {
+          const double n = n_arr ? (double)n_arr[row] : (double)n_uniform;
+          double cc, var;
+          llr_coef(n, p, cc, var);
+          double v = second ? -0.5 * (1.0 / var - 1.0 / (1.0 + p)) : cc * x / var;
+          if (rs) v *= (double)rs[row];
+          val = (float)v;
+        } else {
+          val = (float)(second ? x * x : x);
+        }
+      }
+      tile[c][r] = val;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = t & 63;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int q = (t >> 6) + pass * 4;  // local kq 0..7
+      const int kq = (k0 >> 2) + q;
+      if (kq < KQ) {
+        f32x4 v;
+        v.x = tile[4 * q + 0][r];
+        v.y = tile[4 * q + 1][r];
+        v.z = tile[4 * q + 2][r];
+        v.w = tile[4 * q + 3][r];
+        reinterpret_cast<f32x4 *>(P)[(int64_t)kq * Rpad + row0 + r] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K5 / K8: the trials GEMM.
+//   block  = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64
+//            = 2 x 2 MFMA tiles of 32 x 32 (64 fp32 accumulators per lane)
+//   stage  = NKQ k-quads (4 NKQ values of k) of both operands, global->LDS by DMA,
+//            double buffered; LDS = 2 * NKQ * 4 KiB
+//   step   = 8 k (two k-quads): lane (i = lane & 31, h = lane >> 5) reads the float4
+//            of row i in k-quad 2p + h and issues 4 MFMAs per (tm, tn): component t
+//            contracts the k pair {8p + t, 8p + 4 + t}.  (Any fixed pairing of k's
+//            is a valid contraction order; A and B use the same one.)
+//   grid   = 1-D, XCD-aware: block b -> XCD b % 8 (observed dispatch order), and each
+//            XCD walks its own sequence of PM x PN tile patches so that the panels
+//            its resident blocks share stay in that XCD's 4 MiB L2.
+//   EPI 0  : out[i][j] = rscale_i * (acc + cbias_j) + rbias_i, non-temporal stores
+//   EPI 1  : fused z-norm statistics -- per column j accumulate sum / sum of squares
+//            of (score - shift_j) over rows i < M into fp64 (no score matrix)
+// ------------------------------------------------------------------------------------
+constexpr int PATCH_M = 8;
+constexpr int PATCH_N = 16;
+
+template <int NKQ>
+__device__ __forceinline__ void stage_tiles(const f32x4 *__restrict__ Apk,
+                                            const f32x4 *__restrict__ Bpk, int64_t Mpad,
+                                            int64_t Npad, int kq0, int KQ, int64_t r0,
+                                            int64_t c0, f32x4 *buf, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < NKQ; ++j) {
+    const int c = wave + 4 * j;  // chunk id in [0, 4 NKQ)
+    const bool isB = c >= 2 * NKQ;
+    const int cc = isB ? c - 2 * NKQ : c;
+    const int kql = cc >> 1, half = cc & 1;
+    const int kq = kq0 + kql;
+    if (kq < KQ) {
+      const f32x4 *g = isB ? Bpk + ((int64_t)kq * Npad + c0 + half * 64 + lane)
+                           : Apk + ((int64_t)kq * Mpad + r0 + half * 64 + lane);
+      f32x4 *l = buf + (isB ? NKQ * 128 : 0) + kql * 128 + half * 64;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)g, (LDS_AS void *)l, 16, 0, 0);
+    }
+  }
+}
+
+template <int NKQ, int EPI, bool ZN>
+__global__ __launch_bounds__(256) void trials_gemm_kernel(
+    const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, int64_t Mpad, int64_t Npad,
+    int KQ, const float *__restrict__ rbias, const float *__restrict__ rscale,
+    const float *__restrict__ cbias, float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt,
+    int tilesM, int tilesN, int patchesN, int numPatches, const float *__restrict__ shift,
+    double *__restrict__ colsum, double *__restrict__ colsq) {
+  static_assert(NKQ % 2 == 0, "stage must hold whole 8-k steps");
+  __shared__ f32x4 smem[2 * NKQ * 256];
+
+  // ---- XCD-aware block -> tile map ----
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b & 7u, seq = b >> 3;
+  const unsigned per = PATCH_M * PATCH_N;
+  const unsigned patch = (seq / per) * 8u + xcd;
+  if (patch >= (unsigned)numPatches) return;
+  const unsigned w = seq % per;
+  const int tile_m = (int)(patch / patchesN) * PATCH_M + (int)(w / PATCH_N);
+  const int tile_n = (int)(patch % patchesN) * PATCH_N + (int)(w % PATCH_N);
+  if (tile_m >= tilesM || tile_n >= tilesN) return;
+  const int64_t r0 = (int64_t)tile_m * 128, c0 = (int64_t)tile_n * 128;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 31, hh = lane >> 5;
+  const int64_t wrow0 = r0 + wm * 64, wcol0 = c0 + wn * 64;
+
+  // first stage in flight before anything else
+  stage_tiles<NKQ>(Apk, Bpk, Mpad, Npad, 0, KQ, r0, c0, smem, wave, lane);
+
+  // ---- bias prefetch (bias arrays are padded to the tile grid, so no bounds checks).
+  //      C/D layout of the 32x32 MFMA: col = lane & 31,
+  //      row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): regs 4q..4q+3 are 4 consecutive rows.
+  f32x4 rb[2][4];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      rb[tm][q] = *reinterpret_cast<const f32x4 *>(rbias + wrow0 + tm * 32 + 8 * q + 4 * hh);
+  float cb[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? cbias[wcol0 + tn * 32 + i] : 0.f;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  const int nst = (KQ + NKQ - 1) / NKQ;
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const f32x4 *cur = smem + (st & 1) * (NKQ * 256);
+    if (st + 1 < nst)
+      stage_tiles<NKQ>(Apk, Bpk, Mpad, Npad, (st + 1) * NKQ, KQ, r0, c0,
+                       smem + ((st + 1) & 1) * (NKQ * 256), wave, lane);
+    const int np = min(NKQ, KQ - st * NKQ) >> 1;
+    const f32x4 *Al = cur + hh * 128 + wm * 64 + i;
+    const f32x4 *Bl = cur + NKQ * 128 + hh * 128 + wn * 64 + i;
+    f32x4 a0 = Al[0], a1 = Al[32], b0 = Bl[0], b1 = Bl[32];
+#pragma unroll 1
+    for (int p = 0; p < np; ++p) {
+      const int pn = min(p + 1, np - 1) * 256;   // register prefetch of the next 8-k step
+      const f32x4 na0 = Al[pn], na1 = Al[pn + 32], nb0 = Bl[pn], nb1 = Bl[pn + 32];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+      }
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if (EPI == 0) {
+    f32x4 rs[2][4];
+    if (ZN) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rs[tm][q] = *reinterpret_cast<const f32x4 *>(rscale + wrow0 + tm * 32 + 8 * q + 4 * hh);
+    }
+    float *obase = out + (wrow0 + 4 * hh) * ld + wcol0 + i;
+    const bool interior = (r0 + 128 <= M) && (c0 + 128 <= Nt);
+    if (interior) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float *orow = obase + (int64_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ld;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            float v = acc[tm][tn][r] + cb[tn];
+            v = ZN ? v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3] : v + rb[tm][r >> 2][r & 3];
+            __builtin_nontemporal_store(v, orow + tn * 32);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = tm * 32 + (r & 3) + 8 * (r >> 2);
+          const bool rok = wrow0 + 4 * hh + lr < M;
+          float *orow = obase + (int64_t)lr * ld;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            float v = acc[tm][tn][r] + cb[tn];
+            v = ZN ? v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3] : v + rb[tm][r >> 2][r & 3];
+            if (rok && wcol0 + tn * 32 + i < Nt) __builtin_nontemporal_store(v, orow + tn * 32);
+          }
+        }
+    }
+  } else {
+    // fused z-norm statistics: per column sums over the rows of this wave tile
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int64_t col = wcol0 + tn * 32 + i;
+      const float sh = shift[col];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + 4 * hh + tm * 32 + (r & 3) + 8 * (r >> 2);
+          const float d = (row < M) ? (acc[tm][tn][r] + cb[tn] + rb[tm][r >> 2][r & 3]) - sh : 0.f;
+          s1 += d;
+          s2 += d * d;
+        }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (hh == 0 && col < Nt) {
+        atomicAdd(colsum + col, (double)s1);
+        atomicAdd(colsq + col, (double)s2);
+      }
+    }
+  }
+}
+
+// finalise fused z-norm statistics: mean = shift + S1/N, std = sqrt(S2/N - (S1/N)^2)
+__global__ void znorm_finalize_kernel(const float *__restrict__ shift, const double *__restrict__ colsum,
+                                      const double *__restrict__ colsq, int64_t M, double invN,
+                                      double *__restrict__ out_mean, double *__restrict__ out_std) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const double m1 = colsum[j] * invN;
+  double var = colsq[j] * invN - m1 * m1;
+  if (var < 0.0) var = 0.0;
+  out_mean[j] = (double)shift[j] + m1;
+  out_std[j] = sqrt(var);
+}
+
+__global__ void pilot_shift_kernel(const double *__restrict__ colsum, int64_t M, double invN,
+                                   float *__restrict__ shift) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < M) shift[j] = (float)(colsum[j] * invN);
+}
+
+// ------------------------------------------------------------------------------------
+// trial list in fp64: one wave per (enrol, test) pair -- Plda::LogLikelihoodRatio
+// verbatim (pldamodule.cpp:266) plus the z-norm of :269-273.
+// ------------------------------------------------------------------------------------
+__global__ void score_pairs_kernel(const double *__restrict__ U, const int32_t *__restrict__ n_enrol,
+                                   const double *__restrict__ V, const int64_t *__restrict__ e_idx,
+                                   const int64_t *__restrict__ t_idx, int64_t P,
+                                   const double *__restrict__ psi, int D,
+                                   const double *__restrict__ zmean, const double *__restrict__ zstd,
+                                   double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int64_t e = e_idx[p], t = t_idx[p];
+  const double n = (double)n_enrol[e];
+  const double *u = U + e * (int64_t)D, *v = V + t * (int64_t)D;
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    double c, var;
+    const double ps = psi[d];
+    llr_coef(n, ps, c, var);
+    const double diff = v[d] - c * u[d];
+    acc += (log(var) + diff * diff / var) - (log(1.0 + ps) + v[d] * v[d] / (1.0 + ps));
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    double s = -0.5 * acc;
+    if (zmean && zstd && zstd[e] != 0.0) s = (s - zmean[e]) / zstd[e];
+    out[p] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// TransformIvector epilogue (Plda::TransformIvector + GetNormalizationFactor,
+// reached at pldamodule.cpp:171,224): t = offset + T x (the GEMM wrote T x into out),
+// f = sqrt(Dout / sum_d t_d^2 / (psi_d + 1/n)), out = f t.  One wave per row, fp64.
+// ------------------------------------------------------------------------------------
+__global__ void length_norm_kernel(double *__restrict__ out, int64_t R, int Dout,
+                                   const double *__restrict__ offset, const double *__restrict__ psi,
+                                   const int32_t *__restrict__ n_arr, int n_uniform) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const double inv_n = 1.0 / (n_arr ? (double)n_arr[row] : (double)n_uniform);
+  double *t = out + row * (int64_t)Dout;
+  double acc = 0.0;
+  for (int d = lane; d < Dout; d += 64) {
+    const double v = t[d] + offset[d];
+    acc += v * v / (psi[d] + inv_n);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  const double f = sqrt((double)Dout / acc);
+  for (int d = lane; d < Dout; d += 64) t[d] = f * (t[d] + offset[d]);
+}
+
+int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
+                          int n_uniform, double *dout) {
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
+  if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
+  if (R <= 0) return PLDA_OK;
+  // out[r][o] = sum_k X[r][k] T[o][k]
+  PLDA_TRY(gemm_f64(h, R, h->Dout, Din, 1.0, dX, Din, 1, h->d_transform.as<double>(), 1, Din,
+                    nullptr, 0.0, dout, h->Dout));
+  const int wpb = 4;
+  length_norm_kernel<<<(unsigned)ceil_div(R, wpb), wpb * 64, 0, h->stream>>>(
+      dout, R, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn, n_uniform);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// host orchestration of a trials-matrix call
+// ------------------------------------------------------------------------------------
+constexpr int GEMM_NKQ = 6;
+
+struct TrialOperands {
+  int64_t Mpad, Npad;
+  int KQ, Kg;
+  bool mixed;
+};
+
+static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform,
+                            int64_t M, const double *dV, int64_t Nt, const double *dzmean,
+                            const double *dzstd, TrialOperands &op) {
+  const int D = h->Dout;
+  const int Dp = (int)round_up(D, 8);
+  op.mixed = dn != nullptr;
+  op.Kg = op.mixed ? 2 * Dp : Dp;
+  op.KQ = op.Kg / 4;
+  op.Mpad = round_up(M, 128);
+  op.Npad = round_up(Nt, 128);
+  PLDA_HIP(h, h->s_Apk.reserve((size_t)op.KQ * op.Mpad * 16));
+  PLDA_HIP(h, h->s_Bpk.reserve((size_t)op.KQ * op.Npad * 16));
+  PLDA_HIP(h, h->s_rbias.reserve((size_t)op.Mpad * 4));
+  PLDA_HIP(h, h->s_rscale.reserve((size_t)op.Mpad * 4));
+  PLDA_HIP(h, h->s_cbias.reserve((size_t)op.Npad * 4));
+  const double *psi = h->d_psi.as<double>();
+  const bool zn = dzmean && dzstd;
+  const int wpb = 4;
+  enrol_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
+      dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
+      zn ? h->s_rscale.as<float>() : nullptr);
+  PLDA_LAUNCH_CHECK(h);
+  if (!op.mixed) {
+    test_bias_kernel<<<(unsigned)ceil_div(Nt, wpb), wpb * 64, 0, h->stream>>>(
+        dV, n_uniform, psi, D, Nt, h->s_cbias.as<float>());
+    PLDA_LAUNCH_CHECK(h);
+  }
+  const dim3 ga((unsigned)(op.Mpad / 64), (unsigned)ceil_div(op.Kg, 32));
+  const dim3 gb((unsigned)(op.Npad / 64), (unsigned)ceil_div(op.Kg, 32));
+  if (op.mixed) {
+    pack_kernel<1><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
+                                              op.KQ, h->s_Apk.as<float>());
+    pack_kernel<3><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
+                                              op.KQ, h->s_Bpk.as<float>());
+  } else {
+    pack_kernel<0><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
+                                              op.KQ, h->s_Apk.as<float>());
+    pack_kernel<2><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
+                                              op.KQ, h->s_Bpk.as<float>());
+  }
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+template <int EPI, bool ZN>
+static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64_t Nt, bool use_rscale,
+                       float *dout, int64_t ld, const float *shift, double *colsum, double *colsq) {
+  // M may be a row prefix of the packed operand (z-norm pilot): only its tiles are launched
+  const int tilesM = (int)ceil_div(M, 128), tilesN = (int)(op.Npad / 128);
+  const int patchesM = (int)ceil_div(tilesM, PATCH_M), patchesN = (int)ceil_div(tilesN, PATCH_N);
+  const int64_t numPatches = (int64_t)patchesM * patchesN;
+  const int64_t grid = round_up(numPatches, 8) * PATCH_M * PATCH_N;
+  if (grid > 0x7fffffffLL) return fail(h, PLDA_E_INVAL, "score_matrix: block too large, shard it");
+  trials_gemm_kernel<GEMM_NKQ, EPI, ZN><<<(unsigned)grid, 256, 0, h->stream>>>(
+      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),
+      use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout,
+      ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
+                        const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
+                        float *dout, int64_t ld) {
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
+  if (M <= 0 || Nt <= 0) return PLDA_OK;
+  if (!dU || !dV || !dout || ld < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
+  if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix: n_uniform must be > 0 when n_enrol is NULL");
+  TrialOperands op;
+  PLDA_TRY(prepare_operands(h, dU, dn, n_uniform, M, dV, Nt, dzmean, dzstd, op));
+  h->last_M = M; h->last_Nt = Nt; h->last_k = op.mixed ? 2 * h->Dout : h->Dout;
+  if (dzmean && dzstd) return launch_gemm<0, true>(h, op, M, Nt, true, dout, ld, nullptr, nullptr, nullptr);
+  return launch_gemm<0, false>(h, op, M, Nt, false, dout, ld, nullptr, nullptr, nullptr);
+}
+
+int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,
+                       const int64_t *de, const int64_t *dt, int64_t P, const double *dzmean,
+                       const double *dzstd, double *dout) {
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_pairs: model not fitted");
+  if (P <= 0) return PLDA_OK;
+  const int wpb = 4;
+  score_pairs_kernel<<<(unsigned)ceil_div(P, wpb), wpb * 64, 0, h->stream>>>(
+      dU, dn, dV, de, dt, P, h->d_psi.as<double>(), h->Dout, dzmean, dzstd, dout);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// MPlda_norm (pldamodule.cpp:196-256), fused.  dbkg raw [Nb, Din]; dmodels transformed [M, Dout].
+int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
+                       const double *dmodels, int64_t M, double *dmean, double *dstd) {
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
+  if (Nb <= 0 || M <= 0) return fail(h, PLDA_E_INVAL, "norm: empty input");
+  const int D = h->Dout;
+  // cohort rows transformed with num_examples = Nb (quirk Q6, :224)
+  PLDA_HIP(h, h->w[8].reserve((size_t)Nb * D * 8));
+  double *dT = h->w[8].as<double>();
+  if (num_examples <= 0) num_examples = (int)Nb;
+  PLDA_TRY(transform_rows_device(h, dbkg, Nb, Din, nullptr, num_examples, dT));
+  // cohort = train side with n = 1 (quirk Q7, :235); models = test side
+  TrialOperands op;
+  PLDA_TRY(prepare_operands(h, dT, nullptr, 1, Nb, dmodels, M, nullptr, nullptr, op));
+  PLDA_HIP(h, h->w[9].reserve((size_t)op.Npad * (8 + 8 + 4)));
+  double *colsum = h->w[9].as<double>();
+  double *colsq = colsum + op.Npad;
+  float *shift = reinterpret_cast<float *>(colsq + op.Npad);
+  // pilot: mean over the first rows -> shift (keeps the single-pass variance well conditioned)
+  const int64_t Np = Nb < 128 ? Nb : 128;
+  PLDA_HIP(h, hipMemsetAsync(colsum, 0, (size_t)op.Npad * 20, h->stream));
+  PLDA_TRY(launch_gemm<1, false>(h, op, Np, M, false, nullptr, 0, shift, colsum, colsq));
+  pilot_shift_kernel<<<(unsigned)ceil_div(M, 256), 256, 0, h->stream>>>(colsum, M, 1.0 / (double)Np, shift);
+  PLDA_HIP(h, hipMemsetAsync(colsum, 0, (size_t)op.Npad * 16, h->stream));
+  PLDA_TRY(launch_gemm<1, false>(h, op, Nb, M, false, nullptr, 0, shift, colsum, colsq));
+  znorm_finalize_kernel<<<(unsigned)ceil_div(M, 256), 256, 0, h->stream>>>(shift, colsum, colsq, M,
+                                                                           1.0 / (double)Nb, dmean, dstd);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+}  // namespace plda

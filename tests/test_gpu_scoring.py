@@ -1,0 +1,150 @@
+"""GPU parity: trials matrix / trial list / transform / z-norm vs the fp64 oracle.
+
+All calls go through the C ABI (plda_amd.MPlda -> ctypes -> libplda_hip.so).
+Reference behaviour under test: src/pldamodule.cpp:111-277.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_data, score_tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from plda_amd import MPlda
+    return MPlda(0)
+
+
+def _model(oracle, seed, n, d, k, **kw):
+    x, y = make_data(seed, n, d, k, **kw)
+    return oracle.fit(x, y, 5), x, y
+
+
+def _load(engine, m):
+    engine.set_model(m["mean"], m["transform"], m["psi"])
+
+
+@pytest.mark.parametrize("d,m_rows,nt", [(200, 300, 517), (64, 128, 128), (10, 7, 1000), (33, 129, 257), (150, 1, 1)])
+@pytest.mark.parametrize("n_enrol", [1, 7])
+def test_score_matrix_uniform(engine, oracle, d, m_rows, nt, n_enrol):
+    m, x, y = _model(oracle, 11, 40 * 30, d, 40, scale_between=0.3)
+    _load(engine, m)
+    rng = np.random.default_rng(5)
+    U = np.stack([oracle.transform_ivector(m, r, n_enrol) for r in rng.random((m_rows, d)) + 0.2])
+    V = np.stack([oracle.transform_ivector(m, r, 1) for r in rng.random((nt, d))])
+    ref = oracle.score_block(m["psi"], U, n_enrol, V)
+    got = engine.score_matrix((n_enrol, U), (1, V))
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
+
+
+def test_score_matrix_mixed_counts(engine, oracle):
+    d = 96
+    m, x, y = _model(oracle, 12, 2000, d, 50, skew=True, scale_between=0.5)
+    _load(engine, m)
+    rng = np.random.default_rng(6)
+    counts = rng.integers(1, 6, 211).astype(np.int32)
+    U = np.stack([oracle.transform_ivector(m, r, c) for r, c in zip(rng.random((211, d)), counts)])
+    V = np.stack([oracle.transform_ivector(m, r, 1) for r in rng.random((333, d))])
+    ref = oracle.score_block(m["psi"], U, counts, V)
+    got = engine.score_matrix((counts, U), (1, V))
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
+
+
+def test_transposed_b_detected(engine, oracle):
+    """asymmetric operands: a transposed tile or swapped row/col bias cannot pass."""
+    d = 40
+    m, _, _ = _model(oracle, 13, 600, d, 20, scale_between=1.0)
+    _load(engine, m)
+    U = np.zeros((130, d)); V = np.zeros((70, d))
+    U[np.arange(130), np.arange(130) % d] = 1.0 + np.arange(130) / 7.0
+    V[np.arange(70), (3 * np.arange(70)) % d] = -2.0 + np.arange(70) / 5.0
+    ref = oracle.score_block(m["psi"], U, 3, V)
+    got = engine.score_matrix((3, U), (1, V))
+    assert (np.abs(got - ref) <= score_tol(ref)).all()
+
+
+def test_score_pairs_and_scalar_score(engine, oracle):
+    d = 50
+    m, x, y = _model(oracle, 14, 900, d, 30, skew=True, scale_between=0.4)
+    _load(engine, m)
+    el, ec, ev = oracle.transform_groups(m, x[:200], y[:200])
+    tl, tc, tv = oracle.transform_groups(m, x[200:300], np.arange(100, dtype=np.uint64))
+    rng = np.random.default_rng(1)
+    e = rng.integers(0, len(el), 500); t = rng.integers(0, 100, 500)
+    ref = np.array([oracle.llr(m["psi"], ev[a], ec[a], tv[b]) for a, b in zip(e, t)])
+    got = engine.score_trials((ec, ev), (tc, tv), e, t)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-11)
+    s = engine.score(int(el[3]), (int(ec[3]), ev[3]), (1, tv[5]))
+    assert isinstance(s, float)
+    assert abs(s - oracle.llr(m["psi"], ev[3], ec[3], tv[5])) < 1e-10
+
+
+def test_transform_groups_matches_oracle(engine, oracle):
+    d = 72
+    m, x, y = _model(oracle, 15, 1500, d, 60, skew=True, scale_between=0.2)
+    _load(engine, m)
+    labels = (y[:700] * 7919 + 13).astype(np.uint64)      # non-dense, large label values
+    got = engine.transform(x[:700], labels)
+    rl, rc, rv = oracle.transform_groups(m, x[:700], labels)
+    assert list(got.keys()) == [int(v) for v in rl]         # ascending label order (:164)
+    for i, k in enumerate(rl):
+        n, vec = got[int(k)]
+        assert n == rc[i] and vec.dtype == np.float64
+        np.testing.assert_allclose(vec, rv[i], rtol=1e-9, atol=1e-11)
+        # length-norm invariant: sum t^2/(psi + 1/n) = D
+        assert abs((vec ** 2 / (m["psi"] + 1.0 / n)).sum() - d) < 1e-8
+
+
+def test_znorm_stats_and_normalised_scores(engine, oracle):
+    d = 48
+    m, x, y = _model(oracle, 16, 1200, d, 40, scale_between=0.5)
+    from plda_amd import MPlda
+    eng = MPlda(0)
+    _load(eng, m)
+    enrol = eng.transform(x[:160], y[:160])
+    ids = list(enrol.keys())
+    models = np.stack([enrol[k][1] for k in ids])
+    bkg = x[300:300 + 391]
+    rm, rs = oracle.norm(m, bkg, models)
+    assert eng.norm(bkg, enrol) is None
+    zm, zs = eng.znorm_stats()
+    gm = np.array([zm[k] for k in ids]); gs = np.array([zs[k] for k in ids])
+    assert (np.abs(gm - rm) <= 1e-4 * np.maximum(np.abs(rm), np.abs(rm).mean())).all(), np.abs(gm - rm).max()
+    assert (np.abs(gs - rs) <= 1e-4 * rs).all(), (np.abs(gs - rs) / rs).max()
+    # insert-once (quirk Q8): a second norm() on other data leaves the statistics alone
+    eng.norm(x[700:900], enrol)
+    zm2, _ = eng.znorm_stats()
+    assert zm2 == zm
+    # z-normalised trials matrix vs oracle with the ORACLE's statistics plugged in
+    eng2 = MPlda(0); _load(eng2, m)
+    eng2._meanz = {k: float(v) for k, v in zip(ids, rm)}
+    eng2._stdvz = {k: float(v) for k, v in zip(ids, rs)}
+    test = eng2.transform(x[500:620], np.arange(120, dtype=np.uint64))
+    tv = np.stack([test[k][1] for k in test])
+    counts = np.array([enrol[k][0] for k in ids], np.int32)
+    ref = oracle.score_block(m["psi"], models, counts, tv, rm, rs)
+    got = eng2.score_matrix(enrol, test)
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
+    s = eng2.score(ids[2], enrol[ids[2]], test[7])
+    assert abs(s - ref[2, 7]) < 1e-9 * max(1.0, abs(ref[2, 7]))
+
+
+def test_smooth_and_truncate(engine, oracle):
+    d = 30
+    m, x, y = _model(oracle, 17, 600, d, 20, scale_between=0.6)
+    _load(engine, m)
+    engine.smooth(0.5)
+    sm = oracle.smooth(m, 0.5)
+    g = engine.get_model()
+    np.testing.assert_allclose(g["psi"], sm["psi"], rtol=1e-12)
+    np.testing.assert_allclose(g["transform"], sm["transform"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(g["offset"], sm["offset"], rtol=1e-10, atol=1e-12)
+    engine.smooth(0.0)  # identity
+    np.testing.assert_allclose(engine.get_model()["psi"], sm["psi"], rtol=1e-15)
+    engine.truncate(12)
+    assert engine.dims() == (12, d)
+    out = engine.transform_array(x[:5], 1)
+    assert out.shape == (5, 12)
