@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- PLDA LLR trials/sec (and fit-EM iters/sec) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1], "C2"): 100 000 random i-vectors, featdim 200,
+5 000 speakers; fit = statistics + 10 EM iterations + GetOutput on the GPU; a "step"
+= one pass of the hot path over one batch = the 100k x 100k trials matrix (1e10
+log-likelihood ratios, n = 1 per enrol model) through `plda_score_matrix_dev`:
+fp64 bias terms, fp64->fp32 operand packing, fp32-MFMA GEMM, 40 GB of fp32 scores
+written to HBM.  Inputs are HBM-resident before the timed region; scores stay in HBM.
+
+N > 1: one process per GPU (torchrun), weak scaling -- every rank scores its own
+100k-row enrol slab of a (N*100k) x 100k trials matrix against the replicated test
+set; the model is fitted on rank 0 and broadcast over RCCL.  No data-path collective
+is inside the timed region (scores stay row-sharded); an all-gather of a
+bounded slab is timed separately and reported under "allgather".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 flop/clk
+
+
+def cpu_baseline(D, psi, seconds=12.0):
+    """Faithful single-thread CPU restatement (oracle = "port") on a bounded sample of the
+    same workload: per-trial Plda::LogLikelihoodRatio incl. the wrapper's per-call vector
+    copies (pldamodule.cpp:258-277), n = 1, same D and psi as the GPU run."""
+    from oracle import binding as ob
+    ob.build()
+    rng = np.random.default_rng(1234)
+    m = 256
+    U = rng.standard_normal((m, D)); V = rng.standard_normal((m, D))
+    t0 = time.perf_counter(); ob.score_block(psi, U, 1, V); dt = time.perf_counter() - t0
+    rate = m * m / dt
+    side = int(max(256, min(6000, (rate * seconds) ** 0.5)))
+    U = rng.standard_normal((side, D)); V = rng.standard_normal((side, D))
+    t0 = time.perf_counter(); ob.score_block(psi, U, 1, V); dt = time.perf_counter() - t0
+    return {"value": side * side / dt, "unit": "trials/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d trials, D=%d, n=1, oracle/plda_oracle.c per-trial LLR loop, %.1f s" % (side, side, D, dt)}
+
+
+def cpu_em_baseline(X, y, seconds_cap=60.0):
+    """One Kaldi-style EM iteration (per-class loop, explicit inversions) of the oracle on
+    the SAME C2 statistics, single thread."""
+    from oracle import binding as ob
+    st = ob.stats(X, y)
+    D = X.shape[1]
+    t0 = time.perf_counter()
+    ob.em_iter(st, np.eye(D), np.eye(D))
+    dt = time.perf_counter() - t0
+    return {"em_iters_per_s": 1.0 / dt, "sample": "1 EM iteration at N=%d D=%d K=%d, %.1f s" % (X.shape[0], D, int(y.max()) + 1, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100000, help="i-vectors (fit rows = enrol rows per rank = test rows)")
+    ap.add_argument("--dim", type=int, default=200)
+    ap.add_argument("--speakers", type=int, default=5000)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--targetdim", type=int, default=0, help="build extension: keep the top-psi dims (0 = all)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--gather-rows", type=int, default=2048, help="rows per rank in the separately timed all-gather")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from plda_amd import MPlda
+    eng = MPlda(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)
+
+    N, D, K = args.n, args.dim, args.speakers
+    # ---- synthetic data: np.random.default_rng(2), uniform [0,1) rows, 20 utts / speaker ----
+    rng = np.random.default_rng(2)
+    X = rng.random((N, D))
+    y = (np.arange(N) % K).astype(np.uint64)
+
+    # ---- fit (rank 0) + broadcast of the model ----
+    fit_info = None
+    if rank == 0:
+        dX = torch.from_numpy(X).to(dev)
+        dy = torch.from_numpy(y.astype(np.int64)).to(dev)   # same bits as uint64 for labels < 2^63
+        torch.cuda.synchronize(dev)
+        eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)   # warm (allocations, code load)
+        t0 = time.perf_counter()
+        eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)
+        torch.cuda.synchronize(dev)
+        fit_wall = time.perf_counter() - t0
+        ft = eng.fit_timings()
+        fit_info = {"stats_ms": round(ft["stats_ms"], 3), "em_ms": round(ft["em_ms"], 3),
+                    "output_ms": round(ft["output_ms"], 3), "iters": ft["iters"],
+                    "em_iters_per_s": round(ft["iters"] / (ft["em_ms"] / 1e3), 2) if ft["em_ms"] > 0 else None,
+                    "fit_wall_s": round(fit_wall, 4), "N": N, "D": D, "K": K}
+        del dX, dy
+        model = eng.get_model()
+        packed = np.concatenate([model["mean"], model["transform"].ravel(), model["psi"]])
+    else:
+        packed = np.zeros(D + D * D + D)
+    if world > 1:
+        t = torch.from_numpy(packed).to(dev)
+        dist.broadcast(t, src=0)
+        packed = t.cpu().numpy()
+        if rank != 0:
+            eng.set_model(packed[:D], packed[D:D + D * D].reshape(D, D), packed[D + D * D:])
+    psi = packed[D + D * D:]
+    if args.targetdim:
+        eng.truncate(args.targetdim)
+    dout = eng.dims()[0]
+
+    # ---- enrol / test sets in the PLDA space (HBM-resident fp64), n = 1 ----
+    M = Nt = N
+    erng = np.random.default_rng(1000 + rank)          # this rank's enrol slab
+    dE = torch.from_numpy(erng.random((M, D))).to(dev)
+    dV = torch.from_numpy(np.random.default_rng(7).random((Nt, D))).to(dev)   # replicated test set
+    dU = torch.empty((M, dout), dtype=torch.float64, device=dev)
+    dT = torch.empty((Nt, dout), dtype=torch.float64, device=dev)
+    eng.transform_rows_dev(dE.data_ptr(), M, D, None, 1, dU.data_ptr())
+    eng.transform_rows_dev(dV.data_ptr(), Nt, D, None, 1, dT.data_ptr())
+    del dE, dV
+    out = torch.empty((M, Nt), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        eng.score_matrix_dev(dU.data_ptr(), None, 1, M, dT.data_ptr(), Nt, out.data_ptr(), Nt)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    gemm_ms, launches, gemm_flop = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- spot parity check of the timed output against the fp64 trial-list kernel ----
+    sel_e = torch.tensor([0, 1, M // 2, M - 1], device=dev)
+    sel_t = torch.tensor([0, 5, Nt // 3, Nt - 1], device=dev)
+    Uh, Th = dU[sel_e].cpu().numpy(), dT[sel_t].cpu().numpy()
+    got = out[sel_e][:, sel_t].cpu().numpy()
+    ref = eng.score_trials((np.ones(4, np.int32), Uh), (1, Th), np.repeat(np.arange(4), 4), np.tile(np.arange(4), 4)).reshape(4, 4)
+    spot = float(np.abs(got - ref).max())
+
+    # ---- separately timed all-gather of a bounded slab (RCCL over xGMI) ----
+    allgather = None
+    if world > 1:
+        rows = min(args.gather_rows, M)
+        send = out[:rows].contiguous()
+        recv = torch.empty((world * rows, Nt), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+        ag = (time.perf_counter() - t1) / reps
+        nbytes = rows * Nt * 4
+        allgather = {"bytes_per_rank": nbytes, "ms": round(ag * 1e3, 3),
+                     "busbw_GBps": round(nbytes * (world - 1) / ag / 1e9, 1),
+                     "full_matrix_gather_ms_est": round(ag * 1e3 * M / rows, 1),
+                     "note": "not in the timed region: scores stay row-sharded; gathering all of them is xGMI-bound"}
+        del recv
+
+    if rank == 0:
+        trials = float(world) * M * Nt * args.steps
+        value = trials / elapsed
+        avg_gemm_s = gemm_ms / 1e3 / max(launches, 1)
+        achieved = (gemm_flop / max(launches, 1)) / avg_gemm_s / 1e12 if avg_gemm_s > 0 else 0.0
+        res = {
+            "metric": "PLDA LLR trials/sec", "value": value, "unit": "trials/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: %d i-vectors, featdim %d, %d speakers; fit %d EM iters; %dx%d trials per GPU, n=1, D_eff=%d"
+                                   % (N, D, K, args.iters, M, Nt, dout),
+                       "trials_per_step_per_gpu": M * Nt, "parallelism": "row-sharded x%d" % world,
+                       "score_dtype": "f32 (fp64 bias terms, fp32 MFMA contraction)", "fit_dtype": "f64"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": None, "kernel": "trials_gemm_kernel",
+                         "flop_per_trial": 2 * dout, "avg_kernel_ms": round(avg_gemm_s * 1e3, 4),
+                         "launches": launches, "hbm_write_GBps": round(M * Nt * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None},
+            "fit": fit_info, "spot_check_max_abs_err": spot,
+        }
+        if allgather:
+            res["allgather"] = allgather
+        if not args.no_cpu and world == 1:
+            cb = cpu_baseline(dout, psi[:dout])
+            try:
+                cb["fit_em"] = cpu_em_baseline(X, y)
+            except Exception as e:  # the EM leg is informative only
+                cb["fit_em"] = {"error": str(e)}
+            res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,13 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
                           int32_t n_uniform, int64_t M, const double *dV, int64_t Nt,
                           const double *dzmean, const double *dzstd, float *dout,
                           int64_t ld_out);
+/* Kernel timing for roofline accounting: when enabled, every trials-GEMM launch is
+ * bracketed by HIP events recorded on the stream it is launched on; plda_profile_read
+ * synchronises and returns the accumulated GEMM milliseconds, launches, and the
+ * algorithmic flop (2 * gemm_k per trial) since the last reset. */
+int plda_profile_enable(plda_handle *h, int32_t on);
+int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double *gemm_flop,
+                      int32_t reset);
 /* algorithmic work of the last score_matrix call: flop of the trials GEMM and
  * its depth, for roofline accounting */
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k);

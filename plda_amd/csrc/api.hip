@@ -124,6 +124,7 @@ int plda_destroy(plda_handle *h) {
                     &h->s_rscale, &h->s_cbias, &h->s_coef};
   for (DevBuf *b : bufs) b->release();
   for (auto &b : h->w) b.release();
+  for (auto &ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return PLDA_OK;
@@ -367,6 +368,29 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
   }
   h->last_M = M;
+  return PLDA_OK;
+}
+
+int plda_profile_enable(plda_handle *h, int32_t on) {
+  if (!h) return PLDA_E_INVAL;
+  h->prof_on = on != 0;
+  return PLDA_OK;
+}
+
+int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double *gemm_flop, int32_t reset) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  double total = 0.0;
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    float ms = 0.f;
+    PLDA_HIP(h, hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+    total += ms;
+  }
+  if (gemm_ms) *gemm_ms = total;
+  if (launches) *launches = (int64_t)h->prof_used;
+  if (gemm_flop) *gemm_flop = h->prof_flop;
+  if (reset) { h->prof_used = 0; h->prof_flop = 0.0; }
   return PLDA_OK;
 }
 

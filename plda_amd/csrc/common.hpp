@@ -53,6 +53,12 @@ struct plda_handle {
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 
+  // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_flop = 0.0;
+
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
 };

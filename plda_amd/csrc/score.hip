@@ -441,7 +441,8 @@ constexpr int GEMM_NKQ = 6;
 
 struct TrialOperands {
   int64_t Mpad, Npad;
-  int KQ, Kg;
+  int KQ, Kg;   // padded GEMM depth (multiple of 8) and its k-quad count
+  int Kg_alg;   // algorithmic depth: Dout (uniform n) or 2 Dout (mixed n)
   bool mixed;
 };
 
@@ -452,6 +453,7 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   const int Dp = (int)round_up(D, 8);
   op.mixed = dn != nullptr;
   op.Kg = op.mixed ? 2 * Dp : Dp;
+  op.Kg_alg = op.mixed ? 2 * D : D;
   op.KQ = op.Kg / 4;
   op.Mpad = round_up(M, 128);
   op.Npad = round_up(Nt, 128);
@@ -498,11 +500,25 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   const int64_t numPatches = (int64_t)patchesM * patchesN;
   const int64_t grid = round_up(numPatches, 8) * PATCH_M * PATCH_N;
   if (grid > 0x7fffffffLL) return fail(h, PLDA_E_INVAL, "score_matrix: block too large, shard it");
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (h->prof_on) {
+    if (h->prof_used == h->prof_events.size()) {
+      PLDA_HIP(h, hipEventCreate(&ev0));
+      PLDA_HIP(h, hipEventCreate(&ev1));
+      h->prof_events.emplace_back(ev0, ev1);
+    }
+    ev0 = h->prof_events[h->prof_used].first;
+    ev1 = h->prof_events[h->prof_used].second;
+    h->prof_used++;
+    h->prof_flop += 2.0 * (double)op.Kg_alg * (double)M * (double)Nt;
+    PLDA_HIP(h, hipEventRecord(ev0, h->stream));
+  }
   trials_gemm_kernel<GEMM_NKQ, EPI, ZN><<<(unsigned)grid, 256, 0, h->stream>>>(
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),
       use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout,
       ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq);
   PLDA_LAUNCH_CHECK(h);
+  if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
   return PLDA_OK;
 }
 

@@ -307,6 +307,15 @@ class MPlda(object):
     def synchronize(self):
         self._ck(self._lib.plda_synchronize(self._h))
 
+    def profile_enable(self, on=True):
+        self._ck(self._lib.plda_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        """(GEMM ms, launches, algorithmic flop) accumulated by HIP events on the kernel's stream."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._ck(self._lib.plda_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl), 1 if reset else 0))
+        return ms.value, n.value, fl.value
+
     def fit_dev(self, dX, n, d, dlabels, k, iters=10):
         self._ck(self._lib.plda_fit_dev(self._h, C.c_void_p(int(dX)), int(n), int(d), C.c_void_p(int(dlabels)),
                                         int(k), int(iters)))

@@ -1,0 +1,47 @@
+"""Summarise rocprofv3 output dirs: per-kernel time (kernel-trace --stats) and per-kernel
+FETCH_SIZE / WRITE_SIZE from the PMC passes (units and gfx950 correction per
+MI355X_MICROARCH.md section HBM: counters are in KiB; FETCH_SIZE reads exactly 1/2 of a wide
+coalesced stream on gfx950 and is doubled here; WRITE_SIZE is uncalibrated)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
+
+
+def short(name):
+    name = name.split("(")[0]
+    for pre in ("void plda::", "plda::"):
+        if name.startswith(pre):
+            name = name[len(pre):]
+    return name[:70]
+
+
+for f in find("*kernel_stats.csv"):
+    print("== kernel stats:", os.path.relpath(f, out))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:14]:
+        print("  %-70s calls=%6s total_ms=%10.3f avg_us=%10.2f pct=%5s" % (
+            short(r.get("Name", "")), r.get("Calls"), float(r.get("TotalDurationNs", 0)) / 1e6,
+            float(r.get("AverageNs", 0)) / 1e3, r.get("Percentage")))
+
+for label, pat in (("FETCH_SIZE", "*fetch*counter_collection.csv"), ("WRITE_SIZE", "*write*counter_collection.csv")):
+    for f in find(pat):
+        print("== %s: %s" % (label, os.path.relpath(f, out)))
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != label:
+                continue
+            k = short(r.get("Kernel_Name", ""))
+            agg[k][0] += 1
+            agg[k][1] += float(r.get("Counter_Value", 0))
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+            kib = v / n
+            corr = 2.0 if label == "FETCH_SIZE" else 1.0
+            print("  %-70s launches=%6d avg_raw_KiB=%14.1f avg_bytes(corrected x%g)=%.4e" % (k, n, kib, corr, kib * 1024 * corr))
