@@ -45,3 +45,13 @@ for label, pat in (("FETCH_SIZE", "*fetch*counter_collection.csv"), ("WRITE_SIZE
             kib = v / n
             corr = 2.0 if label == "FETCH_SIZE" else 1.0
             print("  %-70s launches=%6d avg_raw_KiB=%14.1f avg_bytes(corrected x%g)=%.4e" % (k, n, kib, corr, kib * 1024 * corr))
+
+
+# filtered raw PMC rows of the dominant kernel (small enough to commit under profiles/)
+for label, pat in (("fetch", "*fetch*counter_collection.csv"), ("write", "*write*counter_collection.csv")):
+    for f in find(pat):
+        rows = list(csv.reader(open(f)))
+        hdr = rows[0]
+        ki = hdr.index("Kernel_Name")
+        keep = [hdr] + [r for r in rows[1:] if "trials_gemm" in r[ki]]
+        csv.writer(open(os.path.join(out, "pmc_%s_trials_gemm.csv" % label), "w")).writerows(keep)
