@@ -55,3 +55,18 @@ def oracle():
     from oracle import binding
     binding.build()
     return binding
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = ["tiny_unequal", "pldatest_shape", "c1_readme"]
+
+
+def load_golden(name):
+    """Fixture + its inputs (stored, or regenerated from the stored seed exactly as
+    tests/golden/make_golden.py did)."""
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    n, d = int(g["N"]), int(g["D"])
+    if "X" not in g:
+        rng = np.random.default_rng(int(g["seed"]))
+        g["X"] = rng.random((n, d))
+    return g

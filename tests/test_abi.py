@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library loads and exports every symbol include/plda_hip.h declares,
+the ctypes table covers exactly that set, and without a GPU the product path fails
+loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, _gpu_available
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "plda_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(plda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from plda_amd import _native
+    assert os.path.exists(_native.SO_PATH), "libplda_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_native.SO_PATH)
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "symbol %s declared in include/plda_hip.h but not exported" % n
+
+
+def test_ctypes_table_matches_header():
+    from plda_amd import _native
+    assert sorted(_native.SIGNATURES) == _declared()
+    lib = _native.load()
+    assert lib.plda_abi_version() == 1
+
+
+def test_header_cites_reference_interfaces():
+    text = open(os.path.join(ROOT, "include", "plda_hip.h")).read()
+    for cite in ("pldamodule.cpp:42-109", "pldamodule.cpp:111-194", "pldamodule.cpp:196-256", "pldamodule.cpp:258-277"):
+        assert cite in text
+
+
+@pytest.mark.skipif(_gpu_available(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    from plda_amd import MPlda
+    from plda_amd._native import PldaError
+    with pytest.raises(PldaError, match="no CPU fallback"):
+        MPlda(0)
+
+
+def test_product_code_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|#\s*include\s+[\"<][^\n]*oracle|libplda_oracle|oracle[./]binding", re.M)
+    for pkg in ("plda_amd", "liblda", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    src = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert pat.search(src) is None, "%s references the oracle" % os.path.join(dirpath, f)

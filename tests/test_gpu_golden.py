@@ -1,0 +1,48 @@
+"""GPU parity against the committed golden fixtures (tests/golden/*.npz), through the
+drop-in `liblda.PLDA` API: fit -> transform -> score_matrix / norm."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden, score_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_engine_matches_golden(name):
+    from liblda import PLDA
+    g = load_golden(name)
+    x, y = g["X"], g["y"]
+    p = PLDA()
+    assert p.fit(x, y, int(g["iters"])) is None
+    m = p._instance.get_model()
+    it = p._instance.fit_internals()
+    T, psi = m["transform"], m["psi"]
+    b = g["TtT"].shape[0]
+    assert np.abs(psi - g["psi"]).max() <= 1e-8 * g["psi"].max()
+    assert _rel(m["mean"], g["mean"]) < 1e-12
+    assert _rel((T.T @ T)[:b, :b], g["TtT"]) < 1e-8
+    assert _rel((T.T @ np.diag(psi) @ T)[:b, :b], g["TtPsiT"]) < 1e-8
+    assert _rel(it["W"][:b, :b], g["W"]) < 1e-8 and _rel(it["B"][:b, :b], g["B"]) < 1e-8
+    tr = np.array([np.trace(T.T @ T), np.trace(T.T @ np.diag(psi) @ T), np.trace(it["W"]), np.trace(it["B"])])
+    np.testing.assert_allclose(tr, g["traces"], rtol=1e-8)
+    ne, nt = int(g["enrol_n"]), int(g["test_n"])
+    enrol = p.transform(x[:ne], y[:ne])
+    assert list(enrol.keys()) == [int(v) for v in g["enrol_labels"]]
+    assert [enrol[k][0] for k in enrol] == [int(c) for c in g["enrol_counts"]]
+    test = p.transform(x[ne:ne + nt], np.arange(nt, dtype=np.uint64))
+    S = p.score_matrix(enrol, test, znorm=False)
+    assert (np.abs(S - g["scores"]) <= score_tol(g["scores"])).all(), np.abs(S - g["scores"]).max()
+    # fp64 trial list reproduces the fixture to fp64 accuracy
+    e_idx = np.repeat(np.arange(S.shape[0]), S.shape[1]); t_idx = np.tile(np.arange(S.shape[1]), S.shape[0])
+    S64 = p.score_trials(enrol, test, e_idx, t_idx, znorm=False).reshape(S.shape)
+    np.testing.assert_allclose(S64, g["scores"], rtol=1e-7, atol=1e-9)
+    p.norm(g["bkg"], enrol)
+    zm, zs = p._instance.znorm_stats()
+    gm = np.array([zm[k] for k in enrol]); gs = np.array([zs[k] for k in enrol])
+    assert (np.abs(gm - g["znorm_mean"]) <= 1e-4 * np.maximum(np.abs(g["znorm_mean"]), np.abs(g["znorm_mean"]).mean())).all()
+    assert (np.abs(gs - g["znorm_std"]) <= 2e-4 * g["znorm_std"]).all(), (np.abs(gs - g["znorm_std"]) / g["znorm_std"]).max()

@@ -1,0 +1,88 @@
+"""CPU: host-side logic of the shim (argument checks mirror pldamodule.cpp's
+ValueErrors) and the row-sharding path on a 2-process gloo group with the oracle as
+the per-slab scorer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from plda_amd import libplda
+from plda_amd.sharding import padded_shard, shard_rows
+
+
+def test_feature_and_label_checks():
+    x = np.random.default_rng(0).random((6, 3))
+    assert libplda._features(x.astype(np.float32)).dtype == np.float64          # quirk Q12 superset
+    assert libplda._features(np.asfortranarray(x)).flags["C_CONTIGUOUS"]
+    with pytest.raises(ValueError, match="not floats"):
+        libplda._features((x * 9).astype(np.int32))                               # pldamodule.cpp:59-62
+    with pytest.raises(TypeError):
+        libplda._features([[1.0, 2.0]])                                           # "O!" parse
+    with pytest.raises(ValueError, match="not an unsigned"):
+        libplda._labels(np.arange(6), 6)                                          # :55-58 / :133-136
+    with pytest.raises(ValueError, match="not strings"):
+        libplda._labels(np.array(["a"] * 6), 6, allow_strings_msg=True)           # :128-131
+    with pytest.raises(ValueError, match="number of samples"):
+        libplda._labels(np.arange(5, dtype=np.uint8), 6)
+    y = libplda._labels(np.arange(6, dtype=np.uint16), 6)
+    assert y.dtype == np.uint64 and y.flags["C_CONTIGUOUS"]
+
+
+@pytest.mark.parametrize("m,world", [(10, 1), (10, 3), (7, 8), (100000, 8), (40000, 8), (5, 5)])
+def test_shard_rows_partition(m, world):
+    spans = [shard_rows(m, world, r) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == m
+    for (a, b), (c, d) in zip(spans, spans[1:]):
+        assert b == c and b >= a and d >= c
+    sizes = [b - a for a, b in spans]
+    assert max(sizes) - min(sizes) <= 1 and max(sizes) == padded_shard(m, world)
+
+
+def _worker(rank, world, port, gather, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as ob
+    from plda_amd.sharding import score_matrix_sharded, shard_rows as sr
+    rng = np.random.default_rng(0)            # same data on every rank
+    d, m, nt = 12, 37, 23
+    psi = np.sort(rng.random(d) * 3)[::-1].copy()
+    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
+    counts = rng.integers(1, 5, m).astype(np.int32)
+    a, b = sr(m, world, rank)
+
+    def block(Ub, nb, Vb):
+        return torch.from_numpy(ob.score_block(psi, Ub.numpy(), nb.numpy(), Vb.numpy()).astype(np.float32))
+
+    loc, full = score_matrix_sharded(block, torch.from_numpy(U[a:b]), torch.from_numpy(counts[a:b]),
+                                     torch.from_numpy(V), m, gather=gather, slab_rows=8)
+    ref = ob.score_block(psi, U, counts, V).astype(np.float32)
+    ok = np.array_equal(loc.numpy(), ref[a:b])
+    if gather:
+        ok = ok and full is not None and np.array_equal(full.numpy(), ref)
+    else:
+        ok = ok and full is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_sharded_trials_matrix_gloo_world2(oracle, gather):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (1 if gather else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, gather, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
