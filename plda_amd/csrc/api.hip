@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -111,6 +112,7 @@ int plda_create(int device, plda_handle **out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
   h->stream = h->own_stream;
+  if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
   *out = h;
   return PLDA_OK;
 }

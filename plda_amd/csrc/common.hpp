@@ -53,6 +53,8 @@ struct plda_handle {
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 
+  int gemm_variant = 0;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
+
   // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

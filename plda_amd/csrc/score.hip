@@ -199,17 +199,41 @@ __device__ __forceinline__ void stage_tiles(const f32x4 *__restrict__ Apk,
   }
 }
 
-template <int NKQ, int EPI, bool ZN>
-__global__ __launch_bounds__(256) void trials_gemm_kernel(
+// ------------------------------------------------------------------------------------
+// Two details measured on MI355X (scripts/gemm_sweep.py):
+//  (1) fragment registers ping-pong between two sets and a sched_barrier pins the LDS
+//      reads of step p+1 ABOVE the 16 MFMAs of step p (hipcc otherwise coalesces the
+//      prefetch registers with the live ones, which forces the reads below the MFMAs
+//      and exposes the LDS latency every 8 k);
+//  (2) the epilogue transposes each wave's 64x64 tile through its own LDS region
+//      (the staging buffers are free after the last barrier) and writes 16-byte
+//      non-temporal stores, 4 rows x 256 B per wave instruction: 16 store instructions
+//      per wave instead of 64 (the store path is issue-bound).
+// ------------------------------------------------------------------------------------
+#define MFMA16(A0, A1, B0, B1)                                                                \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[t], B0[t], acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[t], B1[t], acc[0][1], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[t], B0[t], acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[t], B1[t], acc[1][1], 0, 0, 0);       \
+  }
+
+#define MFMA4(T, A0, A1, B0, B1)                                                              \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[T], B0[T], acc[0][0], 0, 0, 0);         \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[T], B1[T], acc[0][1], 0, 0, 0);         \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[T], B0[T], acc[1][0], 0, 0, 0);         \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[T], B1[T], acc[1][1], 0, 0, 0);
+
+template <int NKQ, int EPI, bool ZN, int MINW, int ABL = 0>
+__global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
     const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, int64_t Mpad, int64_t Npad,
     int KQ, const float *__restrict__ rbias, const float *__restrict__ rscale,
     const float *__restrict__ cbias, float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt,
     int tilesM, int tilesN, int patchesN, int numPatches, const float *__restrict__ shift,
     double *__restrict__ colsum, double *__restrict__ colsq) {
-  static_assert(NKQ % 2 == 0, "stage must hold whole 8-k steps");
+  static_assert(NKQ % 2 == 0 && NKQ >= 4, "stage must hold whole 8-k steps; epilogue needs 32 KiB");
   __shared__ f32x4 smem[2 * NKQ * 256];
 
-  // ---- XCD-aware block -> tile map ----
   const unsigned b = blockIdx.x;
   const unsigned xcd = b & 7u, seq = b >> 3;
   const unsigned per = PATCH_M * PATCH_N;
@@ -227,12 +251,8 @@ __global__ __launch_bounds__(256) void trials_gemm_kernel(
   const int i = lane & 31, hh = lane >> 5;
   const int64_t wrow0 = r0 + wm * 64, wcol0 = c0 + wn * 64;
 
-  // first stage in flight before anything else
   stage_tiles<NKQ>(Apk, Bpk, Mpad, Npad, 0, KQ, r0, c0, smem, wave, lane);
 
-  // ---- bias prefetch (bias arrays are padded to the tile grid, so no bounds checks).
-  //      C/D layout of the 32x32 MFMA: col = lane & 31,
-  //      row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): regs 4q..4q+3 are 4 consecutive rows.
   f32x4 rb[2][4];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
@@ -255,31 +275,47 @@ __global__ __launch_bounds__(256) void trials_gemm_kernel(
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
     const f32x4 *cur = smem + (st & 1) * (NKQ * 256);
-    if (st + 1 < nst)
+    if (st + 1 < nst && !(ABL & 2))
       stage_tiles<NKQ>(Apk, Bpk, Mpad, Npad, (st + 1) * NKQ, KQ, r0, c0,
                        smem + ((st + 1) & 1) * (NKQ * 256), wave, lane);
     const int np = min(NKQ, KQ - st * NKQ) >> 1;
     const f32x4 *Al = cur + hh * 128 + wm * 64 + i;
     const f32x4 *Bl = cur + NKQ * 128 + hh * 128 + wn * 64 + i;
-    f32x4 a0 = Al[0], a1 = Al[32], b0 = Bl[0], b1 = Bl[32];
+    f32x4 xa0 = Al[0], xa1 = Al[32], xb0 = Bl[0], xb1 = Bl[32];
+    f32x4 ya0, ya1, yb0, yb1;
+    int p = 0;
+    // The next step's LDS reads are issued after the first 4 MFMAs of a block, so the
+    // (conservative, full) wait the compiler places before a block's first MFMA only ever
+    // covers reads issued >= 12 MFMAs (768 cycles) earlier.
 #pragma unroll 1
-    for (int p = 0; p < np; ++p) {
-      const int pn = min(p + 1, np - 1) * 256;   // register prefetch of the next 8-k step
-      const f32x4 na0 = Al[pn], na1 = Al[pn + 32], nb0 = Bl[pn], nb1 = Bl[pn + 32];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
-      }
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    for (; p + 1 < np; p += 2) {
+      MFMA4(0, xa0, xa1, xb0, xb1)
+      __builtin_amdgcn_sched_barrier(0);
+      const int o1 = (p + 1) * 256;
+      if (ABL & 1) { ya0 = xa1; ya1 = xa0; yb0 = xb1; yb1 = xb0; }
+      else { ya0 = Al[o1]; ya1 = Al[o1 + 32]; yb0 = Bl[o1]; yb1 = Bl[o1 + 32]; }
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA4(1, xa0, xa1, xb0, xb1) MFMA4(2, xa0, xa1, xb0, xb1) MFMA4(3, xa0, xa1, xb0, xb1)
+      MFMA4(0, ya0, ya1, yb0, yb1)
+      __builtin_amdgcn_sched_barrier(0);
+      const int o2 = min(p + 2, np - 1) * 256;
+      if (ABL & 1) { xa0 = ya1; xa1 = ya0; xb0 = yb1; xb1 = yb0; }
+      else { xa0 = Al[o2]; xa1 = Al[o2 + 32]; xb0 = Bl[o2]; xb1 = Bl[o2 + 32]; }
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA4(1, ya0, ya1, yb0, yb1) MFMA4(2, ya0, ya1, yb0, yb1) MFMA4(3, ya0, ya1, yb0, yb1)
     }
-    __syncthreads();
+    if (p < np) { MFMA16(xa0, xa1, xb0, xb1) }
+    if (!(ABL & 4)) __syncthreads();
   }
 
-  // ---- epilogue ----
-  if (EPI == 0) {
+  if (EPI == 2) {   // ablation only
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[tm][tn][r] + cb[tn] + rb[tm][r >> 2][r & 3]));
+  } else if (EPI == 0) {
     f32x4 rs[2][4];
     if (ZN) {
 #pragma unroll
@@ -288,39 +324,38 @@ __global__ __launch_bounds__(256) void trials_gemm_kernel(
         for (int q = 0; q < 4; ++q)
           rs[tm][q] = *reinterpret_cast<const f32x4 *>(rscale + wrow0 + tm * 32 + 8 * q + 4 * hh);
     }
-    float *obase = out + (wrow0 + 4 * hh) * ld + wcol0 + i;
-    const bool interior = (r0 + 128 <= M) && (c0 + 128 <= Nt);
-    if (interior) {
+    // wave-private 32 x 64 fp32 staging tile (8 KiB); rows of 256 B, conflict-free both ways
+    float *tw = reinterpret_cast<float *>(smem) + wave * 2048;
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;     // transposed read: 4 rows x 256 B
+    const bool interior = (r0 + 128 <= M) && (c0 + 128 <= Nt) && ((ld & 3) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float *orow = obase + (int64_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ld;
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            float v = acc[tm][tn][r] + cb[tn];
-            v = ZN ? v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3] : v + rb[tm][r >> 2][r & 3];
-            __builtin_nontemporal_store(v, orow + tn * 32);
-          }
-        }
-    } else {
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int lr = tm * 32 + (r & 3) + 8 * (r >> 2);
-          const bool rok = wrow0 + 4 * hh + lr < M;
-          float *orow = obase + (int64_t)lr * ld;
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            float v = acc[tm][tn][r] + cb[tn];
-            v = ZN ? v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3] : v + rb[tm][r >> 2][r & 3];
-            if (rok && wcol0 + tn * 32 + i < Nt) __builtin_nontemporal_store(v, orow + tn * 32);
-          }
+          float v = acc[tm][tn][r] + cb[tn];
+          v = ZN ? v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3] : v + rb[tm][r >> 2][r & 3];
+          tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + tn * 32 + i] = v;
         }
+      // (same wave wrote and reads: LDS operations of one wave execute in order)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int lr = rrow + 4 * k;                       // row within this 32-row half
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tw + lr * 64 + rcol);
+        const int64_t row = wrow0 + tm * 32 + lr;
+        float *dst = out + row * ld + wcol0 + rcol;
+        if (interior) {
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+        } else if (row < M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
+        }
+      }
     }
   } else {
-    // fused z-norm statistics: per column sums over the rows of this wave tile
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int64_t col = wcol0 + tn * 32 + i;
@@ -437,7 +472,6 @@ int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, 
 // ------------------------------------------------------------------------------------
 // host orchestration of a trials-matrix call
 // ------------------------------------------------------------------------------------
-constexpr int GEMM_NKQ = 6;
 
 struct TrialOperands {
   int64_t Mpad, Npad;
@@ -513,10 +547,27 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     h->prof_flop += 2.0 * (double)op.Kg_alg * (double)M * (double)Nt;
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
   }
-  trials_gemm_kernel<GEMM_NKQ, EPI, ZN><<<(unsigned)grid, 256, 0, h->stream>>>(
-      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),
-      use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout,
-      ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq);
+  // Kernel instantiations.  Variant 0 is the product configuration; the others are the
+  // tuning / ablation arms of scripts/gemm_sweep.py (PLDA_GEMM_VARIANT), kept because the
+  // numbers in DESIGN.md section 3 come from them.
+#define TG(NKQ_, EPI_, MINW_, ABL_)                                                                     \
+  trials_gemm_kernel<NKQ_, EPI_, ZN, MINW_, ABL_><<<(unsigned)grid, 256, 0, h->stream>>>(               \
+      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),      \
+      use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout, \
+      ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq)
+  constexpr int EPI_NOSTORE = (EPI == 0) ? 2 : EPI;
+  switch (h->gemm_variant) {
+    case 1: TG(8, EPI, 2, 0); break;             // stage depth 32 k
+    case 2: TG(6, EPI, 2, 0); break;             // 24 k
+    case 3: TG(6, EPI, 3, 0); break;             // 24 k, 3 workgroups / CU
+    case 4: TG(4, EPI, 3, 0); break;             // 16 k, 3 workgroups / CU
+    case 9: TG(8, EPI_NOSTORE, 2, 0); break;     // ablation: no output stores
+    case 10: TG(8, EPI_NOSTORE, 2, 1); break;    // ... and no in-loop LDS reads
+    case 11: TG(8, EPI_NOSTORE, 2, 2); break;    // ... and no in-loop DMA
+    case 12: TG(8, EPI_NOSTORE, 2, 4); break;    // ... and no stage barriers
+    default: TG(10, EPI, 2, 0); break;           // product: 40 k per stage, 2 workgroups / CU
+  }
+#undef TG
   PLDA_LAUNCH_CHECK(h);
   if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
   return PLDA_OK;
