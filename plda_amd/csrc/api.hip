@@ -126,6 +126,7 @@ int plda_destroy(plda_handle *h) {
                     &h->s_rscale, &h->s_cbias, &h->s_coef};
   for (DevBuf *b : bufs) b->release();
   for (auto &b : h->w) b.release();
+  if (h->jac_exec) (void)hipGraphExecDestroy(h->jac_exec);
   for (auto &ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;

@@ -53,6 +53,14 @@ struct plda_handle {
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 
+  // ---- Jacobi sweep graph + warm-start state (linalg.hip) ----
+  hipGraphExec_t jac_exec = nullptr;
+  double *jac_G = nullptr, *jac_V = nullptr;
+  int jac_D = 0;
+  long jac_total_sweeps = 0;
+  int simdiag_D = 0;
+  bool simdiag_has_vr = false;
+
   int gemm_variant = 0;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
 
   // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
@@ -103,12 +111,13 @@ int cholesky_f64(plda_handle *h, double *A, int D, int *dflag);
 // X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
 int tri_invert_f64(plda_handle *h, const double *L, double *X, int D);
 // symmetric eigendecomposition of G (row-major, destroyed): eigenvalues sorted
-// descending in s[D] (floored at 0), eigenvectors in the COLUMNS of U (row-major).
-int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *U, int *sweeps_out);
+// descending in s[D] (floored at 0), eigenvectors in the ROWS of Vrows.
+int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,
+                const double *warm);
 // simultaneous diagonalisation of (W,B): T W T^T = I, T B T^T = diag(psi);
 // T [D,D], Tinv = T^{-1} (nullable), psi[D].  W,B are not modified.
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T,
-                double *Tinv, double *psi);
+                double *Tinv, double *psi, bool warm_start);
 
 // ---- fit.hip ----
 int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels,

@@ -320,6 +320,8 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
   const size_t DD = (size_t)D * D;
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  h->simdiag_has_vr = false;   // a new fit starts cold
+  h->jac_total_sweeps = 0;
   const double t0 = now_ms();
 
   // ---------------- statistics (K1a, K1, K2) ----------------
@@ -380,7 +382,7 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   const double cntW = (example_weight - class_weight) + class_weight;  // = K
   const double cntB = class_weight;
   for (int it = 0; it < iters; ++it) {
-    PLDA_TRY(simdiag_f64(h, W, B, D, T, Tinv, psi));
+    PLDA_TRY(simdiag_f64(h, W, B, D, T, Tinv, psi, it > 0));
     // P = Mc T^T  (reuse Y1 as P, then scale into Y1/Y2)
     PLDA_TRY(gemm_f64(h, K, D, D, 1.0, Mc, D, 1, T, 1, D, nullptr, 0.0, Y2, D));
     em_scale_kernel<<<gKD, 256, 0, h->stream>>>(Y2, offsets, psi, K, D, Y1, Y2);
@@ -405,7 +407,7 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   PLDA_HIP(h, h->d_transform.reserve(DD * 8));
   PLDA_HIP(h, h->d_psi.reserve((size_t)D * 8));
   PLDA_HIP(h, h->d_offset.reserve((size_t)D * 8));
-  PLDA_TRY(simdiag_f64(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>()));
+  PLDA_TRY(simdiag_f64(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), iters > 0));
   PLDA_HIP(h, hipMemcpyAsync(h->d_mean.p, mu, (size_t)D * 8, hipMemcpyDeviceToDevice, h->stream));
   h->Dout = D; h->Din = D;
   PLDA_TRY(compute_offset_device(h));

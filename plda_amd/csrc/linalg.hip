@@ -6,9 +6,10 @@
 //   gemm_f64      v_mfma_f64_16x16x4_f64, LDS-staged 64x64 tiles, optional per-k
 //                 weights (weighted SYRK X^T diag(w) X), deterministic split-K
 //   cholesky_f64  right-looking, one workgroup, column staged in LDS
-//   tri_invert    forward substitution, one thread per column
+//   tri_invert    forward substitution, one wave per column, solution held in registers
 //   sym_eig_f64   one-sided (Hestenes) Jacobi with round-robin pair ordering, one
-//                 wave per row pair, one launch per tournament round
+//                 wave per row pair, one launch per tournament round; a sweep's launches
+//                 are replayed from a hipGraph; warm start from the previous eigenvectors
 #include "common.hpp"
 
 #include <algorithm>
@@ -218,84 +219,167 @@ int cholesky_f64(plda_handle *h, double *A, int D, int *dflag) {
 }
 
 // ------------------------------------------------------------------------------------
-// triangular inverse (TpMatrix::Invert): thread j owns column j of X = L^{-1}
+// triangular inverse (TpMatrix::Invert): one WAVE per column j of X = L^{-1}.
+// Forward substitution x_i = (delta_ij - sum_{k=j}^{i-1} L[i][k] x_k) / L[i][i]; lane l keeps
+// x_k for k = l (mod 64) in registers, so the dot product is E coalesced loads of row i of
+// L, E FMAs and one wave reduction per step; nothing goes through memory until the end.
 // ------------------------------------------------------------------------------------
-__global__ void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= D) return;
-  for (int i = 0; i < j; ++i) X[(size_t)i * D + j] = 0.0;
+template <int E>
+__global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D) {
+  const int j = blockIdx.x;
+  const int lane = threadIdx.x;
+  double x[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) x[e] = 0.0;
   for (int i = j; i < D; ++i) {
-    double s = (i == j) ? 1.0 : 0.0;
     const double *Li = L + (size_t)i * D;
-    for (int k = j; k < i; ++k) s -= Li[k] * X[(size_t)k * D + j];
-    X[(size_t)i * D + j] = s / Li[i];
+    double part = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane + e * 64;
+      if (k >= j && k < i) part += Li[k] * x[e];
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const double xi = ((i == j ? 1.0 : 0.0) - part) / Li[i];
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (lane + e * 64 == i) x[e] = xi;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = lane + e * 64;
+    if (k < D) X[(size_t)k * D + j] = x[e];   // rows k < j are the zeros x[] was initialised with
   }
 }
 
 int tri_invert_f64(plda_handle *h, const double *L, double *X, int D) {
-  tri_invert_kernel<<<(unsigned)ceil_div(D, 64), 64, 0, h->stream>>>(L, X, D);
+  const int E = (int)ceil_div(D, 64);
+#define TI(EE) tri_invert_kernel<EE><<<D, 64, 0, h->stream>>>(L, X, D)
+  if (E <= 1) TI(1);
+  else if (E <= 2) TI(2);
+  else if (E <= 4) TI(4);
+  else if (E <= 8) TI(8);
+  else if (E <= 16) TI(16);
+  else return fail(h, PLDA_E_INVAL, "tri_invert: D=%d > 1024 unsupported", D);
+#undef TI
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
 }
 
 // ------------------------------------------------------------------------------------
-// symmetric eigensolver: one-sided Jacobi on the rows of A (= G) with V = I.
+// symmetric eigensolver: one-sided (Hestenes) block Jacobi on the rows of A (= G), V = I.
 // After convergence A = V G has mutually orthogonal rows, so the rows of V are the
 // eigenvectors of G and lambda_p = a_p . v_p.
 // ------------------------------------------------------------------------------------
+// Block form of the one-sided Jacobi round: rows are grouped in blocks of JB = 4; a launch
+// is one OUTER tournament round over the blocks; each workgroup takes one block pair,
+// stages its 8 rows of A and of V in LDS and runs the full INNER tournament on them
+// (7 rounds x 4 disjoint pairs, one wave per pair, __syncthreads between rounds), so 28
+// rotations are applied per round trip to L2 instead of one.
+constexpr int JB = 4;
+
+// fp64 wave-wide sum through DPP: quad butterflies, then half-row and row mirrors (every
+// lane of a 16-lane row then holds the row sum), then four readlanes.  ~6x shorter
+// dependency chain than __shfl_xor, which lowers to ds_bpermute for 64-bit values.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                          __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+  x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_f64<0x141>(x);   // row_half_mirror
+  x += dpp_f64<0x140>(x);   // row_mirror
+  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+
 template <int E>
-__global__ __launch_bounds__(64) void jacobi_round_kernel(double *__restrict__ A, double *__restrict__ V,
-                                                          int D, int n_even, int round, double tol,
-                                                          int *__restrict__ rotations) {
-  // round-robin tournament on n_even players: pair b of this round
-  const int b = blockIdx.x;
-  const int nm1 = n_even - 1;
-  int p, q;
-  if (b == 0) { p = nm1; q = round; }
-  else { p = (round + b) % nm1; q = (round - b + nm1) % nm1; }
-  if (p >= D || q >= D) return;  // bye (odd D)
-  if (p > q) { const int tt = p; p = q; q = tt; }
-  const int lane = threadIdx.x;
-  double *ap = A + (size_t)p * D, *aq = A + (size_t)q * D;
-  double x[E], y[E];
-  double alpha = 0.0, beta = 0.0, gamma = 0.0;
+__global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ A, double *__restrict__ V,
+                                                           int D, int nb_even, int oround, double tol,
+                                                           int *__restrict__ rotations) {
+  extern __shared__ __attribute__((aligned(16))) double rows[];   // [8][D] of A, then [8][D] of V
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nm1 = nb_even - 1;
+  int bp, bq;
+  if (blockIdx.x == 0) { bp = nm1; bq = oround; }
+  else { bp = (oround + blockIdx.x) % nm1; bq = (oround - (int)blockIdx.x + nm1) % nm1; }
+  if (bp > bq) { const int tt = bp; bp = bq; bq = tt; }
+  if (bq * JB >= D) return;   // bye: the partner block does not exist
+  double *lA = rows, *lV = rows + 2 * JB * D;
+  // global row of local row r (r < JB: block bp, else block bq); rows >= D do not exist
+  auto grow = [&](int r) { return (r < JB ? bp * JB + r : bq * JB + (r - JB)); };
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int d = lane + e * 64;
-    x[e] = d < D ? ap[d] : 0.0;
-    y[e] = d < D ? aq[d] : 0.0;
-    alpha += x[e] * x[e];
-    beta += y[e] * y[e];
-    gamma += x[e] * y[e];
+  for (int r = 0; r < 2 * JB; ++r) {
+    const int g = grow(r);
+    if (g < D)
+      for (int c = t; c < D; c += 256) {
+        lA[r * D + c] = A[(size_t)g * D + c];
+        lV[r * D + c] = V[(size_t)g * D + c];
+      }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    alpha += __shfl_xor(alpha, o);
-    beta += __shfl_xor(beta, o);
-    gamma += __shfl_xor(gamma, o);
-  }
-  if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta)) return;
-  const double zeta = (beta - alpha) / (2.0 * gamma);
-  const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  const double c = 1.0 / sqrt(1.0 + tn * tn), s = c * tn;
+  __syncthreads();
+  int nrot = 0;
+  constexpr int NP = 2 * JB;   // 8 players
+#pragma unroll 1
+  for (int ir = 0; ir < NP - 1; ++ir) {
+    int p, q;
+    if (wave == 0) { p = NP - 1; q = ir; }
+    else { p = (ir + wave) % (NP - 1); q = (ir - wave + (NP - 1)) % (NP - 1); }
+    if (p > q) { const int tt = p; p = q; q = tt; }
+    if (grow(p) < D && grow(q) < D) {
+      double *ap = lA + p * D, *aq = lA + q * D;
+      double x[E], y[E];
+      double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int d = lane + e * 64;
-    if (d < D) {
-      ap[d] = c * x[e] - s * y[e];
-      aq[d] = s * x[e] + c * y[e];
+      for (int e = 0; e < E; ++e) {
+        const int d = lane + e * 64;
+        x[e] = d < D ? ap[d] : 0.0;
+        y[e] = d < D ? aq[d] : 0.0;
+        alpha += x[e] * x[e];
+        beta += y[e] * y[e];
+        gamma += x[e] * y[e];
+      }
+      alpha = wave_sum_f64(alpha);
+      beta = wave_sum_f64(beta);
+      gamma = wave_sum_f64(gamma);
+      if (gamma != 0.0 && fabs(gamma) > tol * sqrt(alpha * beta)) {
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + tn * tn), sn = c * tn;
+        double *vp = lV + p * D, *vq = lV + q * D;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int d = lane + e * 64;
+          if (d < D) {
+            ap[d] = c * x[e] - sn * y[e];
+            aq[d] = sn * x[e] + c * y[e];
+            const double vx = vp[d], vy = vq[d];
+            vp[d] = c * vx - sn * vy;
+            vq[d] = sn * vx + c * vy;
+          }
+        }
+        nrot++;
+      }
     }
+    __syncthreads();
   }
-  double *vp = V + (size_t)p * D, *vq = V + (size_t)q * D;
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int d = lane + e * 64;
-    if (d < D) {
-      const double vx = vp[d], vy = vq[d];
-      vp[d] = c * vx - s * vy;
-      vq[d] = s * vx + c * vy;
-    }
+  for (int r = 0; r < 2 * JB; ++r) {
+    const int g = grow(r);
+    if (g < D)
+      for (int c = t; c < D; c += 256) {
+        A[(size_t)g * D + c] = lA[r * D + c];
+        V[(size_t)g * D + c] = lV[r * D + c];
+      }
   }
-  if (lane == 0) atomicAdd(rotations, 1);
+  if (lane == 0 && nrot) atomicAdd(rotations, nrot);
 }
 
 __global__ void set_identity_kernel(double *V, int D) {
@@ -335,35 +419,71 @@ __global__ void eig_sort_kernel(const double *__restrict__ lam, const double *__
   for (int d = threadIdx.x; d < D; d += blockDim.x) Vsorted[(size_t)r * D + d] = V[(size_t)p * D + d];
 }
 
-// eigenvectors are returned in the ROWS of Vrows (sorted by descending eigenvalue)
-int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out) {
-  if (D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: D=%d > 1024 unsupported", D);
-  PLDA_HIP(h, h->w[14].reserve((size_t)D * D * 8 + (size_t)D * 8 + 64));
-  double *V = h->w[14].as<double>();
-  double *lam = V + (size_t)D * D;
-  int *drot = reinterpret_cast<int *>(lam + D);
-  set_identity_kernel<<<(unsigned)ceil_div((int64_t)D * D, 256), 256, 0, h->stream>>>(V, D);
-  PLDA_LAUNCH_CHECK(h);
-  const int n_even = D + (D & 1);
-  const int pairs = n_even / 2;
-  const double tol = 2.220446049250313e-16 * 4.0 * sqrt((double)D);
+// One sweep = nb_even - 1 outer rounds; its launches are captured once into a hipGraph
+// (per handle, re-captured when D or the buffers change) and replayed.
+static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, double tol, int *drot) {
+  const int nb = (int)ceil_div(D, JB);
+  const int nb_even = nb + (nb & 1);
+  const int wgs = nb_even / 2;
   const int E = (int)ceil_div(D, 64);
+  const size_t lds = (size_t)4 * JB * D * sizeof(double);
+  if (h->jac_exec && (h->jac_G != G || h->jac_V != V || h->jac_D != D)) {
+    (void)hipGraphExecDestroy(h->jac_exec);
+    h->jac_exec = nullptr;
+  }
+  if (!h->jac_exec) {
+#define JATTR(EE) PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_block_kernel<EE>), \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    if (E <= 1) JATTR(1); else if (E <= 2) JATTR(2); else if (E <= 4) JATTR(4); else if (E <= 8) JATTR(8); else JATTR(16);
+#undef JATTR
+    hipGraph_t graph = nullptr;
+    PLDA_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+    (void)hipMemsetAsync(drot, 0, sizeof(int), h->stream);
+    for (int round = 0; round < nb_even - 1; ++round) {
+#define JR(EE) jacobi_block_kernel<EE><<<wgs, 256, lds, h->stream>>>(G, V, D, nb_even, round, tol, drot)
+      if (E <= 1) JR(1);
+      else if (E <= 2) JR(2);
+      else if (E <= 4) JR(4);
+      else if (E <= 8) JR(8);
+      else JR(16);
+#undef JR
+    }
+    hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+    if (ec != hipSuccess) return hip_fail(h, ec, "hipStreamEndCapture(jacobi sweep)", __FILE__, __LINE__);
+    ec = hipGraphInstantiate(&h->jac_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ec != hipSuccess) { h->jac_exec = nullptr; return hip_fail(h, ec, "hipGraphInstantiate(jacobi sweep)", __FILE__, __LINE__); }
+    h->jac_G = G; h->jac_V = V; h->jac_D = D;
+  }
+  PLDA_HIP(h, hipGraphLaunch(h->jac_exec, h->stream));
+  return PLDA_OK;
+}
+
+// Eigenvectors are returned in the ROWS of Vrows (sorted by descending eigenvalue).
+// warm != nullptr: rows of `warm` are an orthonormal guess (the previous EM iteration's
+// eigenvectors); the iteration then starts from A = warm G, V = warm instead of A = G, V = I.
+int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,
+                const double *warm) {
+  if (D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: D=%d > 1024 unsupported", D);
+  const size_t DD = (size_t)D * D;
+  PLDA_HIP(h, h->w[14].reserve(DD * 8 * 2 + (size_t)D * 8 + 64));
+  double *V = h->w[14].as<double>();
+  double *A = V + DD;
+  double *lam = A + DD;
+  int *drot = reinterpret_cast<int *>(lam + D);
+  if (warm) {
+    PLDA_HIP(h, hipMemcpyAsync(V, warm, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, warm, D, 1, G, D, 1, nullptr, 0.0, A, D));
+  } else {
+    set_identity_kernel<<<(unsigned)ceil_div((int64_t)DD, 256), 256, 0, h->stream>>>(V, D);
+    PLDA_HIP(h, hipMemcpyAsync(A, G, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+  }
+  PLDA_LAUNCH_CHECK(h);
+  const double tol = 2.220446049250313e-16 * 4.0 * sqrt((double)D);
   int sweeps = 0;
   const int max_sweeps = 40;
-  for (; sweeps < max_sweeps; ++sweeps) {
-    PLDA_HIP(h, hipMemsetAsync(drot, 0, sizeof(int), h->stream));
-    if (D > 1) {
-      for (int round = 0; round < n_even - 1; ++round) {
-#define JR(EE) jacobi_round_kernel<EE><<<pairs, 64, 0, h->stream>>>(G, V, D, n_even, round, tol, drot)
-        if (E <= 1) JR(1);
-        else if (E <= 2) JR(2);
-        else if (E <= 4) JR(4);
-        else if (E <= 8) JR(8);
-        else JR(16);
-#undef JR
-      }
-      PLDA_LAUNCH_CHECK(h);
-    }
+  for (; sweeps < max_sweeps && D > 1; ++sweeps) {
+    PLDA_TRY(jacobi_sweep_graph(h, A, V, D, tol, drot));
     int hrot = 0;
     PLDA_HIP(h, hipMemcpyAsync(&hrot, drot, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
@@ -371,7 +491,8 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
   }
   if (sweeps >= max_sweeps) return fail(h, PLDA_E_NUMERIC, "sym_eig: Jacobi did not converge in %d sweeps", max_sweeps);
   if (sweeps_out) *sweeps_out = sweeps + 1;
-  eig_values_kernel<<<(unsigned)ceil_div(D, 4), 256, 0, h->stream>>>(G, V, D, lam);
+  h->jac_total_sweeps += sweeps + 1;
+  eig_values_kernel<<<(unsigned)ceil_div(D, 4), 256, 0, h->stream>>>(A, V, D, lam);
   eig_sort_kernel<<<D, 64, 0, h->stream>>>(lam, V, D, s, Vrows);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
@@ -392,12 +513,15 @@ __global__ void symmetrize_kernel(double *G, int D) {
 }
 
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv,
-                double *psi) {
+                double *psi, bool warm_start) {
   const size_t DD = (size_t)D * D;
+  const bool fresh = h->w[13].cap < DD * 8 * 5 + 64 || h->simdiag_D != D;
   PLDA_HIP(h, h->w[13].reserve(DD * 8 * 5 + 64));
+  h->simdiag_D = D;
   double *Cc = h->w[13].as<double>();
-  double *T1 = Cc + DD, *tmp = T1 + DD, *G = tmp + DD, *Vr = G + DD;
+  double *T1 = Cc + DD, *tmp = T1 + DD, *G = tmp + DD, *Vr = G + DD;   // Vr persists: next call's warm start
   int *dflag = reinterpret_cast<int *>(Vr + DD);
+  const bool warm = warm_start && !fresh && h->simdiag_has_vr;
   PLDA_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
   PLDA_HIP(h, hipMemcpyAsync(Cc, W, DD * 8, hipMemcpyDeviceToDevice, h->stream));
   PLDA_TRY(cholesky_f64(h, Cc, D, dflag));
@@ -407,7 +531,9 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
   symmetrize_kernel<<<(unsigned)ceil_div((int64_t)DD, 256), 256, 0, h->stream>>>(G, D);
   PLDA_LAUNCH_CHECK(h);
-  PLDA_TRY(sym_eig_f64(h, G, D, psi, Vr, nullptr));
+  PLDA_TRY(sym_eig_f64(h, G, D, psi, warm ? tmp : Vr, nullptr, warm ? Vr : nullptr));
+  if (warm) PLDA_HIP(h, hipMemcpyAsync(Vr, tmp, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+  h->simdiag_has_vr = true;
   int hflag = 0;
   PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
