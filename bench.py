@@ -199,6 +199,17 @@ def main():
                      "note": "not in the timed region: scores stay row-sharded; gathering all of them is xGMI-bound"}
         del recv
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (same workload);
+    # bench.py itself cannot run PMC collection, so this is null unless that profile exists
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_trials_gemm.json")
+    if os.path.exists(tpath) and (M, Nt, dout) == (100000, 100000, 200):
+        try:
+            traffic = float(json.load(open(tpath))["hbm_bytes_per_launch"])
+            traffic_src = "profiles/traffic_trials_gemm.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+        except Exception:
+            traffic = None
+
     if rank == 0:
         trials = float(world) * M * Nt * args.steps
         value = trials / elapsed
@@ -215,7 +226,8 @@ def main():
                        "score_dtype": "f32 (fp64 bias terms, fp32 MFMA contraction)", "fit_dtype": "f64"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None, "kernel": "trials_gemm_kernel",
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": M * Nt * 4,
+                         "kernel": "trials_gemm_bigtile_kernel",
                          "flop_per_trial": 2 * dout, "avg_kernel_ms": round(avg_gemm_s * 1e3, 4),
                          "launches": launches, "hbm_write_GBps": round(M * Nt * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None},
             "fit": fit_info, "spot_check_max_abs_err": spot,

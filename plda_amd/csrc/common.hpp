@@ -61,7 +61,8 @@ struct plda_handle {
   int simdiag_D = 0;
   bool simdiag_has_vr = false;
 
-  int gemm_variant = 0;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
+  int gemm_variant = 0;
+  bool bt_attr_set = false;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
 
   // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
   bool prof_on = false;

@@ -380,6 +380,183 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Big-tile persistent form (EPI 0 only).  The 128x128 kernel above is limited by the
+// global->LDS DMA path (ablation: 93 % of MFMA peak without the in-loop DMA, 84 % with):
+// it moves 8 KiB per 64 MFMAs.  Here a workgroup of 8 waves (2 x 4) owns a 256 x 256 tile,
+// each wave 128 x 64 (4 x 2 MFMA tiles, 128 accumulator registers): 16 KiB per 256 MFMAs,
+// half the DMA bytes per flop, and 6 LDS fragment reads per 32 MFMAs instead of 4 per 16.
+// One workgroup per CU, persistent over tiles:
+//   * tile order: at iteration `it` XCD x works on patch (8 it + x) = BPR x BPC tiles, its
+//     32 workgroups take one tile each, so an XCD's resident tiles share 4 + 8 panels;
+//   * the next tile's first stage is DMA'd during the current tile's LAST stage, into the
+//     stage buffer that has just been freed; the other buffer (read by the last stage)
+//     becomes the wave-private staging area of the transposed epilogue;
+//   * LDS: 2 stages x 8 k-quads x 512 rows x 16 B = 128 KiB (dynamic).
+// ------------------------------------------------------------------------------------
+constexpr int BT_NKQ = 8;
+constexpr int BPR = 4, BPC = 8;   // patch of 256x256 tiles per XCD iteration (32 CUs)
+
+__device__ __forceinline__ void bt_stage(const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk,
+                                         int64_t Mpad, int64_t Npad, int kq0, int KQ, int64_t r0,
+                                         int64_t c0, f32x4 *buf, int wave, int lane) {
+  // 8 NKQ chunks of 64 rows; wave w takes chunks w, w + 8, ...: A rows 0..255 are chunks
+  // (kql, quarter) for c < 4 NKQ, B likewise after that.
+#pragma unroll
+  for (int j = 0; j < BT_NKQ; ++j) {
+    const int c = wave + 8 * j;
+    const bool isB = c >= 4 * BT_NKQ;
+    const int cc = isB ? c - 4 * BT_NKQ : c;
+    const int kql = cc >> 2, quarter = cc & 3;
+    const int kq = kq0 + kql;
+    if (kq < KQ) {
+      const f32x4 *g = isB ? Bpk + ((int64_t)kq * Npad + c0 + quarter * 64 + lane)
+                           : Apk + ((int64_t)kq * Mpad + r0 + quarter * 64 + lane);
+      f32x4 *l = buf + (isB ? BT_NKQ * 256 : 0) + kql * 256 + quarter * 64;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)g, (LDS_AS void *)l, 16, 0, 0);
+    }
+  }
+}
+
+#define BT_MFMA8(T, S)                                                                           \
+  _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) {                                             \
+    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[tm][T], S##b[0][T], acc[tm][0], 0, 0, 0); \
+    acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[tm][T], S##b[1][T], acc[tm][1], 0, 0, 0); \
+  }
+#define BT_LOAD(S, OFF)                                                                          \
+  _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) S##a[tm] = Al[(OFF) + tm * 32];              \
+  S##b[0] = Bl[(OFF)]; S##b[1] = Bl[(OFF) + 32];
+
+template <bool ZN>
+__global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
+    const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, int64_t Mpad, int64_t Npad,
+    int KQ, const float *__restrict__ rbias, const float *__restrict__ rscale,
+    const float *__restrict__ cbias, float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt,
+    int tilesM, int tilesN, int patchesN, int numPatches) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 smem[];   // 2 * BT_NKQ * 512 float4
+  constexpr int STAGE = BT_NKQ * 512;                             // float4 per stage buffer
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;            // 2 x 4 waves
+  const int i = lane & 31, hh = lane >> 5;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int nst = (KQ + BT_NKQ - 1) / BT_NKQ;
+  const int niter = (numPatches + 7) >> 3;
+
+  auto tile_of = [&](int it, int64_t &r0, int64_t &c0) -> bool {
+    const int patch = it * 8 + xcd;
+    if (patch >= numPatches) return false;
+    const int tm = (patch / patchesN) * BPR + lb / BPC;
+    const int tn = (patch % patchesN) * BPC + lb % BPC;
+    r0 = (int64_t)tm * 256;
+    c0 = (int64_t)tn * 256;
+    return tm < tilesM && tn < tilesN;
+  };
+
+  int base = 0;
+  int64_t r0 = 0, c0 = 0;
+  int it = 0;
+  bool have = false;
+  for (; it < niter; ++it)
+    if ((have = tile_of(it, r0, c0))) break;
+  if (have) bt_stage(Apk, Bpk, Mpad, Npad, 0, KQ, r0, c0, smem + base * STAGE, wave, lane);
+
+  while (have) {
+    const int64_t wrow0 = r0 + wm * 128, wcol0 = c0 + wn * 64;
+    const int64_t tr0 = r0, tc0 = c0;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    bool next_have = false;
+    int64_t nr0 = 0, nc0 = 0;
+    for (int st = 0; st < nst; ++st) {
+      __syncthreads();   // stage st landed (vmcnt(0) + barrier); everyone is done with stage st-1
+      f32x4 *other = smem + ((base + st + 1) & 1) * STAGE;
+      if (st + 1 < nst) {
+        bt_stage(Apk, Bpk, Mpad, Npad, (st + 1) * BT_NKQ, KQ, r0, c0, other, wave, lane);
+      } else {
+        // last stage: prefetch the NEXT tile's first stage into the freed buffer
+        for (++it; it < niter; ++it)
+          if ((next_have = tile_of(it, nr0, nc0))) break;
+        if (next_have) bt_stage(Apk, Bpk, Mpad, Npad, 0, KQ, nr0, nc0, other, wave, lane);
+      }
+      const f32x4 *cur = smem + ((base + st) & 1) * STAGE;
+      const int np = min(BT_NKQ, KQ - st * BT_NKQ) >> 1;
+      const f32x4 *Al = cur + hh * 256 + wm * 128 + i;
+      const f32x4 *Bl = cur + BT_NKQ * 256 + hh * 256 + wn * 64 + i;
+      f32x4 xa[4], xb[2], ya[4], yb[2];
+      BT_LOAD(x, 0)
+      int p = 0;
+#pragma unroll 1
+      for (; p + 1 < np; p += 2) {
+        BT_MFMA8(0, x)
+        __builtin_amdgcn_sched_barrier(0);
+        { const int o1 = (p + 1) * 512; BT_LOAD(y, o1) }
+        __builtin_amdgcn_sched_barrier(0);
+        BT_MFMA8(1, x) BT_MFMA8(2, x) BT_MFMA8(3, x)
+        BT_MFMA8(0, y)
+        __builtin_amdgcn_sched_barrier(0);
+        { const int o2 = min(p + 2, np - 1) * 512; BT_LOAD(x, o2) }
+        __builtin_amdgcn_sched_barrier(0);
+        BT_MFMA8(1, y) BT_MFMA8(2, y) BT_MFMA8(3, y)
+      }
+      if (p < np) { BT_MFMA8(0, x) BT_MFMA8(1, x) BT_MFMA8(2, x) BT_MFMA8(3, x) }
+    }
+
+    // ---- epilogue: staging area = the buffer the last stage read ----
+    float cb[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? cbias[wcol0 + tn * 32 + i] : 0.f;
+    __syncthreads();   // all waves are done reading the last stage's buffer
+    float *tw = reinterpret_cast<float *>(smem + ((base + nst - 1) & 1) * STAGE) + wave * 2048;
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+    const bool interior = (tr0 + 256 <= M) && (tc0 + 256 <= Nt) && ((ld & 3) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      f32x4 rb[4], rs[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rb[q] = *reinterpret_cast<const f32x4 *>(rbias + wrow0 + tm * 32 + 8 * q + 4 * hh);
+        if (ZN) rs[q] = *reinterpret_cast<const f32x4 *>(rscale + wrow0 + tm * 32 + 8 * q + 4 * hh);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[tm][tn][r] + cb[tn];
+          v = ZN ? v * rs[r >> 2][r & 3] + rb[r >> 2][r & 3] : v + rb[r >> 2][r & 3];
+          tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + tn * 32 + i] = v;
+        }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int lr = rrow + 4 * k;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tw + lr * 64 + rcol);
+        const int64_t row = wrow0 + tm * 32 + lr;
+        float *dst = out + row * ld + wcol0 + rcol;
+        if (interior) {
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+        } else if (row < M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
+        }
+      }
+    }
+    base = (base + nst) & 1;
+    have = next_have;
+    r0 = nr0; c0 = nc0;
+  }
+}
+#undef BT_MFMA8
+#undef BT_LOAD
+
 // finalise fused z-norm statistics: mean = shift + S1/N, std = sqrt(S2/N - (S1/N)^2)
 __global__ void znorm_finalize_kernel(const float *__restrict__ shift, const double *__restrict__ colsum,
                                       const double *__restrict__ colsq, int64_t M, double invN,
@@ -489,8 +666,8 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   op.Kg = op.mixed ? 2 * Dp : Dp;
   op.Kg_alg = op.mixed ? 2 * D : D;
   op.KQ = op.Kg / 4;
-  op.Mpad = round_up(M, 128);
-  op.Npad = round_up(Nt, 128);
+  op.Mpad = round_up(M, 256);   // 256: the big-tile kernel's block tile (the 128 kernel tolerates it)
+  op.Npad = round_up(Nt, 256);
   PLDA_HIP(h, h->s_Apk.reserve((size_t)op.KQ * op.Mpad * 16));
   PLDA_HIP(h, h->s_Bpk.reserve((size_t)op.KQ * op.Npad * 16));
   PLDA_HIP(h, h->s_rbias.reserve((size_t)op.Mpad * 4));
@@ -546,6 +723,28 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     h->prof_used++;
     h->prof_flop += 2.0 * (double)op.Kg_alg * (double)M * (double)Nt;
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
+  }
+  // big-tile persistent kernel: when there are enough 256x256 tiles to keep 256 CUs busy
+  const int btM = (int)ceil_div(M, 256), btN = (int)(op.Npad / 256);
+  const bool use_bt = EPI == 0 && h->gemm_variant != 20 &&
+                      (h->gemm_variant == 21 || (h->gemm_variant == 0 && (int64_t)btM * btN >= 1024));
+  if (use_bt) {
+    const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
+    const size_t lds = (size_t)2 * BT_NKQ * 512 * 16;
+    if (!h->bt_attr_set) {
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      h->bt_attr_set = true;
+    }
+    trials_gemm_bigtile_kernel<ZN><<<256, 512, lds, h->stream>>>(
+        h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),
+        use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout, ld,
+        M, Nt, btM, btN, pN, pM * pN);
+    PLDA_LAUNCH_CHECK(h);
+    if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
+    return PLDA_OK;
   }
   // Kernel instantiations.  Variant 0 is the product configuration; the others are the
   // tuning / ablation arms of scripts/gemm_sweep.py (PLDA_GEMM_VARIANT), kept because the

@@ -11,7 +11,7 @@ ARGS="${BENCH_ARGS:---steps 3 --warmup 1 --no-cpu}"
 ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/write_bench.json 2> $OUT/write.err )
 find $OUT -type f | head -50
 python $GRAFT_REPO_ROOT/scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+cat $OUT/summary.txt; cat $OUT/traffic_trials_gemm.json
 # keep only small artefacts for the merge back
 find $OUT -name "*.csv" -size +4M -delete
 find $OUT -name "*.db" -delete
