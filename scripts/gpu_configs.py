@@ -1,0 +1,151 @@
+"""scripts/gpu_configs.py -- runs the single-GPU part of BASELINE.json configs C3, C4, C5
+at full size (synthetic, seeded), checks size-independent properties against the fp64
+trial-list kernel / invariants, and prints timings as JSON.  Parity-test cases, not bench
+lines (bench.py measures C2)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from plda_amd import MPlda
+
+dev = torch.device("cuda", 0)
+res = {}
+
+
+def spot(eng, dU, counts, dT, out, rng, P=2048):
+    """random trials of a device score matrix vs the fp64 trial-list kernel"""
+    M, Nt = out.shape
+    e = rng.integers(0, M, P); t = rng.integers(0, Nt, P)
+    ue, ui = np.unique(e, return_inverse=True)
+    ut, ti = np.unique(t, return_inverse=True)
+    Uh = dU[torch.from_numpy(ue).to(dev)].cpu().numpy()
+    Th = dT[torch.from_numpy(ut).to(dev)].cpu().numpy()
+    ch = counts[ue] if isinstance(counts, np.ndarray) else np.full(len(ue), counts, np.int32)
+    ref = eng.score_trials((ch.astype(np.int32), Uh), (1, Th), ui, ti, znorm=False)
+    got = out[torch.from_numpy(e).to(dev), torch.from_numpy(t).to(dev)].cpu().numpy().astype(np.float64)
+    tol = 1e-4 * np.maximum(np.abs(ref), np.abs(ref).mean())
+    return bool((np.abs(got - ref) <= tol).all()), float(np.abs(got - ref).max()), float(np.abs(ref).mean())
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def c3():
+    """1M x-vectors, D=512, 10k speakers; fit; 10k speaker models (n=100) x 1M tests."""
+    N, D, K = 1_000_000, 512, 10_000
+    rng = np.random.default_rng(3)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    X = torch.from_numpy(rng.random((N, D))).to(dev)
+    y = torch.from_numpy((np.arange(N) % K).astype(np.int64)).to(dev)
+    eng.fit_dev(X.data_ptr(), N, D, y.data_ptr(), K, 10)
+    t0 = time.perf_counter(); eng.fit_dev(X.data_ptr(), N, D, y.data_ptr(), K, 10); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ft = eng.fit_timings()
+    m = eng.get_model(); it = eng.fit_internals()
+    T, psi = m["transform"], m["psi"]
+    inv1 = float(np.abs(T @ it["W"] @ T.T - np.eye(D)).max())
+    inv2 = float(np.abs(T @ it["B"] @ T.T - np.diag(psi)).max())
+    out = {"fit_wall_s": wall, "stats_ms": ft["stats_ms"], "em_ms_per_iter": ft["em_ms"] / 10, "output_ms": ft["output_ms"],
+           "TWT_minus_I": inv1, "TBT_minus_psi": inv2, "psi_desc_nonneg": bool((np.diff(psi) <= 0).all() and (psi >= 0).all())}
+    # enrol = speaker means (n = 100), test = all 1M vectors
+    means = torch.from_numpy(it["means"]).to(dev)
+    dU = torch.empty((K, D), dtype=torch.float64, device=dev)
+    dT = torch.empty((N, D), dtype=torch.float64, device=dev)
+    eng.transform_rows_dev(means.data_ptr(), K, D, None, 100, dU.data_ptr())
+    eng.transform_rows_dev(X.data_ptr(), N, D, None, 1, dT.data_ptr())
+    del X
+    S = torch.empty((K, N), dtype=torch.float32, device=dev)
+    dt = timed(lambda: eng.score_matrix_dev(dU.data_ptr(), None, 100, K, dT.data_ptr(), N, S.data_ptr(), N))
+    ok, err, scale = spot(eng, dU, 100, dT, S, rng)
+    out.update({"score_ms": dt * 1e3, "trials_per_s": K * N / dt, "tflops": 2 * D * K * N / dt / 1e12,
+                "spot_ok": ok, "spot_max_err": err, "mean_abs_score": scale})
+    # targetdim = 200 (build extension)
+    eng.truncate(200)
+    dU2 = torch.empty((K, 200), dtype=torch.float64, device=dev)
+    dT2 = torch.empty((N, 200), dtype=torch.float64, device=dev)
+    Xm = torch.from_numpy(np.random.default_rng(3).random((N, D))).to(dev)
+    eng.transform_rows_dev(means.data_ptr(), K, D, None, 100, dU2.data_ptr())
+    eng.transform_rows_dev(Xm.data_ptr(), N, D, None, 1, dT2.data_ptr())
+    del Xm
+    dt2 = timed(lambda: eng.score_matrix_dev(dU2.data_ptr(), None, 100, K, dT2.data_ptr(), N, S.data_ptr(), N))
+    ok2, err2, _ = spot(eng, dU2, 100, dT2, S, rng)
+    out.update({"targetdim200_score_ms": dt2 * 1e3, "targetdim200_trials_per_s": K * N / dt2, "targetdim200_spot_ok": ok2})
+    return out
+
+
+def c4_shard():
+    """one rank's slab of C4: 5000 (= 40k / 8) enrol models with n in 1..5 x 1.2M tests, D=256 (GEMM depth 512)."""
+    D, M, Nt = 256, 5000, 1_200_000
+    rng = np.random.default_rng(4)
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.set_model(rng.random(D), q * (1 + rng.random(D))[:, None], np.sort(rng.random(D) * 5)[::-1].copy())
+    counts = rng.integers(1, 6, M).astype(np.int32)
+    dn = torch.from_numpy(counts).to(dev)
+    E = torch.from_numpy(rng.random((M, D))).to(dev); V = torch.from_numpy(rng.random((Nt, D))).to(dev)
+    dU = torch.empty((M, D), dtype=torch.float64, device=dev); dT = torch.empty((Nt, D), dtype=torch.float64, device=dev)
+    eng.transform_rows_dev(E.data_ptr(), M, D, dn.data_ptr(), 0, dU.data_ptr())
+    eng.transform_rows_dev(V.data_ptr(), Nt, D, None, 1, dT.data_ptr())
+    S = torch.empty((M, Nt), dtype=torch.float32, device=dev)
+    dt = timed(lambda: eng.score_matrix_dev(dU.data_ptr(), dn.data_ptr(), 0, M, dT.data_ptr(), Nt, S.data_ptr(), Nt))
+    ok, err, scale = spot(eng, dU, counts, dT, S, rng)
+    return {"score_ms": dt * 1e3, "trials_per_s": M * Nt / dt, "gemm_depth": 2 * D, "tflops": 4 * D * M * Nt / dt / 1e12,
+            "spot_ok": ok, "spot_max_err": err, "mean_abs_score": scale}
+
+
+def c5():
+    """z-norm: 50k models (n=1) vs 200k cohort, fused (1e10 LLRs, no matrix), then 50k x 50k z-normed trials."""
+    D, M, Nb = 200, 50_000, 200_000
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.set_model(rng.random(D), q * (1 + rng.random(D))[:, None], np.sort(rng.random(D) * 5)[::-1].copy())
+    E = torch.from_numpy(rng.random((M, D))).to(dev)
+    dU = torch.empty((M, D), dtype=torch.float64, device=dev)
+    eng.transform_rows_dev(E.data_ptr(), M, D, None, 1, dU.data_ptr())
+    bkg = torch.from_numpy(rng.random((Nb, D))).to(dev)
+    zm = torch.empty(M, dtype=torch.float64, device=dev); zs = torch.empty(M, dtype=torch.float64, device=dev)
+    dt = timed(lambda: eng.znorm_stats_dev(bkg.data_ptr(), Nb, 0, D, dU.data_ptr(), M, zm.data_ptr(), zs.data_ptr()), reps=2)
+    # reference for 3 models over the full cohort with the fp64 trial-list kernel (roles as in MPlda_norm)
+    cohort_t = torch.empty((Nb, D), dtype=torch.float64, device=dev)
+    eng.transform_rows_dev(bkg.data_ptr(), Nb, D, None, Nb, cohort_t.data_ptr())
+    Ch = cohort_t.cpu().numpy()
+    sel = np.array([0, M // 2, M - 1])
+    Mh = dU[torch.from_numpy(sel).to(dev)].cpu().numpy()
+    okz, worst = True, 0.0
+    for k, j in enumerate(sel):
+        s = eng.score_trials((np.ones(Nb, np.int32), Ch), (1, Mh[k:k + 1]), np.arange(Nb), np.zeros(Nb, np.int64), znorm=False)
+        rm, rs = s.mean(), s.std()
+        gm, gs = float(zm[j]), float(zs[j])
+        e1 = abs(gm - rm) / max(abs(rm), np.abs(s).mean()); e2 = abs(gs - rs) / rs
+        worst = max(worst, e1, e2)
+        okz = okz and e1 < 1e-4 and e2 < 1e-4
+    out = {"znorm_ms": dt * 1e3, "llr_per_s": M * Nb / dt, "znorm_ok": bool(okz), "znorm_worst_rel_err": float(worst)}
+    S = torch.empty((M, M), dtype=torch.float32, device=dev)
+    dt2 = timed(lambda: eng.score_matrix_dev(dU.data_ptr(), None, 1, M, dU.data_ptr(), M, S.data_ptr(), M, zm.data_ptr(), zs.data_ptr()))
+    out.update({"znormed_50kx50k_ms": dt2 * 1e3, "znormed_trials_per_s": M * M / dt2, "finite": bool(torch.isfinite(S[::499]).all())})
+    return out
+
+
+for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5)):
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        continue
+    t0 = time.perf_counter()
+    try:
+        res[name] = fn()
+    except Exception as ex:  # report, keep going
+        res[name] = {"error": repr(ex)}
+    res[name]["wall_s"] = time.perf_counter() - t0
+    torch.cuda.empty_cache()
+print(json.dumps(res, indent=1))
