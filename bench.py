@@ -65,13 +65,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100000, help="i-vectors (fit rows = enrol rows per rank = test rows)")
+    ap.add_argument("--rows", dest="n", type=int, default=100000, help="i-vectors (fit rows = enrol rows per rank = test rows)")
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--speakers", type=int, default=5000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--targetdim", type=int, default=0, help="build extension: keep the top-psi dims (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--gather-rows", type=int, default=2048, help="rows per rank in the separately timed all-gather")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for logic checks)")
+    ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -79,14 +81,17 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from plda_amd import MPlda
     eng = MPlda(local_rank)

@@ -49,7 +49,7 @@ struct plda_handle {
   double fit_ms[4] = {0, 0, 0, 0};
 
   // ---- scoring workspace ----
-  plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias, s_coef;
+  plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias;
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 

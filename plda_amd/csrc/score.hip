@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------
-// K5 / K8: the trials GEMM.
+// K5 / K8: the trials GEMM, 128 x 128 form (small / medium problems and the fused z-norm
+// epilogue; large EPI-0 problems take the persistent 256 x 256 form further down).
 //   block  = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64
 //            = 2 x 2 MFMA tiles of 32 x 32 (64 fp32 accumulators per lane)
 //   stage  = NKQ k-quads (4 NKQ values of k) of both operands, global->LDS by DMA,
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
 //   grid   = 1-D, XCD-aware: block b -> XCD b % 8 (observed dispatch order), and each
 //            XCD walks its own sequence of PM x PN tile patches so that the panels
 //            its resident blocks share stay in that XCD's 4 MiB L2.
-//   EPI 0  : out[i][j] = rscale_i * (acc + cbias_j) + rbias_i, non-temporal stores
+//   EPI 0  : out[i][j] = rscale_i * (acc + cbias_j) + rbias_i, transposed through LDS and
+//            written as 16-byte non-temporal stores
 //   EPI 1  : fused z-norm statistics -- per column j accumulate sum / sum of squares
 //            of (score - shift_j) over rows i < M into fp64 (no score matrix)
 // ------------------------------------------------------------------------------------

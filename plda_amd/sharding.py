@@ -57,7 +57,6 @@ def score_matrix_sharded(score_block, U_local, n_local, V, m_global, gather=Fals
     gathered = torch.empty((world, m_pad, nt), dtype=torch.float32, device=dev)
     use_streams = dev.type == "cuda"
     side = torch.cuda.Stream(device=dev) if use_streams else None
-    works = []
     for r0 in range(0, m_pad, slab_rows):
         r1 = min(m_pad, r0 + slab_rows)
         send = torch.zeros((r1 - r0, nt), dtype=torch.float32, device=dev)
@@ -79,7 +78,6 @@ def score_matrix_sharded(score_block, U_local, n_local, V, m_global, gather=Fals
             dist.all_gather(parts, send, group=group)
             for w, p in enumerate(parts):
                 gathered[w, r0:r1] = p
-        works.append(None)
     if use_streams:
         torch.cuda.current_stream(dev).wait_stream(side)
     # drop the padding rows and restore global order
