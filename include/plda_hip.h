@@ -150,6 +150,19 @@ int plda_znorm_stats_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t
                          int32_t Din, const double *dmodels, int64_t M, double *dout_mean,
                          double *dout_std);
 
+/* ---- d-vector front-end (the step before the path): replaces
+ * scoring/extractdvector.py:19-58 -- per-frame L2 normalisation (getnormalizedvector,
+ * :19-29; skipped when l2norm == 0, the *_nol2 variants :50-59) and pooling over each
+ * utterance's frames: method 0 = mean (:37-39), 1 = max (:32-34), 2 = population
+ * variance (:42-47).  frames [T, D] row-major, dtype 0 = float32 / 1 = float64;
+ * offsets[U+1] frame boundaries of the U utterances; out [U, D] fp64. ---- */
+int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t T, int32_t D,
+                      const int64_t *offsets, int64_t U, int32_t method, int32_t l2norm,
+                      double *out);
+int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, int64_t T, int32_t D,
+                          const int64_t *doffsets, int64_t U, int32_t method, int32_t l2norm,
+                          double *dout);
+
 #ifdef __cplusplus
 }
 #endif

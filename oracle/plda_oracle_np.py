@@ -154,3 +154,16 @@ def smooth(model, f):
     out["transform"] = model["transform"] * (wc ** -0.5)[:, None]
     out["offset"] = -out["transform"] @ model["mean"]
     return out
+
+
+def dvector_pool(frames, offsets, method="mean", l2norm=True):
+    """d-vector front-end (scoring/extractdvector.py:19-59): getnormalizedvector (:19-29)
+    then np.mean / np.max / np.var over each utterance's frames (:32-47), in float64."""
+    frames = np.asarray(frames, np.float64)
+    out = []
+    for a, b in zip(offsets[:-1], offsets[1:]):
+        u = frames[a:b]
+        if l2norm:
+            u = u / np.linalg.norm(u, axis=1)[:, np.newaxis]
+        out.append({"mean": np.mean, "max": np.max, "var": np.var}[method](u, axis=0))
+    return np.array(out)

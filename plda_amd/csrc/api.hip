@@ -464,4 +464,32 @@ int plda_znorm_stats(plda_handle *h, const double *bkg, int64_t Nb, int32_t num_
   return PLDA_OK;
 }
 
+// ---------------------------------------------------------------- d-vector front-end
+int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, int64_t T, int32_t D,
+                          const int64_t *doffsets, int64_t U, int32_t method, int32_t l2norm, double *dout) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return dvector_pool_device(h, dframes, dtype, T, D, doffsets, U, method, l2norm, dout);
+}
+
+int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t T, int32_t D, const int64_t *offsets,
+                      int64_t U, int32_t method, int32_t l2norm, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (U <= 0) return PLDA_OK;
+  if (!frames || !offsets || !out || T < 0 || D <= 0 || (dtype != 0 && dtype != 1))
+    return fail(h, PLDA_E_INVAL, "dvector_pool: bad argument");
+  for (int64_t u = 0; u < U; ++u)
+    if (offsets[u] < 0 || offsets[u + 1] < offsets[u] || offsets[u + 1] > T)
+      return fail(h, PLDA_E_INVAL, "dvector_pool: offsets must be non-decreasing within [0, T]");
+  PLDA_TRY(set_device(h));
+  Tmp dF, dO, dOut;
+  PLDA_TRY(upload(h, dF, frames, (size_t)T * D * (dtype == 0 ? 4 : 8)));
+  PLDA_TRY(upload(h, dO, offsets, (size_t)(U + 1) * 8));
+  PLDA_HIP(h, dOut.alloc((size_t)U * D * 8));
+  PLDA_TRY(dvector_pool_device(h, dF.p, dtype, T, D, dO.as<int64_t>(), U, method, l2norm, dOut.as<double>()));
+  PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, (size_t)U * D * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
 }  // extern "C"

@@ -120,6 +120,10 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T,
                 double *Tinv, double *psi, bool warm_start);
 
+// ---- frontend.hip ----
+int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t T, int D,
+                        const int64_t *doffsets, int64_t U, int method, int l2norm, double *dout);
+
 // ---- fit.hip ----
 int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels,
                int64_t K, int iters);
@@ -127,5 +131,29 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
 // ---- score.hip ----
 int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din,
                           const int32_t *dn, int n_uniform, double *dout);
+
+#ifdef __HIPCC__
+// fp64 wave-wide sum through DPP: quad butterflies, then half-row and row mirrors (every
+// lane of a 16-lane row then holds the row sum), then four readlanes.  ~6x shorter
+// dependency chain than __shfl_xor, which lowers to ds_bpermute for 64-bit values.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                          __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+  x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_f64<0x141>(x);   // row_half_mirror
+  x += dpp_f64<0x140>(x);   // row_mirror
+  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+#endif
 
 }  // namespace plda

@@ -278,28 +278,6 @@ int tri_invert_f64(plda_handle *h, const double *L, double *X, int D) {
 // rotations are applied per round trip to L2 instead of one.
 constexpr int JB = 4;
 
-// fp64 wave-wide sum through DPP: quad butterflies, then half-row and row mirrors (every
-// lane of a 16-lane row then holds the row sum), then four readlanes.  ~6x shorter
-// dependency chain than __shfl_xor, which lowers to ds_bpermute for 64-bit values.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double x, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
-                          __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-__device__ __forceinline__ double wave_sum_f64(double x) {
-  x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]
-  x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]
-  x += dpp_f64<0x141>(x);   // row_half_mirror
-  x += dpp_f64<0x140>(x);   // row_mirror
-  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
-}
-
 template <int E>
 __global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ A, double *__restrict__ V,
                                                            int D, int nb_even, int oround, double tol,

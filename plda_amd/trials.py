@@ -1,0 +1,78 @@
+"""plda_amd/trials.py -- trial lists and the score file around the hot path (SURVEY.md section 8f
+rank 1): what /root/reference/scoring/scorePLDA.py does right after `plda.transform`.
+
+  parse_trial_ref  = test_ref   (scorePLDA.py:40-50)   "target enrol-testutt" lines
+  parse_mlf        = mlffile    (scorePLDA.py:55-73)   HTK master-label files
+  score_trial_list = the scoring loop (scorePLDA.py:299-321), same skip/warn rules and the
+                     same output bytes ("{} {}-{} {:.3f}\\n", :317-318), but ONE batched
+                     fp64 trial-list launch instead of one `plda.score` call per trial.
+"""
+import logging
+from collections import OrderedDict
+
+import numpy as np
+
+log = logging.getLogger(__name__)
+
+
+def parse_trial_ref(path):
+    """{target model: [[testutt, enrol model], ...]} in file order (scorePLDA.py:40-50)."""
+    tests = OrderedDict()
+    with open(path, "r") as fp:
+        for line in fp:
+            line = line.rstrip("\n")
+            if not line.strip():
+                continue
+            targetmdl, enrol_testutt = line.split()[:2]
+            parts = enrol_testutt.split("-")
+            tests.setdefault(targetmdl, []).append(["-".join(parts[1:]), parts[0]])
+    return tests
+
+
+def parse_mlf(path):
+    """Same structure from an HTK MLF (scorePLDA.py:55-73)."""
+    tests = OrderedDict()
+    with open(path, "r") as fp:
+        next(fp)  # "#!MLF!#"
+        for line in fp:
+            line = line.rstrip("\n")
+            if line.startswith('"'):
+                withoutslashes = line.split(".")[0].split("/")[1]
+                parts = withoutslashes.split("-")
+                targetmdl = next(fp).rstrip("\n")
+                tests.setdefault(targetmdl, []).append(["-".join(parts[1:]), parts[0]])
+    return tests
+
+
+def score_trial_list(plda, testreference, enroltransform, testtransform, enrolspktonum, testspktonum,
+                     scoreoutfile, znorm=True):
+    """Score every (model, utterance) trial of `testreference` and write the reference's score
+    file.  Returns (n_scored, n_errors).  `plda` is a liblda.PLDA / plda_amd.MPlda."""
+    enrol_ids = list(enroltransform.keys())
+    test_ids = list(testtransform.keys())
+    epos = {k: i for i, k in enumerate(enrol_ids)}
+    tpos = {k: i for i, k in enumerate(test_ids)}
+    e_idx, t_idx, rows = [], [], []
+    errors = 0
+    for enrolemodel, vals in testreference.items():
+        if enrolemodel not in enrolspktonum:                       # scorePLDA.py:303-306
+            errors += 1
+            log.warning("Enrolemodel %s not found in the labels", enrolemodel)
+            continue
+        enrolspk = enrolspktonum[enrolemodel]
+        for testutt, targetmdl in vals:
+            if testutt not in testspktonum:                        # :309-312
+                log.warning("Utterance %s not found in the testset", testutt)
+                errors += 1
+                continue
+            e_idx.append(epos[enrolspk])
+            t_idx.append(tpos[testspktonum[testutt]])
+            rows.append((enrolemodel, targetmdl, testutt))
+    if rows:
+        scorer = getattr(plda, "score_trials", None) or plda._instance.score_trials
+        scores = scorer(enroltransform, testtransform, np.asarray(e_idx), np.asarray(t_idx), znorm)
+        for (enrolemodel, targetmdl, testutt), s in zip(rows, scores):
+            scoreoutfile.write("{} {}-{} {:.3f}\n".format(enrolemodel, targetmdl, testutt, s))   # :317-318
+    if errors > 0:
+        log.warning("Overall %i errors occured during the testing phase!", errors)
+    return len(rows), errors

@@ -148,3 +148,26 @@ def test_smooth_and_truncate(engine, oracle):
     assert engine.dims() == (12, d)
     out = engine.transform_array(x[:5], 1)
     assert out.shape == (5, 12)
+
+
+def test_trial_list_scoring_matches_per_call_score(engine, oracle):
+    """scorePLDA.py's loop (one plda.score per trial) == one batched trial-list launch."""
+    import io
+    from liblda import PLDA
+    from plda_amd import trials
+    x, y = make_data(31, 600, 24, 12, scale_between=0.5)
+    p = PLDA()
+    p.fit(x, y, 4)
+    enrol = p.transform(x[:120], y[:120])
+    test = p.transform(x[120:150], np.arange(30, dtype=np.uint64))
+    p.norm(x[200:280], enrol)
+    names_e = {"m%d" % k: k for k in enrol}
+    names_t = {"u-%d" % k: k for k in test}
+    ref = {"m%d" % k: [["u-%d" % j, "m%d" % k] for j in (0, 7, 29)] for k in list(enrol)[:5]}
+    out = io.StringIO()
+    n, err = trials.score_trial_list(p, ref, enrol, test, names_e, names_t, out)
+    assert (n, err) == (15, 0)
+    lines = out.getvalue().splitlines()
+    for line, (k, j) in zip(lines, [(k, j) for k in list(enrol)[:5] for j in (0, 7, 29)]):
+        expect = "m%d m%d-u-%d %.3f" % (k, k, j, p.score(k, enrol[k], test[j]))
+        assert line == expect
