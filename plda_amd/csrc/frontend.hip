@@ -72,13 +72,119 @@ __global__ __launch_bounds__(256) void dvector_pool_kernel(const T *__restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Vectorised path: float32 frames with D = 4 G, G a power of two in [4, 64].  A frame is G
+// float4 items, so one wave-wide 16-byte load fetches 64 / G whole frames (1 KiB per
+// instruction); four such loads are issued back to back before any arithmetic so that
+// the reductions of one batch overlap the loads of the next.  The frame norm is a G-lane
+// butterfly (DPP inside a 16-lane row, ds_bpermute across rows).
+// ------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ double group_sum_f64(double x) {
+  if (G >= 2) x += dpp_f64<0xB1>(x);    // xor 1
+  if (G >= 4) x += dpp_f64<0x4E>(x);    // xor 2
+  if (G >= 8) x += dpp_f64<0x141>(x);   // quads already uniform: half-row mirror == xor 4
+  if (G >= 16) x += dpp_f64<0x140>(x);  // row mirror == xor 8
+  if (G >= 32) x += __shfl_xor(x, 16);
+  if (G >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int G>
+__global__ __launch_bounds__(256) void dvector_pool_vec4_kernel(const f32x4v *__restrict__ frames,
+                                                                const int64_t *__restrict__ offsets,
+                                                                int method, int l2norm,
+                                                                double *__restrict__ out) {
+  constexpr int FPW = 64 / G;   // frames per wave-wide load
+  constexpr int UNR = 4;
+  __shared__ double part[3][4][4 * G];
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane / G, c = lane % G;
+  const int64_t beg = offsets[u], end = offsets[u + 1];
+  const int64_t n = end - beg;
+  double sum[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+  double mx[4] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+  for (int64_t base = beg + (int64_t)wave * FPW * UNR; base < end; base += 4 * FPW * UNR) {
+    f32x4v x[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const int64_t f = base + k * FPW + fr;
+      ok[k] = f < end;
+      x[k] = ok[k] ? __builtin_nontemporal_load(frames + f * G + c) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      double y[4] = {(double)x[k].x, (double)x[k].y, (double)x[k].z, (double)x[k].w};
+      if (l2norm) {
+        const double ss = group_sum_f64<G>(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
+        const double inv = 1.0 / sqrt(ss);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] *= inv;
+      }
+      if (ok[k]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sum[e] += y[e];
+          sq[e] += y[e] * y[e];
+          mx[e] = (y[e] > mx[e] || y[e] != y[e]) ? y[e] : mx[e];
+        }
+      }
+    }
+  }
+  // combine the FPW frame groups of the wave (lanes with equal c), then the 4 waves
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sum[e] += __shfl_xor(sum[e], o);
+      sq[e] += __shfl_xor(sq[e], o);
+      const double m2 = __shfl_xor(mx[e], o);
+      mx[e] = (m2 > mx[e] || m2 != m2) ? m2 : mx[e];
+    }
+  }
+  if (fr == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      part[0][wave][4 * c + e] = sum[e];
+      part[1][wave][4 * c + e] = sq[e];
+      part[2][wave][4 * c + e] = mx[e];
+    }
+  }
+  __syncthreads();
+  const int d = threadIdx.x;
+  if (d < 4 * G) {
+    const double s = (part[0][0][d] + part[0][1][d]) + (part[0][2][d] + part[0][3][d]);
+    const double q = (part[1][0][d] + part[1][1][d]) + (part[1][2][d] + part[1][3][d]);
+    double m = part[2][0][d];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { const double v = part[2][w][d]; m = (v > m || v != v) ? v : m; }
+    const double nn = (double)n;
+    double r;
+    if (n == 0) r = __builtin_nan("");
+    else if (method == 0) r = s / nn;
+    else if (method == 1) r = m;
+    else { const double mean = s / nn; r = q / nn - mean * mean; if (r < 0.0) r = 0.0; }
+    out[(int64_t)u * (4 * G) + d] = r;
+  }
+}
+
 int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t T, int D,
                         const int64_t *doffsets, int64_t U, int method, int l2norm, double *dout) {
   if (U <= 0) return PLDA_OK;
   if (!dframes || !doffsets || !dout || D <= 0 || D > 64 * DV_MAXE || T < 0 || method < 0 || method > 2 ||
       (dtype != 0 && dtype != 1))
     return fail(h, PLDA_E_INVAL, "dvector_pool: bad argument (D must be <= %d, dtype 0=f32/1=f64, method 0..2)", 64 * DV_MAXE);
-  if (dtype == 0)
+  if (dtype == 0 && (reinterpret_cast<uintptr_t>(dframes) & 15) == 0 &&
+      (D == 16 || D == 32 || D == 64 || D == 128 || D == 256)) {
+    const f32x4v *fv = static_cast<const f32x4v *>(dframes);
+#define DV(G_) dvector_pool_vec4_kernel<G_><<<(unsigned)U, 256, 0, h->stream>>>(fv, doffsets, method, l2norm, dout)
+    if (D == 16) DV(4); else if (D == 32) DV(8); else if (D == 64) DV(16); else if (D == 128) DV(32); else DV(64);
+#undef DV
+  } else if (dtype == 0)
     dvector_pool_kernel<float><<<(unsigned)U, 256, 0, h->stream>>>(static_cast<const float *>(dframes), D, doffsets,
                                                                   method, l2norm, dout);
   else

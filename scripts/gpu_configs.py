@@ -138,7 +138,31 @@ def c5():
     return out
 
 
-for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5)):
+def frontend():
+    """d-vector pooling: 200k utterances x 100 frames x 64 dims, float32 -> HBM GB/s."""
+    import ctypes as C
+    U, F, D = 200_000, 100, 64
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    frames = torch.randn((U * F, D), dtype=torch.float32, device=dev)
+    off = torch.arange(0, (U + 1) * F, F, dtype=torch.int64, device=dev)
+    out = torch.empty((U, D), dtype=torch.float64, device=dev)
+    def run(method):
+        rc = eng._lib.plda_dvector_pool_dev(eng._h, C.c_void_p(frames.data_ptr()), 0, U * F, D, C.c_void_p(off.data_ptr()), U,
+                                            method, 1, C.c_void_p(out.data_ptr()))
+        assert rc == 0
+    res = {}
+    for name, m in (("mean", 0), ("max", 1), ("var", 2)):
+        dt = timed(lambda: run(m), reps=5)
+        res[name + "_ms"] = dt * 1e3
+        res[name + "_GBps"] = frames.numel() * 4 / dt / 1e9
+    ref = torch.nn.functional.normalize(frames[:F * 3].double().view(3, F, D), dim=2).mean(1)
+    run(0); torch.cuda.synchronize()
+    res["check_max_err"] = float((out[:3] - ref).abs().max())
+    res["bytes"] = frames.numel() * 4
+    return res
+
+
+for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend)):
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     t0 = time.perf_counter()
