@@ -282,6 +282,8 @@ class MPlda(object):
         _, _, V = self._unpack(test)
         m, nt = U.shape[0], V.shape[0]
         out = np.zeros((m, nt), np.float32)
+        if m == 0 or nt == 0:
+            return out
         zm, zs = self._zn_arrays(ids, znorm)
         uniform = int(counts[0]) if np.all(counts == counts[0]) else 0
         self._ck(self._lib.plda_score_matrix(self._h, _ptr(U), None if uniform else _ptr(counts), uniform, m,
@@ -292,9 +294,11 @@ class MPlda(object):
         """Sparse trial list in fp64: out[p] = score(enrol[e_idx[p]], test[t_idx[p]])."""
         ids, counts, U = self._unpack(enrol)
         _, _, V = self._unpack(test)
-        e = np.ascontiguousarray(e_idx, np.int64)
-        t = np.ascontiguousarray(t_idx, np.int64)
+        e = np.ascontiguousarray(e_idx, np.int64).reshape(-1)
+        t = np.ascontiguousarray(t_idx, np.int64).reshape(-1)
         out = np.zeros(e.shape[0])
+        if e.shape[0] == 0:
+            return out
         zm, zs = self._zn_arrays(ids, znorm)
         self._ck(self._lib.plda_score_pairs(self._h, _ptr(U), _ptr(counts), U.shape[0], _ptr(V), V.shape[0],
                                             _ptr(e), _ptr(t), e.shape[0], _ptr(zm), _ptr(zs), _ptr(out)))

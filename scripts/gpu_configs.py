@@ -138,6 +138,42 @@ def c5():
     return out
 
 
+def c2_skew():
+    """C2 with skewed speaker sizes (n_k in 5..60): fit on the GPU, invariants + oracle-free checks."""
+    N, D, K = 100_000, 200, 5000
+    rng = np.random.default_rng(22)
+    sizes = rng.integers(5, 61, K)
+    sizes = np.floor(sizes * (N / sizes.sum())).astype(np.int64); sizes[-1] += N - sizes.sum()
+    y = np.repeat(np.arange(K), sizes); rng.shuffle(y)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    X = torch.from_numpy(rng.random((N, D)) + 0.3 * rng.standard_normal((K, D))[y]).to(dev)
+    yy = torch.from_numpy(y.astype(np.int64)).to(dev)
+    eng.fit_dev(X.data_ptr(), N, D, yy.data_ptr(), K, 10)
+    t0 = time.perf_counter(); eng.fit_dev(X.data_ptr(), N, D, yy.data_ptr(), K, 10); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ft = eng.fit_timings(); m = eng.get_model(); it = eng.fit_internals()
+    T, psi = m["transform"], m["psi"]
+    Xh = X.cpu().numpy()
+    means_ref = np.zeros((K, D)); np.add.at(means_ref, y, Xh); means_ref /= sizes[:, None]
+    return {"fit_wall_s": wall, "stats_ms": ft["stats_ms"], "em_ms_per_iter": ft["em_ms"] / 10, "distinct_n": int(len(np.unique(sizes))),
+            "counts_ok": bool((it["counts"] == sizes).all()), "means_rel_err": float(np.abs(it["means"] - means_ref).max() / np.abs(means_ref).max()),
+            "TWT_minus_I": float(np.abs(T @ it["W"] @ T.T - np.eye(D)).max()),
+            "TBT_minus_psi": float(np.abs(T @ it["B"] @ T.T - np.diag(psi)).max()), "psi_max": float(psi[0])}
+
+
+def pcie():
+    """host-pointer plda_score_matrix (pageable numpy buffers): the PCIe-inclusive rate, never the bench value."""
+    D, M = 200, 20_000
+    rng = np.random.default_rng(9)
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    eng = MPlda(0)
+    eng.set_model(rng.random(D), q, np.sort(rng.random(D) * 4)[::-1].copy())
+    U = eng.transform_array(rng.random((M, D)), 1)
+    eng.score_matrix((1, U[:512]), (1, U[:512]))
+    t0 = time.perf_counter(); S = eng.score_matrix((1, U), (1, U)); dt = time.perf_counter() - t0
+    return {"trials": M * M, "seconds": dt, "trials_per_s_incl_pcie": M * M / dt, "out_GB": M * M * 4 / 1e9}
+
+
 def frontend():
     """d-vector pooling: 200k utterances x 100 frames x 64 dims, float32 -> HBM GB/s."""
     import ctypes as C
@@ -162,7 +198,7 @@ def frontend():
     return res
 
 
-for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend)):
+for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie)):
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     t0 = time.perf_counter()

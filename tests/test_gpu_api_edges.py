@@ -1,0 +1,119 @@
+"""GPU: edge cases of the C ABI and the shim -- empty / ragged inputs, strided outputs, the
+host path's row slabs, numutts subsets, persistence, error codes (never an abort)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_data, score_tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fitted(oracle):
+    from plda_amd import MPlda
+    x, y = make_data(41, 900, 20, 30, skew=True, scale_between=0.5)
+    eng = MPlda(0)
+    eng.fit(x, y, 4)
+    return eng, oracle.fit(x, y, 4), x, y
+
+
+def test_error_codes_do_not_abort(fitted):
+    from plda_amd import MPlda, _native as N
+    eng, ref, x, y = fitted
+    lib = eng._lib
+    fresh = MPlda(0)
+    assert lib.plda_get_dims(fresh._h, None, None) == N.PLDA_E_NOT_FITTED
+    assert "not fitted" in N.last_error(fresh._h)
+    out = np.zeros((2, 2), np.float32)
+    u = np.zeros((2, 20))
+    # ld_out < Nt, NULL pointers, n_uniform <= 0 with no counts
+    assert lib.plda_score_matrix(eng._h, u.ctypes.data, None, 1, 2, u.ctypes.data, 2, None, None, out.ctypes.data, 1) == N.PLDA_E_INVAL
+    assert lib.plda_score_matrix(eng._h, None, None, 1, 2, u.ctypes.data, 2, None, None, out.ctypes.data, 2) == N.PLDA_E_INVAL
+    assert lib.plda_score_matrix(eng._h, u.ctypes.data, None, 0, 2, u.ctypes.data, 2, None, None, out.ctypes.data, 2) == N.PLDA_E_INVAL
+    # feature-dim mismatch in transform
+    cap = C.c_int64(4)
+    bad = np.zeros((4, 7))
+    lab = np.arange(4, dtype=np.uint64)
+    assert lib.plda_transform_groups(eng._h, bad.ctypes.data, 4, 7, lab.ctypes.data, lab.ctypes.data,
+                                     np.zeros(4, np.int64).ctypes.data, np.zeros((4, 20)).ctypes.data, C.byref(cap)) == N.PLDA_E_INVAL
+    # capacity too small is reported with the needed size
+    cap = C.c_int64(1)
+    xx = np.ascontiguousarray(x[:4])
+    rc = lib.plda_transform_groups(eng._h, xx.ctypes.data, 4, 20, lab.ctypes.data, np.zeros(1, np.uint64).ctypes.data,
+                                   np.zeros(1, np.int64).ctypes.data, np.zeros((1, 20)).ctypes.data, C.byref(cap))
+    assert rc == N.PLDA_E_CAPACITY and cap.value == 4
+    # non-dense labels at the ABI level (the shim compacts; the ABI refuses)
+    xs = np.ascontiguousarray(x[:6]); gap = np.array([0, 0, 2, 2, 3, 3], np.uint64)
+    assert lib.plda_fit(fresh._h, xs.ctypes.data, 6, 20, gap.ctypes.data, 2) == N.PLDA_E_LABELS
+    assert lib.plda_fit(fresh._h, xs.ctypes.data, 6, 20, np.zeros(6, np.uint64).ctypes.data, 2) == N.PLDA_E_ONE_SPEAKER
+    assert lib.plda_truncate(eng._h, 0) == N.PLDA_E_INVAL and lib.plda_smooth(eng._h, 1.5) == N.PLDA_E_INVAL
+    # trial indexes outside the sets
+    with pytest.raises(RuntimeError):
+        eng.score_trials((np.ones(2, np.int32), u), (1, u), [0, 5], [0, 0])
+    assert eng.dims() == (20, 20)   # handle still usable
+
+
+def test_empty_and_single_inputs(fitted):
+    eng, ref, x, y = fitted
+    assert eng.transform(np.zeros((0, 20)), np.zeros(0, np.uint64)) == {}
+    assert eng.score_matrix((1, np.zeros((0, 20))), (1, np.zeros((3, 20)))).shape == (0, 3)
+    assert eng.score_matrix((1, np.zeros((3, 20))), (1, np.zeros((0, 20)))).shape == (3, 0)
+    assert eng.score_trials((np.ones(1, np.int32), np.zeros((1, 20))), (1, np.zeros((1, 20))), [], []).shape == (0,)
+    assert eng.norm(x[:10], {}) is None
+    one = eng.transform(x[:1], np.array([123456789012], np.uint64))     # 64-bit label (quirk Q11)
+    assert list(one) == [123456789012] and one[123456789012][0] == 1
+
+
+def test_strided_output_and_host_slabs(fitted, oracle):
+    eng, ref, x, y = fitted
+    rng = np.random.default_rng(2)
+    U = np.stack([oracle.transform_ivector(ref, r, 2) for r in rng.random((300, 20))])
+    V = np.stack([oracle.transform_ivector(ref, r, 1) for r in rng.random((77, 20))])
+    S_ref = oracle.score_block(ref["psi"], U, 2, V)
+    big = np.full((300, 100), -7.0, np.float32)                # ld_out = 100 > Nt = 77
+    rc = eng._lib.plda_score_matrix(eng._h, U.ctypes.data, None, 2, 300, V.ctypes.data, 77, None, None,
+                                    big.ctypes.data, 100)
+    assert rc == 0
+    assert (np.abs(big[:, :77] - S_ref) <= score_tol(S_ref)).all() and (big[:, 77:] == -7.0).all()
+
+
+def test_norm_numutts_subset_and_persistence(fitted, oracle, tmp_path):
+    from plda_amd import MPlda
+    eng0, ref, x, y = fitted
+    eng = MPlda(0); eng.set_model(ref["mean"], ref["transform"], ref["psi"])
+    enrol = eng.transform(x[:90], y[:90])
+    ids = list(enrol)
+    models = np.stack([enrol[k][1] for k in ids])
+    bkg = x[300:420]
+    eng.norm(bkg, enrol, 50)                                   # 50 of 120 rows, num_examples stays 120 (:224)
+    sel = np.sort(np.random.default_rng(0).permutation(120)[:50])
+    t = np.stack([oracle.transform_ivector(ref, r, 120) for r in bkg[sel]])
+    S = np.array([[oracle.llr(ref["psi"], tr, 1, m) for m in models] for tr in t])
+    zm, zs = eng.znorm_stats()
+    np.testing.assert_allclose([zm[k] for k in ids], S.mean(0), rtol=1e-4, atol=1e-4 * np.abs(S.mean(0)).mean())
+    np.testing.assert_allclose([zs[k] for k in ids], S.std(0), rtol=2e-4)
+    path = os.path.join(tmp_path, "model.npz")
+    eng.save(path)
+    eng2 = MPlda(0); eng2.load(path)
+    assert eng2.znorm_stats() == eng.znorm_stats()
+    a = eng.score(ids[1], enrol[ids[1]], (1, models[3]))
+    b = eng2.score(ids[1], enrol[ids[1]], (1, models[3]))
+    assert a == b
+    for k in ("mean", "transform", "psi", "offset"):
+        np.testing.assert_array_equal(eng.get_model()[k], eng2.get_model()[k])
+
+
+def test_float32_and_fortran_inputs_are_coerced(fitted, oracle):
+    """superset of the reference, which silently mis-reads such arrays (quirk Q12)."""
+    eng, ref, x, y = fitted
+    a = eng.transform(np.asfortranarray(x[:40]), y[:40].astype(np.uint8))
+    b = eng.transform(x[:40], y[:40])
+    assert list(a) == list(b)
+    for k in a:
+        np.testing.assert_array_equal(a[k][1], b[k][1])
+    c = eng.transform(x[:40].astype(np.float32), y[:40])
+    for k in c:
+        np.testing.assert_allclose(c[k][1], b[k][1], rtol=1e-5, atol=1e-6)
