@@ -146,28 +146,55 @@ __global__ __launch_bounds__(256) void centroid_kernel(const double *__restrict_
   for (int r = beg + threadIdx.x; r < end; r += blockDim.x) roww[perm[r]] = inv;
 }
 
-// sum_d = sum_k w_k m_kd (w_k = 1/n_k); class_weight = sum_k w_k.  One block, deterministic.
-__global__ __launch_bounds__(256) void class_sum_kernel(const double *__restrict__ means,
-                                                        const int *__restrict__ offsets, int64_t K, int D,
-                                                        double *__restrict__ sum, double *__restrict__ mu,
-                                                        double *__restrict__ scalars /*[0]=class_weight*/) {
-  __shared__ double red[256];
-  double cw = 0.0;
-  for (int64_t k = threadIdx.x; k < K; k += blockDim.x) cw += 1.0 / (double)(offsets[k + 1] - offsets[k]);
-  red[threadIdx.x] = cw;
+// sum_d = sum_k w_k m_kd (w_k = 1/n_k) and class_weight = sum_k w_k, deterministic two-stage:
+// (1) class_sum_partial_kernel: grid (D / 64, CS_SPLIT); a block sums its K-slice for 64
+//     columns (4 k-sub-slices in parallel, combined in LDS in fixed order) -> partial[s][d];
+//     block (0, s) also sums 1/n_k over its slice -> wpart[s];
+// (2) class_sum_final_kernel: fixed-order sum over the slices, mu = sum / class_weight.
+constexpr int CS_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void class_sum_partial_kernel(const double *__restrict__ means,
+                                                                const int *__restrict__ offsets, int64_t K, int D,
+                                                                double *__restrict__ partial /*[CS_SPLIT][D]*/,
+                                                                double *__restrict__ wpart /*[CS_SPLIT]*/) {
+  __shared__ double red[4][64];
+  __shared__ double wred[256];
+  const int t = threadIdx.x, c = t & 63, sub = t >> 6;
+  const int d = blockIdx.x * 64 + c;
+  const int64_t per = (K + CS_SPLIT - 1) / CS_SPLIT;
+  const int64_t k0 = (int64_t)blockIdx.y * per, k1 = min(K, k0 + per);
+  double acc = 0.0;
+  if (d < D)
+    for (int64_t k = k0 + sub; k < k1; k += 4) acc += means[k * D + d] / (double)(offsets[k + 1] - offsets[k]);
+  red[sub][c] = acc;
+  if (blockIdx.x == 0) {
+    double w = 0.0;
+    for (int64_t k = k0 + t; k < k1; k += 256) w += 1.0 / (double)(offsets[k + 1] - offsets[k]);
+    wred[t] = w;
+  }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (sub == 0 && d < D) partial[(size_t)blockIdx.y * D + d] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (blockIdx.x == 0) {
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) wred[t] += wred[t + o];
+      __syncthreads();
+    }
+    if (t == 0) wpart[blockIdx.y] = wred[0];
   }
-  const double class_weight = red[0];
-  if (threadIdx.x == 0) scalars[0] = class_weight;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    double acc = 0.0;
-    for (int64_t k = 0; k < K; ++k) acc += means[k * D + d] / (double)(offsets[k + 1] - offsets[k]);
-    sum[d] = acc;
-    mu[d] = acc / class_weight;
-  }
+}
+
+__global__ void class_sum_final_kernel(const double *__restrict__ partial, const double *__restrict__ wpart, int D,
+                                       double *__restrict__ sum, double *__restrict__ mu,
+                                       double *__restrict__ scalars /*[0]=class_weight*/) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  double cw = 0.0;
+  for (int s2 = 0; s2 < CS_SPLIT; ++s2) cw += wpart[s2];
+  if (d == 0) scalars[0] = cw;
+  if (d >= D) return;
+  double acc = 0.0;
+  for (int s2 = 0; s2 < CS_SPLIT; ++s2) acc += partial[(size_t)s2 * D + d];
+  sum[d] = acc;
+  mu[d] = acc / cw;
 }
 
 // ------------------------------------------------------------------------------------
@@ -357,7 +384,13 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   }
   centroid_kernel<<<(unsigned)K, 256, 0, h->stream>>>(dX, D, perm, offsets, means, roww);
   PLDA_LAUNCH_CHECK(h);
-  class_sum_kernel<<<1, 256, 0, h->stream>>>(means, offsets, K, D, sum, mu, scalars);
+  PLDA_HIP(h, h->w[7].reserve((size_t)CS_SPLIT * (D + 1) * 8));
+  {
+    double *partial = h->w[7].as<double>(), *wpart = partial + (size_t)CS_SPLIT * D;
+    class_sum_partial_kernel<<<dim3((unsigned)ceil_div(D, 64), CS_SPLIT), 256, 0, h->stream>>>(means, offsets, K, D,
+                                                                                              partial, wpart);
+    class_sum_final_kernel<<<(unsigned)ceil_div(D, 256), 256, 0, h->stream>>>(partial, wpart, D, sum, mu, scalars);
+  }
   PLDA_LAUNCH_CHECK(h);
   // offset_scatter = X^T diag(1/n_label) X - sum_k (n_k w_k) m_k m_k^T,  n_k w_k = 1
   PLDA_TRY(gemm_f64(h, D, D, N, 1.0, dX, 1, D, dX, D, 1, roww, 0.0, S, D));
