@@ -420,6 +420,32 @@ __device__ __forceinline__ void bt_stage(const f32x4 *__restrict__ Apk, const f3
   }
 }
 
+// Same staging through a buffer descriptor: `buffer_load_dwordx4 ... offen lds` takes ONE
+// loop-invariant VGPR (lane * 16) and a scalar byte offset, so a DMA instruction needs no
+// per-lane 64-bit address arithmetic or operands.  Requires each packed operand < 4 GiB.
+__device__ __forceinline__ void bt_stage_buf(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb_, int64_t Mpad,
+                                             int64_t Npad, int kq0, int KQ, int64_t r0, int64_t c0,
+                                             f32x4 *buf, int wave, int lane16) {
+#pragma unroll
+  for (int j = 0; j < BT_NKQ; ++j) {
+    const int c = wave + 8 * j;
+    const bool isB = c >= 4 * BT_NKQ;
+    const int cc = isB ? c - 4 * BT_NKQ : c;
+    const int kql = cc >> 2, quarter = cc & 3;
+    const int kq = kq0 + kql;
+    if (kq < KQ) {
+      f32x4 *l = buf + (isB ? BT_NKQ * 256 : 0) + kql * 256 + quarter * 64;
+      if (isB) {
+        const unsigned so = (unsigned)(((int64_t)kq * Npad + c0 + quarter * 64) * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (LDS_AS void *)l, 16, lane16, (int)so, 0, 0);
+      } else {
+        const unsigned so = (unsigned)(((int64_t)kq * Mpad + r0 + quarter * 64) * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_AS void *)l, 16, lane16, (int)so, 0, 0);
+      }
+    }
+  }
+}
+
 #define BT_MFMA8(T, S)                                                                           \
   _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) {                                             \
     acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[tm][T], S##b[0][T], acc[tm][0], 0, 0, 0); \
@@ -429,7 +455,7 @@ __device__ __forceinline__ void bt_stage(const f32x4 *__restrict__ Apk, const f3
   _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) S##a[tm] = Al[(OFF) + tm * 32];              \
   S##b[0] = Bl[(OFF)]; S##b[1] = Bl[(OFF) + 32];
 
-template <bool ZN>
+template <bool ZN, bool BUF>
 __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
     const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, int64_t Mpad, int64_t Npad,
     int KQ, const float *__restrict__ rbias, const float *__restrict__ rscale,
@@ -445,6 +471,12 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
   const int nst = (KQ + BT_NKQ - 1) / BT_NKQ;
   const int niter = (numPatches + 7) >> 3;
+  const int lane16 = lane * 16;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(Apk), 0, (int)(KQ * Mpad * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(Bpk), 0, (int)(KQ * Npad * 16), 0x00020000);
+#define BT_STAGE(KQ0, R0, C0, BUFP)                                                        \
+  if (BUF) bt_stage_buf(rsA, rsB, Mpad, Npad, (KQ0), KQ, (R0), (C0), (BUFP), wave, lane16); \
+  else bt_stage(Apk, Bpk, Mpad, Npad, (KQ0), KQ, (R0), (C0), (BUFP), wave, lane);
 
   auto tile_of = [&](int it, int64_t &r0, int64_t &c0) -> bool {
     const int patch = it * 8 + xcd;
@@ -462,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
   bool have = false;
   for (; it < niter; ++it)
     if ((have = tile_of(it, r0, c0))) break;
-  if (have) bt_stage(Apk, Bpk, Mpad, Npad, 0, KQ, r0, c0, smem + base * STAGE, wave, lane);
+  if (have) { BT_STAGE(0, r0, c0, smem + base * STAGE) }
 
   while (have) {
     const int64_t wrow0 = r0 + wm * 128, wcol0 = c0 + wn * 64;
@@ -481,12 +513,12 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
       __syncthreads();   // stage st landed (vmcnt(0) + barrier); everyone is done with stage st-1
       f32x4 *other = smem + ((base + st + 1) & 1) * STAGE;
       if (st + 1 < nst) {
-        bt_stage(Apk, Bpk, Mpad, Npad, (st + 1) * BT_NKQ, KQ, r0, c0, other, wave, lane);
+        BT_STAGE((st + 1) * BT_NKQ, r0, c0, other)
       } else {
         // last stage: prefetch the NEXT tile's first stage into the freed buffer
         for (++it; it < niter; ++it)
           if ((next_have = tile_of(it, nr0, nc0))) break;
-        if (next_have) bt_stage(Apk, Bpk, Mpad, Npad, 0, KQ, nr0, nc0, other, wave, lane);
+        if (next_have) { BT_STAGE(0, nr0, nc0, other) }
       }
       const f32x4 *cur = smem + ((base + st) & 1) * STAGE;
       const int np = min(BT_NKQ, KQ - st * BT_NKQ) >> 1;
@@ -556,6 +588,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
     r0 = nr0; c0 = nc0;
   }
 }
+#undef BT_STAGE
 #undef BT_MFMA8
 #undef BT_LOAD
 
@@ -729,21 +762,30 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   // big-tile persistent kernel: when there are enough 256x256 tiles to keep 256 CUs busy
   const int btM = (int)ceil_div(M, 256), btN = (int)(op.Npad / 256);
   const bool use_bt = EPI == 0 && h->gemm_variant != 20 &&
-                      (h->gemm_variant == 21 || (h->gemm_variant == 0 && (int64_t)btM * btN >= 1024));
+                      (h->gemm_variant == 21 || h->gemm_variant == 28 || (h->gemm_variant == 0 && (int64_t)btM * btN >= 1024));
   if (use_bt) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     const size_t lds = (size_t)2 * BT_NKQ * 512 * 16;
     if (!h->bt_attr_set) {
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false>),
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<true>),
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<true, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       h->bt_attr_set = true;
     }
-    trials_gemm_bigtile_kernel<ZN><<<256, 512, lds, h->stream>>>(
-        h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),
-        use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout, ld,
-        M, Nt, btM, btN, pN, pM * pN);
+    // buffer-descriptor DMA needs 32-bit byte offsets into each packed operand
+    const bool fits32 = (int64_t)op.KQ * op.Mpad * 16 < (1ll << 31) && (int64_t)op.KQ * op.Npad * 16 < (1ll << 31);
+#define BTL(BUF_)                                                                                        \
+  trials_gemm_bigtile_kernel<ZN, BUF_><<<256, 512, lds, h->stream>>>(                                    \
+      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),       \
+      use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout, \
+      ld, M, Nt, btM, btN, pN, pM * pN)
+    if (fits32 && h->gemm_variant != 21) BTL(true); else BTL(false);
+#undef BTL
     PLDA_LAUNCH_CHECK(h);
     if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
     return PLDA_OK;
