@@ -163,6 +163,18 @@ int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, in
                           const int64_t *doffsets, int64_t U, int32_t method, int32_t l2norm,
                           double *dout);
 
+/* ---- equal error rate (the step after the path): replaces scoring/eer.py:68-73
+ * (bob.measure.eer_threshold + farfrr; bob is absent and un-pinned, its published
+ * definition is restated: FAR = #{impostor >= t}/Nn, FRR = #{target < t}/Np, t = the
+ * midpoint after the score where |FAR - FRR| is minimal, later candidate on ties).
+ * out[6] = threshold, FAR, FRR, EER = (FAR + FRR)/2, #targets, #impostors.
+ * _matrix: trial (i, j) of the fp32 score matrix is a target iff enrol_spk[i] == test_spk[j];
+ * _lists: separate target / impostor score arrays (the two files eer.py reads). ---- */
+int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                        const int64_t *denrol_spk, const int64_t *dtest_spk, double *out);
+int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn,
+                   double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,3 +167,21 @@ def dvector_pool(frames, offsets, method="mean", l2norm=True):
             u = u / np.linalg.norm(u, axis=1)[:, np.newaxis]
         out.append({"mean": np.mean, "max": np.max, "var": np.var}[method](u, axis=0))
     return np.array(out)
+
+
+def eer(negatives, positives):
+    """Equal error rate as scoring/eer.py:68-73 computes it through bob.measure (absent,
+    un-pinned: published definition restated; PARITY UNPINNED for this row):
+      farfrr(neg, pos, t): FAR = #{neg >= t}/Nn, FRR = #{pos < t}/Np;
+      eer_threshold: candidates are the minimum score, then the midpoint after each distinct
+      score of the union (last one: score + 1e-8); minimal |FAR - FRR| wins, later on ties.
+    Returns (threshold, far, frr, eer) computed on float32 scores in float64."""
+    neg = np.sort(np.asarray(negatives, np.float32).astype(np.float64))
+    pos = np.sort(np.asarray(positives, np.float32).astype(np.float64))
+    s = np.unique(np.concatenate([neg, pos]))
+    mids = np.concatenate([[s[0]], s[:-1] + (s[1:] - s[:-1]) / 2.0, [s[-1] + 1e-8]])
+    far = (len(neg) - np.searchsorted(neg, mids, side="left")) / len(neg)   # #{neg >= t} / Nn
+    frr = np.searchsorted(pos, mids, side="left") / len(pos)           # pos < t
+    pred = np.abs(far - frr)
+    best = len(pred) - 1 - int(np.argmin(pred[::-1]))                  # later candidate on ties
+    return float(mids[best]), float(far[best]), float(frr[best]), float(0.5 * (far[best] + frr[best]))

@@ -53,6 +53,9 @@ int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_e
 int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
                        int64_t Ku, double *dmeans, int32_t *dcounts32);
 int compute_offset_device(plda_handle *h);
+int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
+                      const int64_t *dtspk, double *out);
+int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out);
 
 // simple RAII device temp for host-pointer entry points
 struct Tmp {
@@ -490,6 +493,25 @@ int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t
   PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, (size_t)U * D * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   return PLDA_OK;
+}
+
+// ---------------------------------------------------------------- EER
+int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                        const int64_t *denrol_spk, const int64_t *dtest_spk, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
+}
+
+int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!pos || !neg || !out || np <= 0 || nn <= 0)
+    return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor score");
+  PLDA_TRY(set_device(h));
+  Tmp dP, dN;
+  PLDA_TRY(upload(h, dP, pos, (size_t)np * 4));
+  PLDA_TRY(upload(h, dN, neg, (size_t)nn * 4));
+  return eer_lists_device(h, dP.as<float>(), np, dN.as<float>(), nn, out);
 }
 
 }  // extern "C"

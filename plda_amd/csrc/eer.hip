@@ -1,0 +1,219 @@
+// plda_amd/csrc/eer.hip -- equal error rate of a trials matrix on the GPU (SURVEY.md section 8f
+// rank 4).  Replaces /root/reference/scoring/eer.py:68-73, which calls
+// bob.measure.eer_threshold(negatives, positives) and bob.measure.farfrr(...): `bob` is an
+// absent, un-pinned third-party dependency, so (as for Kaldi) its published definition is
+// restated -- oracle/plda_oracle_np.py:eer -- and parity for this row is UNPINNED:
+//   farfrr(neg, pos, t):  FAR = #{neg >= t} / Nn,  FRR = #{pos < t} / Np
+//   eer_threshold:        candidate thresholds are the minimum score and the midpoints
+//                         between consecutive distinct scores of the union; the one with
+//                         minimal |FAR - FRR| wins, the later one on ties.
+// Sort-free: g(k) = FRR - FAR "after score k" is non-decreasing in k, so the minimum of |g|
+// is at the smallest key k1 with g(k1) >= 0 or at its predecessor.  k1 is found EXACTLY by
+// three HBM-bound passes over the fp32 scores that histogram an order-preserving uint32 key
+// 11 + 11 + 10 bits at a time (per-block LDS histograms, float4 loads), with the crossing
+// located in integer arithmetic on the host between passes.  Algorithmic bytes: 3 x 4 B per trial read, nothing written.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace plda {
+
+__device__ __forceinline__ unsigned score_key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone: a < b  <=>  key(a) < key(b)
+}
+static inline float key_score(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+constexpr int EER_BINS = 2048;
+
+// one pass: class c (0 = impostor, 1 = target) histogram of bits [shift, shift + nbits) of the
+// keys whose higher bits equal `prefix` (pass 0: every key).  below/above track the largest
+// key below and the smallest key above the prefix range (needed for neighbours in pass 2).
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+
+// MATRIX: blocks stride over rows, threads over groups of 4 columns (one aligned float4 load
+// per thread when the row base allows it); otherwise a flat list with a fixed class.
+template <bool MATRIX>
+__global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__ scores, int64_t ld, int64_t M,
+                                                       int64_t Nt, const int64_t *__restrict__ espk,
+                                                       const int64_t *__restrict__ tspk, int fixed_class,
+                                                       int shift, int nbits, unsigned prefix, int has_prefix,
+                                                       unsigned long long *__restrict__ hist /*[2][EER_BINS]*/,
+                                                       unsigned *__restrict__ below, unsigned *__restrict__ above) {
+  __shared__ unsigned lh[2][EER_BINS];
+  for (int i = threadIdx.x; i < 2 * EER_BINS; i += 256) (&lh[0][0])[i] = 0;
+  __syncthreads();
+  const unsigned mask = (1u << nbits) - 1u;
+  const int hi_shift = shift + nbits;
+  const int lane = threadIdx.x & 63;
+  unsigned lo_max = 0u, hi_min = 0xffffffffu;
+  const int64_t cols4 = (Nt + 3) / 4;
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
+
+  auto account = [&](bool ok, float sc, int cls) {
+    unsigned bin = 0xffffffffu;   // inactive
+    if (ok) {
+      const unsigned k = score_key(sc);
+      if (has_prefix && (k >> hi_shift) != prefix) {
+        if ((k >> hi_shift) < prefix) lo_max = k > lo_max ? k : lo_max; else hi_min = k < hi_min ? k : hi_min;
+      } else {
+        bin = ((k >> shift) & mask) | ((unsigned)cls << 11);
+      }
+    }
+    // plain non-returning LDS atomics: measured 2.8 TB/s over 120 GB, against 1.8 TB/s when lanes
+    // with equal bins were first aggregated with 12 ballots per element
+    if (bin != 0xffffffffu) atomicAdd(&lh[bin >> 11][bin & 2047u], 1u);
+  };
+
+  if (MATRIX) {
+    for (int64_t row = blockIdx.x; row < M; row += gridDim.x) {
+      const int64_t spk = espk[row];
+      const float *srow = scores + row * ld;
+      for (int64_t c4 = threadIdx.x; c4 - threadIdx.x < cols4; c4 += 256) {
+        const int64_t col = c4 * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        bool ok[4];
+        int cls[4];
+        if (c4 < cols4 && vec && col + 3 < Nt) {
+          const f32x4e x = __builtin_nontemporal_load(reinterpret_cast<const f32x4e *>(srow + col));
+          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c4 < cols4 && col + e < Nt) v[e] = srow[col + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ok[e] = c4 < cols4 && col + e < Nt;
+          cls[e] = ok[e] ? (tspk[col + e] == spk ? 1 : 0) : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) account(ok[e], v[e], cls[e]);
+      }
+    }
+  } else {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx - threadIdx.x < Nt; idx += (int64_t)gridDim.x * 256)
+      account(idx < Nt, idx < Nt ? scores[idx] : 0.f, fixed_class);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * EER_BINS; i += 256) {
+    const unsigned v = (&lh[0][0])[i];
+    if (v) atomicAdd(hist + i, (unsigned long long)v);
+  }
+  if (has_prefix) {
+    if (lo_max) atomicMax(below, lo_max);
+    if (hi_min != 0xffffffffu) atomicMin(above, hi_min);
+  }
+}
+
+struct EerSource {
+  const float *scores; int64_t ld, M, Nt; const int64_t *espk, *tspk;   // matrix + labels, or
+  const float *pos; int64_t np; const float *neg; int64_t nn;            // two flat lists
+};
+
+static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, unsigned prefix, int has_prefix,
+                    unsigned long long *dhist, unsigned *dbelow, unsigned *dabove, std::vector<unsigned long long> &hh) {
+  PLDA_HIP(h, hipMemsetAsync(dhist, 0, 2 * EER_BINS * 8, h->stream));
+  if (src.scores) {
+    const unsigned grid = (unsigned)std::min<int64_t>(src.M, 256 * 16);
+    eer_hist_kernel<true><<<grid, 256, 0, h->stream>>>(src.scores, src.ld, src.M, src.Nt, src.espk, src.tspk, 0, shift,
+                                                       nbits, prefix, has_prefix, dhist, dbelow, dabove);
+  } else {
+    for (int c = 0; c < 2; ++c) {
+      const float *p = c ? src.pos : src.neg;
+      const int64_t n = c ? src.np : src.nn;
+      const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 256), 256 * 16);
+      eer_hist_kernel<false><<<grid, 256, 0, h->stream>>>(p, n, 1, n, nullptr, nullptr, c, shift, nbits, prefix,
+                                                          has_prefix, dhist, dbelow, dabove);
+    }
+  }
+  PLDA_LAUNCH_CHECK(h);
+  hh.resize(2 * EER_BINS);
+  PLDA_HIP(h, hipMemcpyAsync(hh.data(), dhist, 2 * EER_BINS * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+// out: [0] threshold, [1] FAR, [2] FRR, [3] EER = (FAR + FRR) / 2, [4] #targets, [5] #impostors
+int eer_device(plda_handle *h, const EerSource &src, double *out) {
+  typedef unsigned __int128 u128;
+  PLDA_HIP(h, h->w[10].reserve(2 * EER_BINS * 8 + 64));
+  unsigned long long *dhist = h->w[10].as<unsigned long long>();
+  unsigned *dbelow = reinterpret_cast<unsigned *>(dhist + 2 * EER_BINS), *dabove = dbelow + 1;
+  std::vector<unsigned long long> H;
+  // g(k) >= 0  <=>  P(k) * Nn >= (Nn - N(k)) * Np  with P, N = #targets / #impostors with key <= k
+  unsigned long long Np = 0, Nn = 0, Pb = 0, Nb = 0;   // totals; counts strictly below the current range
+  unsigned prefix = 0;
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  unsigned long long cP = 0, cN = 0;   // counts at k1
+  std::vector<unsigned long long> last;
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass == 2) {
+      const unsigned init[2] = {0u, 0xffffffffu};
+      PLDA_HIP(h, hipMemcpyAsync(dbelow, init, 8, hipMemcpyHostToDevice, h->stream));
+    }
+    PLDA_TRY(eer_pass(h, src, shifts[pass], bits[pass], prefix, pass > 0, dhist, dbelow, dabove, H));
+    const int nb = 1 << bits[pass];
+    if (pass == 0) {
+      for (int b = 0; b < nb; ++b) { Nn += H[b]; Np += H[EER_BINS + b]; }
+      if (Np == 0 || Nn == 0) return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor trial");
+    }
+    int sel = -1;
+    unsigned long long P = Pb, N = Nb;
+    for (int b = 0; b < nb; ++b) {
+      const unsigned long long p2 = P + H[EER_BINS + b], n2 = N + H[b];
+      if ((H[b] | H[EER_BINS + b]) && (u128)p2 * Nn >= (u128)(Nn - n2) * Np) { sel = b; cP = H[EER_BINS + b]; cN = H[b]; break; }
+      P = p2; N = n2;
+    }
+    if (sel < 0) return fail(h, PLDA_E_NUMERIC, "eer: crossing not found (inconsistent counts)");
+    Pb = P; Nb = N;
+    prefix = (prefix << bits[pass]) | (unsigned)sel;
+    if (pass == 2) last = H;
+  }
+  const unsigned k1 = prefix;                       // smallest key with g >= 0; Pb/Nb = counts below k1
+  unsigned hb[2];
+  PLDA_HIP(h, hipMemcpyAsync(hb, dbelow, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  // neighbours of k1 among the data keys
+  const int b2 = (int)(k1 & 1023u);
+  long long k0 = -1, k2 = -1;
+  for (int b = b2 - 1; b >= 0; --b) if (last[b] | last[EER_BINS + b]) { k0 = (long long)((k1 & ~1023u) | (unsigned)b); break; }
+  if (k0 < 0 && (Pb + Nb) > 0) k0 = hb[0];
+  for (int b = b2 + 1; b < 1024; ++b) if (last[b] | last[EER_BINS + b]) { k2 = (long long)((k1 & ~1023u) | (unsigned)b); break; }
+  if (k2 < 0 && (Pb + cP + Nb + cN) < (Np + Nn)) k2 = hb[1];
+  // g(k1) = (Pb + cP)/Np - (Nn - Nb - cN)/Nn >= 0 ; g(prev) = Pb/Np - (Nn - Nb)/Nn < 0 (prev = k0, or the start)
+  const long double g1 = (long double)(Pb + cP) / Np - (long double)(Nn - Nb - cN) / Nn;
+  const long double g0 = (long double)Pb / Np - (long double)(Nn - Nb) / Nn;
+  double thr, far, frr;
+  if (fabsl(g1) <= fabsl(g0)) {                     // later candidate wins ties
+    const double s = key_score(k1);
+    thr = k2 >= 0 ? s + ((double)key_score((unsigned)k2) - s) / 2.0 : s + 1e-8;
+    far = (double)(Nn - Nb - cN) / (double)Nn; frr = (double)(Pb + cP) / (double)Np;
+  } else {
+    const double s1 = key_score(k1);
+    thr = k0 >= 0 ? (double)key_score((unsigned)k0) + (s1 - (double)key_score((unsigned)k0)) / 2.0 : s1;
+    far = (double)(Nn - Nb) / (double)Nn; frr = (double)Pb / (double)Np;
+  }
+  out[0] = thr; out[1] = far; out[2] = frr; out[3] = 0.5 * (far + frr); out[4] = (double)Np; out[5] = (double)Nn;
+  return PLDA_OK;
+}
+
+int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
+                      const int64_t *dtspk, double *out) {
+  if (!dscores || !despk || !dtspk || !out || M <= 0 || Nt <= 0 || ld < Nt) return fail(h, PLDA_E_INVAL, "eer: bad argument");
+  EerSource s{dscores, ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
+  return eer_device(h, s, out);
+}
+
+int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out) {
+  if (!dpos || !dneg || !out || np <= 0 || nn <= 0) return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor score");
+  EerSource s{nullptr, 0, 0, 0, nullptr, nullptr, dpos, np, dneg, nn};
+  return eer_device(h, s, out);
+}
+
+}  // namespace plda

@@ -1,0 +1,33 @@
+"""plda_amd/eer.py -- equal error rate on the GPU: counterpart of
+/root/reference/scoring/eer.py:68-73 (bob.measure.eer_threshold + farfrr)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def eer_from_lists(engine, truescores, impostscores):
+    """(threshold, FAR, FRR, EER) from target / impostor score arrays (eer.py's two files)."""
+    pos = np.ascontiguousarray(truescores, np.float32)
+    neg = np.ascontiguousarray(impostscores, np.float32)
+    out = np.zeros(6)
+    N.check(engine._h, engine._lib.plda_eer_lists(engine._h, C.c_void_p(pos.ctypes.data), pos.shape[0],
+                                                  C.c_void_p(neg.ctypes.data), neg.shape[0], C.c_void_p(out.ctypes.data)))
+    return tuple(out[:4])
+
+
+def eer_from_matrix_dev(engine, dscores, ld, m, nt, denrol_spk, dtest_spk):
+    """Same on an HBM-resident fp32 trials matrix; trial (i, j) is a target iff
+    enrol_spk[i] == test_spk[j] (int64 device arrays).  Returns the 6-vector
+    (threshold, FAR, FRR, EER, #targets, #impostors)."""
+    out = np.zeros(6)
+    N.check(engine._h, engine._lib.plda_eer_matrix_dev(engine._h, C.c_void_p(int(dscores)), int(ld), int(m), int(nt),
+                                                       C.c_void_p(int(denrol_spk)), C.c_void_p(int(dtest_spk)),
+                                                       C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def format_line(far, frr, threshold):
+    """The line eer.py:72-73 writes."""
+    return "EER = %.2f%%, FAR = %.2f, FRR=%.2f, Threshold = %e\n" % ((far + frr) / 2 * 100, far, frr, threshold)

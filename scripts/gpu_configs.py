@@ -174,6 +174,35 @@ def pcie():
     return {"trials": M * M, "seconds": dt, "trials_per_s_incl_pcie": M * M / dt, "out_GB": M * M * 4 / 1e9}
 
 
+def eer_full():
+    """EER of a 100k x 100k trials matrix (5000 speakers, 20 utts each): 3 histogram passes over 40 GB."""
+    from plda_amd import eer
+    D, N, K = 200, 100_000, 5000
+    rng = np.random.default_rng(8)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    y = (np.arange(N) % K)
+    X = rng.random((N, D)) + 0.25 * rng.standard_normal((K, D))[y]
+    dX = torch.from_numpy(X).to(dev); dy = torch.from_numpy(y.astype(np.int64)).to(dev)
+    eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, 5)
+    U = torch.empty((N, D), dtype=torch.float64, device=dev)
+    eng.transform_rows_dev(dX.data_ptr(), N, D, None, 1, U.data_ptr())
+    S = torch.empty((N, N), dtype=torch.float32, device=dev)
+    eng.score_matrix_dev(U.data_ptr(), None, 1, N, U.data_ptr(), N, S.data_ptr(), N)
+    torch.cuda.synchronize()
+    out = None
+    def run():
+        nonlocal out
+        out = eer.eer_from_matrix_dev(eng, S.data_ptr(), N, N, N, dy.data_ptr(), dy.data_ptr())
+    dt = timed(run, reps=2)
+    # cross-check on a 6000 x 6000 corner with the same device code vs exact numpy counts at the returned threshold
+    sub = S[:6000, :6000].cpu().numpy(); tgt = y[:6000, None] == y[None, :6000]
+    o2 = eer.eer_from_matrix_dev(eng, S.data_ptr(), N, 6000, 6000, dy.data_ptr(), dy.data_ptr())
+    far = float((sub[~tgt].astype(np.float64) >= o2[0]).mean()); frr = float((sub[tgt].astype(np.float64) < o2[0]).mean())
+    return {"eer_ms": dt * 1e3, "GBps": 3 * N * N * 4 / dt / 1e9, "eer": float(out[3]), "far": float(out[1]), "frr": float(out[2]),
+            "threshold": float(out[0]), "targets": float(out[4]), "impostors": float(out[5]),
+            "corner_farfrr_consistent": bool(far == o2[1] and frr == o2[2])}
+
+
 def frontend():
     """d-vector pooling: 200k utterances x 100 frames x 64 dims, float32 -> HBM GB/s."""
     import ctypes as C
@@ -198,7 +227,7 @@ def frontend():
     return res
 
 
-for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie)):
+for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     t0 = time.perf_counter()

@@ -148,3 +148,15 @@ def test_fit_errors_and_edges(oracle):
     # ragged: transform of a single row / single group
     l, c, v = oracle.transform_groups(m, x[:1], np.array([7], np.uint64))
     assert list(l) == [7] and list(c) == [1] and v.shape == (1, 3)
+
+
+def test_eer_restatement_properties():
+    """oracle eer(): farfrr identities and the tie rule on a hand-checkable case."""
+    thr, far, frr, e = onp.eer([0.1, 0.4, 0.35, 0.8], [0.3, 0.6, 0.9])
+    # candidates: .1 | .2 .325 .375 .5 .7 .85 .9+1e-8 -> |FAR-FRR| = 1, .75, .417, .167, .083, .417, .75(?), 1
+    assert (far, frr) == (0.25, 1.0 / 3.0) and thr == pytest.approx(0.5) and e == pytest.approx((0.25 + 1 / 3) / 2)
+    rng = np.random.default_rng(0)
+    neg, pos = rng.normal(-1, 1, 2000), rng.normal(1, 1, 300)
+    thr, far, frr, e = onp.eer(neg, pos)
+    n32, p32 = neg.astype(np.float32).astype(np.float64), pos.astype(np.float32).astype(np.float64)
+    assert far == (n32 >= thr).mean() and frr == (p32 < thr).mean() and abs(far - frr) < 0.01
