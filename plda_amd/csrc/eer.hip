@@ -51,7 +51,6 @@ __global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__
   __syncthreads();
   const unsigned mask = (1u << nbits) - 1u;
   const int hi_shift = shift + nbits;
-  const int lane = threadIdx.x & 63;
   unsigned lo_max = 0u, hi_min = 0xffffffffu;
   const int64_t cols4 = (Nt + 3) / 4;
   const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
