@@ -29,34 +29,38 @@ constexpr int LDM = 80;   // leading dim of a  [k][m] tile (m-contiguous source)
 template <bool KC>
 __device__ __forceinline__ int tile_idx(int m, int k) { return KC ? m * LDK + k : k * LDM + m; }
 
-// load a 64 (m) x 16 (k) tile of op(A) into LDS; element (m,k) = A[m*sm + k*sk] * kw[k]
+// A 64 (m) x 16 (k) tile of op(A) is fetched global -> registers (4 doubles per thread) and
+// later written registers -> LDS, so that the fetch of tile t+1 overlaps the MFMAs of tile t.
+// element (m,k) = A[m*sm + k*sk] * kw[k]
 template <bool KC>
-__device__ __forceinline__ void load_tile(double *lds, const double *__restrict__ A, int64_t sm,
-                                          int64_t sk, int64_t m0, int64_t M, int64_t k0, int64_t Kend,
-                                          const double *__restrict__ kw, int t) {
+__device__ __forceinline__ void fetch_tile(double (&r)[4], const double *__restrict__ A, int64_t sm, int64_t sk,
+                                           int64_t m0, int64_t M, int64_t k0, int64_t Kend,
+                                           const double *__restrict__ kw, int t) {
   if (KC) {
     const int k = t & 15;
     const int64_t gk = k0 + k;
     const double wk = (gk < Kend) ? (kw ? kw[gk] : 1.0) : 0.0;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-      const int m = (t >> 4) + pass * 16;
-      const int64_t gm = m0 + m;
-      double v = 0.0;
-      if (gm < M && gk < Kend) v = A[gm * sm + gk * sk] * wk;
-      lds[tile_idx<true>(m, k)] = v;
+      const int64_t gm = m0 + (t >> 4) + pass * 16;
+      r[pass] = (gm < M && gk < Kend) ? A[gm * sm + gk * sk] * wk : 0.0;
     }
   } else {
-    const int m = t & 63;
-    const int64_t gm = m0 + m;
+    const int64_t gm = m0 + (t & 63);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-      const int k = (t >> 6) + pass * 4;
-      const int64_t gk = k0 + k;
-      double v = 0.0;
-      if (gm < M && gk < Kend) v = A[gm * sm + gk * sk] * (kw ? kw[gk] : 1.0);
-      lds[tile_idx<false>(m, k)] = v;
+      const int64_t gk = k0 + (t >> 6) + pass * 4;
+      r[pass] = (gm < M && gk < Kend) ? A[gm * sm + gk * sk] * (kw ? kw[gk] : 1.0) : 0.0;
     }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(double *lds, const double (&r)[4], int t) {
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (KC) lds[tile_idx<true>((t >> 4) + pass * 16, t & 15)] = r[pass];
+    else lds[tile_idx<false>(t & 63, (t >> 6) + pass * 4)] = r[pass];
   }
 }
 
@@ -68,8 +72,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
                                                        int64_t sbn, const double *__restrict__ kw,
                                                        double beta, double *__restrict__ C, int64_t ldc,
                                                        double *__restrict__ part) {
-  __shared__ double As[GK * LDM];
-  __shared__ double Bs[GK * LDM];
+  __shared__ double As[2][GK * LDM];
+  __shared__ double Bs[2][GK * LDM];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -84,24 +88,38 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
     for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   const int fi = lane & 15, fk = lane >> 4;
+  double ra[4], rb[4];
+  fetch_tile<AKC>(ra, A, sam, sak, m0, M, kbeg, kend, kw, t);
+  fetch_tile<BKC>(rb, B, sbn, sbk, n0, N, kbeg, kend, nullptr, t);
+  store_tile<AKC>(As[0], ra, t);
+  store_tile<BKC>(Bs[0], rb, t);
+  __syncthreads();
+  int cur = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
-    load_tile<AKC>(As, A, sam, sak, m0, M, k0, kend, kw, t);
-    load_tile<BKC>(Bs, B, sbn, sbk, n0, N, k0, kend, nullptr, t);
-    __syncthreads();
+    const bool more = k0 + GK < kend;
+    if (more) {   // next tile's global loads are in flight during this tile's MFMAs
+      fetch_tile<AKC>(ra, A, sam, sak, m0, M, k0 + GK, kend, kw, t);
+      fetch_tile<BKC>(rb, B, sbn, sbk, n0, N, k0 + GK, kend, nullptr, t);
+    }
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
       double a[2], b[2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) a[tm] = As[tile_idx<AKC>(wm * 32 + tm * 16 + fi, kk * 4 + fk)];
+      for (int tm = 0; tm < 2; ++tm) a[tm] = As[cur][tile_idx<AKC>(wm * 32 + tm * 16 + fi, kk * 4 + fk)];
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) b[tn] = Bs[tile_idx<BKC>(wn * 32 + tn * 16 + fi, kk * 4 + fk)];
+      for (int tn = 0; tn < 2; ++tn) b[tn] = Bs[cur][tile_idx<BKC>(wn * 32 + tn * 16 + fi, kk * 4 + fk)];
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
+    if (more) {
+      store_tile<AKC>(As[cur ^ 1], ra, t);
+      store_tile<BKC>(Bs[cur ^ 1], rb, t);
+    }
     __syncthreads();
+    cur ^= 1;
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
