@@ -195,6 +195,29 @@ def main():
     ref = eng.score_trials((np.ones(4, np.int32), Uh), (1, Th), np.repeat(np.arange(4), 4), np.tile(np.arange(4), 4)).reshape(4, 4)
     spot = float(np.abs(got - ref).max())
 
+    # ---- build extension named by BASELINE configs[1]: targetdim = 150 (top-psi dims), same trials ----
+    td = None
+    if rank == 0 and world == 1 and not args.targetdim and dout > 150:
+        eng.truncate(150)
+        dU150 = torch.empty((M, 150), dtype=torch.float64, device=dev)
+        dT150 = torch.empty((Nt, 150), dtype=torch.float64, device=dev)
+        dE2 = torch.from_numpy(np.random.default_rng(1000 + rank).random((M, D))).to(dev)
+        eng.transform_rows_dev(dE2.data_ptr(), M, D, None, 1, dU150.data_ptr())
+        dV2 = torch.from_numpy(np.random.default_rng(7).random((Nt, D))).to(dev)
+        eng.transform_rows_dev(dV2.data_ptr(), Nt, D, None, 1, dT150.data_ptr())
+        del dE2, dV2
+        eng.score_matrix_dev(dU150.data_ptr(), None, 1, M, dT150.data_ptr(), Nt, out.data_ptr(), Nt)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            eng.score_matrix_dev(dU150.data_ptr(), None, 1, M, dT150.data_ptr(), Nt, out.data_ptr(), Nt)
+        torch.cuda.synchronize(dev)
+        dt150 = (time.perf_counter() - t1) / 2
+        td = {"D_eff": 150, "ms_per_step": round(dt150 * 1e3, 3), "trials_per_s": M * Nt / dt150,
+              "tflops": round(2 * 150 * M * Nt / dt150 / 1e12, 2),
+              "note": "no reference parity exists for targetdim (SURVEY.md App. B Q3); GEMM depth padded to 152"}
+        del dU150, dT150
+
     # ---- separately timed all-gather of a bounded slab (RCCL over xGMI) ----
     allgather = None
     if world > 1:
@@ -249,6 +272,8 @@ def main():
                          "launches": launches, "hbm_write_GBps": round(M * Nt * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None},
             "fit": fit_info, "spot_check_max_abs_err": spot,
         }
+        if td:
+            res["targetdim150"] = td
         if allgather:
             res["allgather"] = allgather
         if not args.no_cpu and world == 1:
