@@ -488,13 +488,28 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
     return tm < tilesM && tn < tilesN;
   };
 
+  // per-tile bias area behind the two stage buffers: 2 slots x {256 row biases, 256 column
+  // biases, 256 row scales}; filled by DMA together with the tile's first stage so that the
+  // epilogue reads biases from LDS instead of waiting on global loads four times per tile
+  float *bias_lds = reinterpret_cast<float *>(smem + 2 * STAGE);
+  auto bias_stage = [&](int64_t tr, int64_t tc, int slot) {
+    float *dst = bias_lds + slot * 768;
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rbias + tr + lane * 4), (LDS_AS void *)dst, 16, 0, 0);
+    else if (wave == 1 && cbias)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(cbias + tc + lane * 4), (LDS_AS void *)(dst + 256), 16, 0, 0);
+    else if (wave == 2 && ZN)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rscale + tr + lane * 4), (LDS_AS void *)(dst + 512), 16, 0, 0);
+  };
+  int tseq = 0;   // tile sequence number of this workgroup (bias slot = tseq & 1)
+
   int base = 0;
   int64_t r0 = 0, c0 = 0;
   int it = 0;
   bool have = false;
   for (; it < niter; ++it)
     if ((have = tile_of(it, r0, c0))) break;
-  if (have) { BT_STAGE(0, r0, c0, smem + base * STAGE) }
+  if (have) { BT_STAGE(0, r0, c0, smem + base * STAGE) bias_stage(r0, c0, 0); }
 
   while (have) {
     const int64_t wrow0 = r0 + wm * 128, wcol0 = c0 + wn * 64;
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
         // last stage: prefetch the NEXT tile's first stage into the freed buffer
         for (++it; it < niter; ++it)
           if ((next_have = tile_of(it, nr0, nc0))) break;
-        if (next_have) { BT_STAGE(0, nr0, nc0, other) }
+        if (next_have) { BT_STAGE(0, nr0, nc0, other) bias_stage(nr0, nc0, (tseq + 1) & 1); }
       }
       const f32x4 *cur = smem + ((base + st) & 1) * STAGE;
       const int np = min(BT_NKQ, KQ - st * BT_NKQ) >> 1;
@@ -544,10 +559,11 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
     }
 
     // ---- epilogue: staging area = the buffer the last stage read ----
+    __syncthreads();   // all waves are done reading the last stage's buffer
+    const float *bl = bias_lds + (tseq & 1) * 768;
     float cb[2];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? cbias[wcol0 + tn * 32 + i] : 0.f;
-    __syncthreads();   // all waves are done reading the last stage's buffer
+    for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? bl[256 + wn * 64 + tn * 32 + i] : 0.f;
     float *tw = reinterpret_cast<float *>(smem + ((base + nst - 1) & 1) * STAGE) + wave * 2048;
     const int rrow = lane >> 4, rcol = (lane & 15) * 4;
     const bool interior = (tr0 + 256 <= M) && (tc0 + 256 <= Nt) && ((ld & 3) == 0) &&
@@ -557,8 +573,8 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
       f32x4 rb[4], rs[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        rb[q] = *reinterpret_cast<const f32x4 *>(rbias + wrow0 + tm * 32 + 8 * q + 4 * hh);
-        if (ZN) rs[q] = *reinterpret_cast<const f32x4 *>(rscale + wrow0 + tm * 32 + 8 * q + 4 * hh);
+        rb[q] = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+        if (ZN) rs[q] = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
       }
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
@@ -584,6 +600,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
       }
     }
     base = (base + nst) & 1;
+    ++tseq;
     have = next_have;
     r0 = nr0; c0 = nc0;
   }
@@ -765,7 +782,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
                       (h->gemm_variant == 21 || h->gemm_variant == 28 || (h->gemm_variant == 0 && (int64_t)btM * btN >= 1024));
   if (use_bt) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
-    const size_t lds = (size_t)2 * BT_NKQ * 512 * 16;
+    const size_t lds = (size_t)2 * BT_NKQ * 512 * 16 + 2 * 768 * 4;   // stage buffers + bias slots
     if (!h->bt_attr_set) {
       PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -171,3 +171,26 @@ def test_trial_list_scoring_matches_per_call_score(engine, oracle):
     for line, (k, j) in zip(lines, [(k, j) for k in list(enrol)[:5] for j in (0, 7, 29)]):
         expect = "m%d m%d-u-%d %.3f" % (k, k, j, p.score(k, enrol[k], test[j]))
         assert line == expect
+
+
+def test_sharded_scorer_on_device_tensors(engine, oracle):
+    """plda_amd.sharding on HBM-resident tensors (world size 1 here; the 2-rank logic is
+    covered by the gloo test): row slabs through MPlda.score_matrix_dev reproduce the oracle."""
+    import torch
+    from plda_amd.sharding import gpu_score_block, score_matrix_sharded
+    d = 40
+    m, x, y = _model(oracle, 19, 800, d, 25, scale_between=0.4)
+    _load(engine, m)
+    rng = np.random.default_rng(3)
+    counts = rng.integers(1, 4, 150).astype(np.int32)
+    U = np.stack([oracle.transform_ivector(m, r, c) for r, c in zip(rng.random((150, d)), counts)])
+    V = np.stack([oracle.transform_ivector(m, r, 1) for r in rng.random((90, d))])
+    dev = torch.device("cuda", 0)
+    loc, full = score_matrix_sharded(gpu_score_block(engine), torch.from_numpy(U).to(dev),
+                                     torch.from_numpy(counts).to(dev), torch.from_numpy(V).to(dev), 150,
+                                     gather=True, slab_rows=64)
+    torch.cuda.synchronize()
+    ref = oracle.score_block(m["psi"], U, counts, V)
+    assert full is loc and loc.shape == (150, 90)
+    assert (np.abs(loc.cpu().numpy() - ref) <= score_tol(ref)).all()
+    engine.set_stream(None)
