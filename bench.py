@@ -107,7 +107,9 @@ def main():
 
     from plda_amd import MPlda
     eng = MPlda(local_rank)
-    stream = torch.cuda.current_stream(dev)
+    # everything (torch ops, RCCL collectives, the engine's kernels) on ONE non-default stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
 
     N, D, K = args.n, args.dim, args.speakers

@@ -50,8 +50,11 @@ int plda_create(int device, plda_handle **out);
 int plda_destroy(plda_handle *h);
 const char *plda_last_error(const plda_handle *h);
 int plda_abi_version(void);
-/* use an existing hipStream_t (e.g. torch's current stream); NULL = the handle's own */
+/* enqueue on exactly this hipStream_t (e.g. torch's current stream; NULL is HIP's default
+ * stream, with its implicit-synchronisation rules); plda_reset_stream goes back to the
+ * handle's own non-blocking stream */
 int plda_set_stream(plda_handle *h, void *hip_stream);
+int plda_reset_stream(plda_handle *h);
 int plda_synchronize(plda_handle *h);
 
 /* ---- fit: replaces MPlda_fit (pldamodule.cpp:42-109) ----

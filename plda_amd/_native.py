@@ -29,6 +29,7 @@ SIGNATURES = {
     "plda_destroy": (C.c_int, [_vp]),
     "plda_last_error": (C.c_char_p, [_vp]),
     "plda_set_stream": (C.c_int, [_vp, _vp]),
+    "plda_reset_stream": (C.c_int, [_vp]),
     "plda_synchronize": (C.c_int, [_vp]),
     "plda_fit": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32]),
     "plda_fit_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),

@@ -140,7 +140,13 @@ const char *plda_last_error(const plda_handle *h) { return h ? h->err.c_str() : 
 
 int plda_set_stream(plda_handle *h, void *hip_stream) {
   if (!h) return PLDA_E_INVAL;
-  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return PLDA_OK;
+}
+
+int plda_reset_stream(plda_handle *h) {
+  if (!h) return PLDA_E_INVAL;
+  h->stream = h->own_stream;
   return PLDA_OK;
 }
 

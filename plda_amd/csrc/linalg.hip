@@ -423,6 +423,27 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
   const int wgs = nb_even / 2;
   const int E = (int)ceil_div(D, 64);
   const size_t lds = (size_t)4 * JB * D * sizeof(double);
+  if (h->stream == nullptr) {
+    // HIP's legacy default stream cannot be captured: launch the rounds directly
+    PLDA_HIP(h, hipFuncSetAttribute(E <= 1 ? reinterpret_cast<const void *>(&jacobi_block_kernel<1>)
+                                    : E <= 2 ? reinterpret_cast<const void *>(&jacobi_block_kernel<2>)
+                                    : E <= 4 ? reinterpret_cast<const void *>(&jacobi_block_kernel<4>)
+                                    : E <= 8 ? reinterpret_cast<const void *>(&jacobi_block_kernel<8>)
+                                             : reinterpret_cast<const void *>(&jacobi_block_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PLDA_HIP(h, hipMemsetAsync(drot, 0, sizeof(int), h->stream));
+    for (int round = 0; round < nb_even - 1; ++round) {
+#define JR(EE) jacobi_block_kernel<EE><<<wgs, 256, lds, h->stream>>>(G, V, D, nb_even, round, tol, drot)
+      if (E <= 1) JR(1);
+      else if (E <= 2) JR(2);
+      else if (E <= 4) JR(4);
+      else if (E <= 8) JR(8);
+      else JR(16);
+#undef JR
+    }
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
   if (h->jac_exec && (h->jac_G != G || h->jac_V != V || h->jac_D != D)) {
     (void)hipGraphExecDestroy(h->jac_exec);
     h->jac_exec = nullptr;

@@ -306,7 +306,12 @@ class MPlda(object):
 
     # ------------------------------------------------- device-resident path
     def set_stream(self, hip_stream):
-        self._ck(self._lib.plda_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None))
+        """Enqueue on this hipStream_t (an int handle, e.g. torch.cuda.current_stream().cuda_stream;
+        0 is HIP's default stream).  None returns to the handle's own stream."""
+        if hip_stream is None:
+            self._ck(self._lib.plda_reset_stream(self._h))
+        else:
+            self._ck(self._lib.plda_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def synchronize(self):
         self._ck(self._lib.plda_synchronize(self._h))

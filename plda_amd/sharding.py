@@ -91,7 +91,7 @@ def score_matrix_sharded(score_block, U_local, n_local, V, m_global, gather=Fals
 def gpu_score_block(engine, n_uniform=0):
     """score_block over MPlda.score_matrix_dev for HBM-resident fp64 tensors."""
     import torch as _t
-    engine.set_stream(_t.cuda.current_stream().cuda_stream)
+    engine.set_stream(_t.cuda.current_stream().cuda_stream)   # 0 = HIP's default stream, honoured as such
 
     def fn(U, n, V):
         out = torch.empty((U.shape[0], V.shape[0]), dtype=torch.float32, device=U.device)

@@ -25,7 +25,7 @@ def test_c2_full_size_properties():
     psi = np.sort(rng.random(D) * 4.0)[::-1].copy()
     eng = MPlda(0)
     eng.set_model(rng.random(D), T, psi)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
     X = torch.from_numpy(rng.random((N, D))).to(dev)
     Ut = torch.empty((N, D), dtype=torch.float64, device=dev)
     eng.transform_rows_dev(X.data_ptr(), N, D, None, 1, Ut.data_ptr())
