@@ -71,23 +71,51 @@ __global__ void enrol_bias_kernel(const double *__restrict__ U, const int32_t *_
   }
 }
 
-// q_j (uniform n only): one wave per test row.
-__global__ void test_bias_kernel(const double *__restrict__ V, int n_uniform,
-                                 const double *__restrict__ psi, int D, int64_t Nt,
-                                 float *__restrict__ cbias) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= Nt) return;
-  const double *v = V + row * (int64_t)D;
+// Uniform enrol count: the per-dimension coefficients do not depend on the row, so they are
+// computed once per call (one workgroup): w_d = c^2/var, g_d = 1/var - 1/(1+psi) and
+// L = sum_d [log var - log(1+psi)]; the bias kernels then are plain weighted sums of squares.
+__global__ __launch_bounds__(256) void uniform_coef_kernel(const double *__restrict__ psi, int D, int n_uniform,
+                                                           double *__restrict__ coef /*[2*D + 1]: w, g, L*/) {
+  __shared__ double red[256];
   double acc = 0.0;
-  for (int d = lane; d < D; d += 64) {
+  for (int d = threadIdx.x; d < D; d += 256) {
     double c, var;
     const double p = psi[d];
     llr_coef((double)n_uniform, p, c, var);
-    acc += (1.0 / var - 1.0 / (1.0 + p)) * v[d] * v[d];
+    coef[d] = c * c / var;
+    coef[D + d] = 1.0 / var - 1.0 / (1.0 + p);
+    acc += log(var) - log(1.0 + p);
   }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) coef[2 * D] = red[0];
+}
+
+// out[row] = scale_row * (-1/2) * (L + sum_d w_d x_d^2) (+ z-norm folding), one wave per row
+__global__ void weighted_sq_bias_kernel(const double *__restrict__ X, const double *__restrict__ w, double Lconst_on,
+                                        const double *__restrict__ Lptr, int D, int64_t R,
+                                        const double *__restrict__ zmean, const double *__restrict__ zstd,
+                                        float *__restrict__ bias, float *__restrict__ rscale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const double *x = X + row * (int64_t)D;
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) acc += w[d] * x[d] * x[d];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) cbias[row] = (float)(-0.5 * acc);
+  if (lane == 0) {
+    double r = -0.5 * (acc + (Lconst_on != 0.0 ? *Lptr : 0.0)), sc = 1.0;
+    if (zmean && zstd) {
+      const double sd = zstd[row];
+      if (sd != 0.0) { sc = 1.0 / sd; r = (r - zmean[row]) * sc; }
+    }
+    bias[row] = (float)r;
+    if (rscale) rscale[row] = (float)sc;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -728,15 +756,21 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   const double *psi = h->d_psi.as<double>();
   const bool zn = dzmean && dzstd;
   const int wpb = 4;
-  enrol_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
-      dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
-      zn ? h->s_rscale.as<float>() : nullptr);
-  PLDA_LAUNCH_CHECK(h);
-  if (!op.mixed) {
-    test_bias_kernel<<<(unsigned)ceil_div(Nt, wpb), wpb * 64, 0, h->stream>>>(
-        dV, n_uniform, psi, D, Nt, h->s_cbias.as<float>());
-    PLDA_LAUNCH_CHECK(h);
+  if (op.mixed) {
+    enrol_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
+        dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
+        zn ? h->s_rscale.as<float>() : nullptr);
+  } else {
+    PLDA_HIP(h, h->w[11].reserve((size_t)(2 * D + 1) * 8));
+    double *coef = h->w[11].as<double>();
+    uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
+    weighted_sq_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
+        dU, coef, 1.0, coef + 2 * D, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
+        zn ? h->s_rscale.as<float>() : nullptr);
+    weighted_sq_bias_kernel<<<(unsigned)ceil_div(Nt, wpb), wpb * 64, 0, h->stream>>>(
+        dV, coef + D, 0.0, coef + 2 * D, D, Nt, nullptr, nullptr, h->s_cbias.as<float>(), nullptr);
   }
+  PLDA_LAUNCH_CHECK(h);
   const dim3 ga((unsigned)(op.Mpad / 64), (unsigned)ceil_div(op.Kg, 32));
   const dim3 gb((unsigned)(op.Npad / 64), (unsigned)ceil_div(op.Kg, 32));
   if (op.mixed) {
