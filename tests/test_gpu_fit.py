@@ -170,3 +170,47 @@ def test_pldatest_large_and_odd_shapes(oracle):
     assert SL.shape == (10, 100) and np.isfinite(SL).all()
     gm = pl._instance.get_model(); it = pl._instance.fit_internals()
     assert np.abs(gm["transform"] @ it["W"] @ gm["transform"].T - np.eye(1024)).max() < 1e-8
+
+
+def test_c3_c4_scale_downs(oracle):
+    """BASELINE configs C3 / C4 scaled to oracle-feasible sizes: D = 512 with 100 utterances per
+    speaker model (C3) and D = 256 with enrol counts drawn from 1..5 (C4, GEMM depth 2D)."""
+    from plda_amd import MPlda
+    # C3 scale-down
+    x, y = make_data(33, 2400, 512, 24, scale_between=0.3)
+    eng = MPlda(0)
+    eng.fit(x, y, 3)
+    ref = oracle.fit(x, y, 3)
+    g = eng.get_model()
+    assert np.abs(g["psi"] - ref["psi"]).max() <= 1e-8 * ref["psi"].max()
+    enrol = eng.transform(x, y)                                   # 24 models, n = 100
+    assert all(v[0] == 100 for v in enrol.values())
+    tx = x[::7] + 0.01
+    test = eng.transform(tx, np.arange(len(tx), dtype=np.uint64))
+    S = eng.score_matrix(enrol, test, znorm=False)
+    _, rc, rv = oracle.transform_groups(ref, x, y)
+    rtv = np.stack([oracle.transform_ivector(ref, r, 1) for r in tx[:60]])
+    R = oracle.score_block(ref["psi"], rv, rc, rtv)
+    assert (np.abs(S[:, :60] - R) <= score_tol(R)).all(), np.abs(S[:, :60] - R).max()
+    # C4 scale-down: mixed enrol counts
+    x4, y4 = make_data(34, 1500, 256, 30, scale_between=0.4)
+    e4 = MPlda(0); e4.fit(x4, y4, 3)
+    r4 = oracle.fit(x4, y4, 3)
+    rng = np.random.default_rng(4)
+    lab = np.repeat(np.arange(200), rng.integers(1, 6, 200)).astype(np.uint64)
+    ex = rng.random((len(lab), 256))
+    en = e4.transform(ex, lab)
+    te = e4.transform(x4[:97], np.arange(97, dtype=np.uint64))
+    S4 = e4.score_matrix(en, te, znorm=False)
+    _, c4, v4 = oracle.transform_groups(r4, ex, lab)
+    assert len(np.unique(c4)) > 1
+    t4 = np.stack([oracle.transform_ivector(r4, r, 1) for r in x4[:97]])
+    R4 = oracle.score_block(r4["psi"], v4, c4, t4)
+    assert (np.abs(S4 - R4) <= score_tol(R4)).all(), np.abs(S4 - R4).max()
+
+
+def test_maximum_feature_dim_is_reported():
+    from liblda import PLDA
+    x = np.random.default_rng(0).random((40, 1025))
+    with pytest.raises(RuntimeError, match="1024"):
+        PLDA().fit(x, (np.arange(40) % 4).astype(np.uint64), 1)
