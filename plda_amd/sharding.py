@@ -88,6 +88,43 @@ def score_matrix_sharded(score_block, U_local, n_local, V, m_global, gather=Fals
     return out_local, torch.cat(rows, dim=0)
 
 
+def znorm_stats_sharded(znorm_block, models_local, m_global, group=None):
+    """z-norm statistics sharded by MODEL: every rank holds the whole cohort
+    and computes (mean, std) for its contiguous slab of models with `znorm_block(models) ->
+    (mean[m], std[m])`; the only collective is an all-gather of the padded [M/R, 2] results
+    (a few hundred KB at C5).  Returns (mean[M], std[M]) on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, stop = shard_rows(m_global, world, rank)
+    assert models_local.shape[0] == stop - start, "models_local must hold exactly this rank's models"
+    mean, std = znorm_block(models_local)
+    if world == 1:
+        return mean, std
+    m_pad = padded_shard(m_global, world)
+    send = torch.zeros((m_pad, 2), dtype=torch.float64, device=mean.device)
+    send[: stop - start, 0] = mean
+    send[: stop - start, 1] = std
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    rows = []
+    for w in range(world):
+        s0, e0 = shard_rows(m_global, world, w)
+        rows.append(parts[w][: e0 - s0])
+    full = torch.cat(rows, dim=0)
+    return full[:, 0].contiguous(), full[:, 1].contiguous()
+
+
+def gpu_znorm_block(engine, dbkg, nb, din):
+    """znorm_block over MPlda.znorm_stats_dev: cohort `dbkg` [nb, din] fp64 tensor resident on this GPU."""
+    def fn(models):
+        m = models.shape[0]
+        mean = torch.empty(m, dtype=torch.float64, device=models.device)
+        std = torch.empty(m, dtype=torch.float64, device=models.device)
+        engine.znorm_stats_dev(dbkg.data_ptr(), nb, 0, din, models.data_ptr(), m, mean.data_ptr(), std.data_ptr())
+        return mean, std
+    return fn
+
+
 def gpu_score_block(engine, n_uniform=0):
     """score_block over MPlda.score_matrix_dev for HBM-resident fp64 tensors."""
     import torch as _t

@@ -73,6 +73,45 @@ def _worker(rank, world, port, gather, q):
     dist.destroy_process_group()
 
 
+def _znorm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as ob
+    from conftest import make_data
+    from plda_amd.sharding import shard_rows as sr, znorm_stats_sharded
+    x, y = make_data(61, 400, 10, 20, scale_between=0.5)
+    model = ob.fit(x, y, 3)
+    _, _, models = ob.transform_groups(model, x[:95], np.arange(95, dtype=np.uint64))   # 95 models: uneven slabs
+    bkg = x[200:260]
+    a, b = sr(95, world, rank)
+
+    def block(mods):
+        m, s = ob.norm(model, bkg, mods.numpy())
+        return torch.from_numpy(m), torch.from_numpy(s)
+
+    mean, std = znorm_stats_sharded(block, torch.from_numpy(models[a:b]), 95)
+    rm, rs = ob.norm(model, bkg, models)
+    q.put((rank, bool(np.array_equal(mean.numpy(), rm) and np.array_equal(std.numpy(), rs))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_znorm_gloo_world2(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_znorm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
 @pytest.mark.parametrize("gather", [False, True])
 def test_sharded_trials_matrix_gloo_world2(oracle, gather):
     ctx = mp.get_context("spawn")
