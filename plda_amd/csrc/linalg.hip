@@ -296,6 +296,21 @@ int tri_invert_f64(plda_handle *h, const double *L, double *X, int D) {
 // rotations are applied per round trip to L2 instead of one.
 constexpr int JB = 4;
 
+// fp64 reciprocal / reciprocal square root: hardware estimate refined by Newton steps to full
+// double precision (the inputs here are well inside the normal range)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
 template <int E>
 __global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ A, double *__restrict__ V,
                                                            int D, int nb_even, int oround, double tol,
@@ -345,10 +360,15 @@ __global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ 
       alpha = wave_sum_f64(alpha);
       beta = wave_sum_f64(beta);
       gamma = wave_sum_f64(gamma);
-      if (gamma != 0.0 && fabs(gamma) > tol * sqrt(alpha * beta)) {
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + tn * tn), sn = c * tn;
+      if (gamma != 0.0 && gamma * gamma > tol * tol * alpha * beta) {
+        // tan(theta) = gamma / (a + sign(a) sqrt(a^2 + gamma^2)), a = (beta - alpha)/2 -- the same root
+        // as sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = a/gamma -- with one rsq + one rcp + one
+        // rsq (hardware estimate + Newton steps) instead of three IEEE sqrt and three divisions
+        const double a = 0.5 * (beta - alpha);
+        const double hsq = a * a + gamma * gamma;
+        const double h = hsq * rsqrt_nr(hsq);
+        const double tn = gamma * rcp_nr(a + (a >= 0.0 ? h : -h));
+        const double c = rsqrt_nr(1.0 + tn * tn), sn = c * tn;
         double *vp = lV + p * D, *vq = lV + q * D;
 #pragma unroll
         for (int e = 0; e < E; ++e) {

@@ -117,3 +117,30 @@ def test_float32_and_fortran_inputs_are_coerced(fitted, oracle):
     c = eng.transform(x[:40].astype(np.float32), y[:40])
     for k in c:
         np.testing.assert_allclose(c[k][1], b[k][1], rtol=1e-5, atol=1e-6)
+
+
+def test_fit_degenerate_settings(oracle):
+    """iters = 0 (W = B = I, psi = 1), singleton speakers (n_k = 1), and more dims than samples."""
+    from plda_amd import MPlda
+    x, y = make_data(71, 300, 12, 30, skew=True)
+    eng = MPlda(0)
+    eng.fit(x, y, 0)
+    m = eng.get_model()
+    np.testing.assert_allclose(m["psi"], 1.0, atol=1e-13)
+    np.testing.assert_allclose(m["transform"].T @ m["transform"], np.eye(12), atol=1e-12)
+    # every speaker a singleton except one pair: scatter has rank 1, the EM prior keeps W positive definite
+    ys = np.arange(40, dtype=np.uint64); ys[39] = 38
+    xs = np.random.default_rng(1).random((40, 6))
+    eng.fit(xs, ys, 4)
+    ref = oracle.fit(xs, ys, 4)
+    assert np.abs(eng.get_model()["psi"] - ref["psi"]).max() <= 1e-8 * ref["psi"].max()
+    # D > N
+    xw = np.random.default_rng(2).random((30, 64)); yw = (np.arange(30) % 5).astype(np.uint64)
+    eng.fit(xw, yw, 3)
+    refw = oracle.fit(xw, yw, 3)
+    g = eng.get_model()
+    assert np.abs(g["psi"] - refw["psi"]).max() <= 1e-8 * refw["psi"].max()
+    assert np.abs(g["transform"].T @ g["transform"] - refw["transform"].T @ refw["transform"]).max() <= \
+        1e-7 * np.abs(refw["transform"].T @ refw["transform"]).max()
+    with pytest.raises(RuntimeError):
+        eng.fit(xw, yw, -1)
