@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--targetdim", type=int, default=0, help="build extension: keep the top-psi dims (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--gather-rows", type=int, default=2048, help="rows per rank in the separately timed all-gather")
+    ap.add_argument("--shard-fit", action="store_true",
+                    help="N>1: shard the fit statistics by speaker (all-reduce of the scatter + all-gather of the "
+                         "centroids, replica EM) instead of fitting on rank 0 and broadcasting the model")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for logic checks)")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -120,7 +123,24 @@ def main():
 
     # ---- fit (rank 0) + broadcast of the model ----
     fit_info = None
-    if rank == 0:
+    if args.shard_fit and world > 1:
+        from plda_amd.sharding import fit_sharded, gpu_fit_blocks, speaker_shard
+        mask = speaker_shard(torch.from_numpy(y.astype(np.int64)), world, rank).numpy()
+        dX = torch.from_numpy(X[mask]).to(dev)
+        ly = torch.from_numpy(y[mask].astype(np.int64))
+        stats_block, em_block = gpu_fit_blocks(eng)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        kg = fit_sharded(stats_block, em_block, dX, ly, iters=args.iters)
+        torch.cuda.synchronize(dev)
+        ft = eng.fit_timings()
+        fit_info = {"sharded_by_speaker": True, "speakers": kg, "em_ms": round(ft["em_ms"], 3), "iters": ft["iters"],
+                    "em_iters_per_s": round(ft["iters"] / (ft["em_ms"] / 1e3), 2) if ft["em_ms"] > 0 else None,
+                    "fit_wall_s": round(time.perf_counter() - t0, 4), "N": N, "D": D, "K": K}
+        del dX
+        model = eng.get_model()
+        packed = np.concatenate([model["mean"], model["transform"].ravel(), model["psi"]])
+    elif rank == 0:
         dX = torch.from_numpy(X).to(dev)
         dy = torch.from_numpy(y.astype(np.int64)).to(dev)   # same bits as uint64 for labels < 2^63
         torch.cuda.synchronize(dev)
@@ -139,7 +159,7 @@ def main():
         packed = np.concatenate([model["mean"], model["transform"].ravel(), model["psi"]])
     else:
         packed = np.zeros(D + D * D + D)
-    if world > 1:
+    if world > 1 and not args.shard_fit:
         t = torch.from_numpy(packed).to(dev)
         dist.broadcast(t, src=0)
         packed = t.cpu().numpy()

@@ -66,6 +66,19 @@ int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D,
              const uint64_t *labels, int32_t iters);
 int plda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D,
                  const uint64_t *dlabels, int64_t K, int32_t iters);
+/* The same fit in its two halves, for fitting on several GPUs: every
+ * quantity AddSamples accumulates (pldamodule.cpp:94-98) is a sum over speakers, so each rank
+ * runs the statistics pass on the rows of ITS speakers (local dense labels 0..K-1),
+ *   plda_fit_stats_dev      -> means[K,D], counts[K], offset scatter[D,D] of those speakers,
+ *   plda_fit_get_stats_dev  copies them to caller-owned DEVICE buffers (any may be NULL),
+ * the ranks all-reduce the scatter and all-gather means/counts, and every rank then runs
+ *   plda_fit_em_dev         EM + GetOutput (pldamodule.cpp:102-106) on the merged statistics.
+ * plda_fit_dev == plda_fit_stats_dev followed by plda_fit_em_dev on the handle's own buffers. */
+int plda_fit_stats_dev(plda_handle *h, const double *dX, int64_t N, int32_t D,
+                       const uint64_t *dlabels, int64_t K);
+int plda_fit_get_stats_dev(plda_handle *h, double *dmeans, int64_t *dcounts, double *dscatter);
+int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts, int64_t K,
+                    const double *dscatter, int32_t D, int32_t iters);
 /* timings of the last fit, milliseconds: [0] statistics pass (sort+centroid+scatter),
  * [1] EM loop (all iterations), [2] GetOutput; [3] = iterations run */
 int plda_fit_timings(plda_handle *h, double out_ms[4]);

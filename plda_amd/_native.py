@@ -33,6 +33,9 @@ SIGNATURES = {
     "plda_synchronize": (C.c_int, [_vp]),
     "plda_fit": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32]),
     "plda_fit_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),
+    "plda_fit_stats_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64]),
+    "plda_fit_get_stats_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "plda_fit_em_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32]),
     "plda_fit_timings": (C.c_int, [_vp, _vp]),
     "plda_fit_get_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plda_fit_num_classes": (C.c_int, [_vp, C.POINTER(_i64)]),

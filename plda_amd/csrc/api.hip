@@ -179,6 +179,43 @@ int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64
   return fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), K, iters);
 }
 
+int plda_fit_stats_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return fit_stats_device(h, dX, N, D, dlabels, K);
+}
+
+int plda_fit_get_stats_dev(plda_handle *h, double *dmeans, int64_t *dcounts, double *dscatter) {
+  if (!h) return PLDA_E_INVAL;
+  if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats_dev: no statistics pass has run on this handle");
+  PLDA_TRY(set_device(h));
+  const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
+  if (dmeans) PLDA_HIP(h, hipMemcpyAsync(dmeans, h->f_means.p, K * D * 8, hipMemcpyDeviceToDevice, h->stream));
+  if (dcounts) PLDA_HIP(h, hipMemcpyAsync(dcounts, h->f_counts.p, K * 8, hipMemcpyDeviceToDevice, h->stream));
+  if (dscatter) PLDA_HIP(h, hipMemcpyAsync(dscatter, h->f_scatter.p, D * D * 8, hipMemcpyDeviceToDevice, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts, int64_t K, const double *dscatter,
+                    int32_t D, int32_t iters) {
+  if (!h) return PLDA_E_INVAL;
+  if (!dmeans || !dcounts || !dscatter || K <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit_em: bad argument");
+  if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
+  PLDA_TRY(set_device(h));
+  PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
+  PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
+  PLDA_HIP(h, h->f_scatter.reserve((size_t)D * D * 8));
+  if (dmeans != h->f_means.p)
+    PLDA_HIP(h, hipMemcpyAsync(h->f_means.p, dmeans, (size_t)K * D * 8, hipMemcpyDeviceToDevice, h->stream));
+  if ((const void *)dcounts != h->f_counts.p)
+    PLDA_HIP(h, hipMemcpyAsync(h->f_counts.p, dcounts, (size_t)K * 8, hipMemcpyDeviceToDevice, h->stream));
+  if (dscatter != h->f_scatter.p)
+    PLDA_HIP(h, hipMemcpyAsync(h->f_scatter.p, dscatter, (size_t)D * D * 8, hipMemcpyDeviceToDevice, h->stream));
+  h->fit_ms[0] = 0.0;
+  return fit_em_device(h, K, D, iters);
+}
+
 int plda_fit_timings(plda_handle *h, double out_ms[4]) {
   if (!h || !out_ms) return PLDA_E_INVAL;
   for (int i = 0; i < 4; ++i) out_ms[i] = h->fit_ms[i];

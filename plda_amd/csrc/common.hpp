@@ -125,6 +125,8 @@ int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t 
                         const int64_t *doffsets, int64_t U, int method, int l2norm, double *dout);
 
 // ---- fit.hip ----
+int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K);
+int fit_em_device(plda_handle *h, int64_t K, int D, int iters);
 int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels,
                int64_t K, int iters);
 

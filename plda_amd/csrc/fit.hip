@@ -337,18 +337,15 @@ static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int
   return PLDA_OK;
 }
 
-int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K,
-               int iters) {
-  if (!dX || !dlabels || N <= 0 || D <= 0 || iters < 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
-  if (K == 1)
-    return fail(h, PLDA_E_ONE_SPEAKER,
-                "Number of speakers is 1. Aborting PLDA esimation, at least two speakers are required!");
+// Statistics pass (pldamodule.cpp:76-100): leaves means[K,D], counts[K] and the offset scatter of THESE
+// classes in the handle.  The scatter, the weighted class sum and the class weight are all additive over
+// disjoint sets of speakers, which is what lets the pass shard by speaker.
+int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K) {
+  if (!dX || !dlabels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
   if (K <= 0 || K > N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
   if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
   const size_t DD = (size_t)D * D;
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  h->simdiag_has_vr = false;   // a new fit starts cold
-  h->jac_total_sweeps = 0;
   const double t0 = now_ms();
 
   // ---------------- statistics (K1a, K1, K2) ----------------
@@ -362,18 +359,10 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
   PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
   PLDA_HIP(h, h->f_scatter.reserve(DD * 8));
-  PLDA_HIP(h, h->f_sum.reserve((size_t)D * 8));
-  PLDA_HIP(h, h->f_W.reserve(DD * 8));
-  PLDA_HIP(h, h->f_B.reserve(DD * 8));
   PLDA_HIP(h, h->w[3].reserve((size_t)N * 8));               // row weights
-  PLDA_HIP(h, h->w[4].reserve((size_t)D * 8 * 2 + 64));       // mu, scalars
   double *means = h->f_means.as<double>();
   double *S = h->f_scatter.as<double>();
-  double *sum = h->f_sum.as<double>();
-  double *W = h->f_W.as<double>(), *B = h->f_B.as<double>();
   double *roww = h->w[3].as<double>();
-  double *mu = h->w[4].as<double>();
-  double *scalars = mu + D;
   counts_to_i64_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, h->stream>>>(offsets, K, h->f_counts.as<int64_t>());
   {
     std::vector<int> hoff((size_t)K + 1);
@@ -384,6 +373,66 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   }
   centroid_kernel<<<(unsigned)K, 256, 0, h->stream>>>(dX, D, perm, offsets, means, roww);
   PLDA_LAUNCH_CHECK(h);
+  // offset_scatter = X^T diag(1/n_label) X - sum_k (n_k w_k) m_k m_k^T,  n_k w_k = 1
+  PLDA_TRY(gemm_f64(h, D, D, N, 1.0, dX, 1, D, dX, D, 1, roww, 0.0, S, D));
+  PLDA_TRY(gemm_f64(h, D, D, K, -1.0, means, 1, D, means, D, 1, nullptr, 1.0, S, D));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  h->fit_K = K; h->fit_D = D;
+  h->fit_ms[0] = now_ms() - t0;
+  h->fit_ms[1] = h->fit_ms[2] = h->fit_ms[3] = 0.0;
+  return PLDA_OK;
+}
+
+__global__ void counts_to_offsets_kernel(const int64_t *__restrict__ counts, int64_t K, int *__restrict__ offsets,
+                                         int *__restrict__ bad) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k > K) return;
+  int v = 0;
+  if (k < K) {
+    const int64_t c = counts[k];
+    if (c <= 0 || c > 0x7fffffff) atomicOr(bad, 1);
+    v = (int)c;
+  }
+  offsets[k] = v;
+}
+
+// EM + GetOutput (pldamodule.cpp:102-106) from the statistics held by the handle: means[K,D], counts[K],
+// offset scatter.  Everything else the estimator needs (sum_, class_weight, the global mean) follows from
+// the means and counts, so this is also the replica step after a sharded statistics pass.
+int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
+  if (K <= 0 || D <= 0 || iters < 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
+  if (K == 1)
+    return fail(h, PLDA_E_ONE_SPEAKER,
+                "Number of speakers is 1. Aborting PLDA esimation, at least two speakers are required!");
+  const size_t DD = (size_t)D * D;
+  h->simdiag_has_vr = false;   // a new fit starts cold
+  h->jac_total_sweeps = 0;
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const double t1 = now_ms();
+  PLDA_HIP(h, h->f_sum.reserve((size_t)D * 8));
+  PLDA_HIP(h, h->f_W.reserve(DD * 8));
+  PLDA_HIP(h, h->f_B.reserve(DD * 8));
+  PLDA_HIP(h, h->w[1].reserve((size_t)(K + 2) * 4 + 64));
+  PLDA_HIP(h, h->w[4].reserve((size_t)D * 8 * 2 + 64));       // mu, scalars
+  double *means = h->f_means.as<double>();
+  double *S = h->f_scatter.as<double>();
+  double *sum = h->f_sum.as<double>();
+  double *W = h->f_W.as<double>(), *B = h->f_B.as<double>();
+  double *mu = h->w[4].as<double>();
+  double *scalars = mu + D;
+  int *offsets = h->w[1].as<int>();
+  {
+    int *bad = offsets + K + 1;
+    int hbad = 0;
+    PLDA_HIP(h, hipMemsetAsync(bad, 0, 4, h->stream));
+    counts_to_offsets_kernel<<<(unsigned)ceil_div(K + 1, 256), 256, 0, h->stream>>>(h->f_counts.as<int64_t>(), K,
+                                                                                  offsets, bad);
+    scan_kernel<<<1, 1024, 0, h->stream>>>(offsets, K + 1);
+    PLDA_LAUNCH_CHECK(h);
+    PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (hbad) return fail(h, PLDA_E_INVAL, "fit: class counts must be positive");
+  }
   PLDA_HIP(h, h->w[7].reserve((size_t)CS_SPLIT * (D + 1) * 8));
   {
     double *partial = h->w[7].as<double>(), *wpart = partial + (size_t)CS_SPLIT * D;
@@ -392,14 +441,10 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
     class_sum_final_kernel<<<(unsigned)ceil_div(D, 256), 256, 0, h->stream>>>(partial, wpart, D, sum, mu, scalars);
   }
   PLDA_LAUNCH_CHECK(h);
-  // offset_scatter = X^T diag(1/n_label) X - sum_k (n_k w_k) m_k m_k^T,  n_k w_k = 1
-  PLDA_TRY(gemm_f64(h, D, D, N, 1.0, dX, 1, D, dX, D, 1, roww, 0.0, S, D));
-  PLDA_TRY(gemm_f64(h, D, D, K, -1.0, means, 1, D, means, D, 1, nullptr, 1.0, S, D));
   double class_weight = 0.0;
   PLDA_HIP(h, hipMemcpyAsync(&class_weight, scalars, 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double example_weight = (double)K;  // sum_k w_k n_k with w_k = 1/n_k
-  const double t1 = now_ms();
 
   // ---------------- EM (K3) ----------------
   PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3));   // Mc / P, Y1, Y2
@@ -453,8 +498,18 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   const double t3 = now_ms();
   h->fitted = true;
   h->fit_K = K; h->fit_D = D;
-  h->fit_ms[0] = t1 - t0; h->fit_ms[1] = t2 - t1; h->fit_ms[2] = t3 - t2; h->fit_ms[3] = (double)iters;
+  h->fit_ms[1] = t2 - t1; h->fit_ms[2] = t3 - t2; h->fit_ms[3] = (double)iters;
   return PLDA_OK;
+}
+
+int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K,
+               int iters) {
+  if (!dX || !dlabels || N <= 0 || D <= 0 || iters < 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
+  if (K == 1)
+    return fail(h, PLDA_E_ONE_SPEAKER,
+                "Number of speakers is 1. Aborting PLDA esimation, at least two speakers are required!");
+  PLDA_TRY(fit_stats_device(h, dX, N, D, dlabels, K));
+  return fit_em_device(h, K, D, iters);
 }
 
 // ------------------------------------------------------------------------------------

@@ -329,6 +329,24 @@ class MPlda(object):
         self._ck(self._lib.plda_fit_dev(self._h, C.c_void_p(int(dX)), int(n), int(d), C.c_void_p(int(dlabels)),
                                         int(k), int(iters)))
 
+    def fit_stats_dev(self, dX, n, d, dlabels, k):
+        """Statistics pass only (pldamodule.cpp:76-100) over this handle's share of the speakers."""
+        self._ck(self._lib.plda_fit_stats_dev(self._h, C.c_void_p(int(dX)), int(n), int(d),
+                                              C.c_void_p(int(dlabels)), int(k)))
+
+    def fit_get_stats_dev(self, dmeans, dcounts, dscatter):
+        self._ck(self._lib.plda_fit_get_stats_dev(self._h, C.c_void_p(int(dmeans)) if dmeans else None,
+                                                  C.c_void_p(int(dcounts)) if dcounts else None,
+                                                  C.c_void_p(int(dscatter)) if dscatter else None))
+
+    def fit_em_dev(self, dmeans, dcounts, k, dscatter, d, iters=10):
+        """EM + GetOutput (pldamodule.cpp:102-106) on merged statistics."""
+        rc = self._lib.plda_fit_em_dev(self._h, C.c_void_p(int(dmeans)), C.c_void_p(int(dcounts)), int(k),
+                                       C.c_void_p(int(dscatter)), int(d), int(iters))
+        if rc == -2:
+            raise ValueError(self._lib.plda_last_error(self._h).decode())
+        self._ck(rc)
+
     def transform_rows_dev(self, dX, r, d, dn, n_uniform, dout):
         self._ck(self._lib.plda_transform_rows_dev(self._h, C.c_void_p(int(dX)), int(r), int(d),
                                                    C.c_void_p(int(dn)) if dn else None, int(n_uniform),

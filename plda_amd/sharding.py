@@ -1,4 +1,5 @@
-"""plda_amd/sharding.py -- row-sharded trials matrix across ranks (one process per GPU).
+"""plda_amd/sharding.py -- the path sharded across ranks (one process per GPU): trials by enrol row,
+z-norm statistics by model, fit statistics by speaker.
 
 The trials matrix partitions by enrol row: trial (i, j) needs only enrol row i, the
 replicated test set and the replicated model, so every rank scores its contiguous row
@@ -112,6 +113,80 @@ def znorm_stats_sharded(znorm_block, models_local, m_global, group=None):
         rows.append(parts[w][: e0 - s0])
     full = torch.cat(rows, dim=0)
     return full[:, 0].contiguous(), full[:, 1].contiguous()
+
+
+def speaker_shard(labels, world, rank):
+    """Row mask of the speakers owned by `rank` (speaker id modulo world): a partition BY SPEAKER, so
+    that every centroid is rank-local ("fit statistics")."""
+    labels = torch.as_tensor(labels)
+    return (labels.to(torch.int64) % int(world)) == int(rank)
+
+
+def fit_sharded(stats_block, em_block, X_local, labels_local, iters=10, group=None):
+    """PLDA fit with the statistics pass sharded by speaker.
+
+    Every rank holds the rows of a disjoint set of speakers (`speaker_shard`).  Per rank:
+    `stats_block(X_local, dense_labels, K_local) -> (means[K_local, D], counts[K_local] int64,
+    scatter[D, D])` is the AddSamples pass (pldamodule.cpp:94-98) over its speakers.  Everything
+    AddSamples accumulates is additive over speakers, so the one exchange is an all-reduce of the
+    D x D offset scatter plus an all-gather of the centroids and counts (K*D*8 bytes: 8 MB at C2,
+    41 MB at C3); the EM (pldamodule.cpp:102-106) is D x D work and runs as a replica on every rank
+    from identical inputs: `em_block(means[K, D], counts[K], scatter, iters)`.
+    Returns the global number of speakers.  A rank may own no speaker at all (K_local = 0).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dev = X_local.device
+    d = X_local.shape[1]
+    labels_local = torch.as_tensor(labels_local)
+    if labels_local.numel():
+        _, dense = torch.unique(labels_local.to(torch.int64), sorted=True, return_inverse=True)
+        k_local = int(dense.max().item()) + 1
+        means, counts, scatter = stats_block(X_local, dense.to(dev), k_local)
+    else:
+        k_local = 0
+        means = torch.zeros((0, d), dtype=torch.float64, device=dev)
+        counts = torch.zeros((0,), dtype=torch.int64, device=dev)
+        scatter = torch.zeros((d, d), dtype=torch.float64, device=dev)
+    if world > 1:
+        ks = torch.tensor([k_local], dtype=torch.int64, device=dev)
+        all_k = [torch.empty_like(ks) for _ in range(world)]
+        dist.all_gather(all_k, ks, group=group)
+        all_k = [int(t.item()) for t in all_k]
+        k_pad = max(max(all_k), 1)
+        send_m = torch.zeros((k_pad, d), dtype=torch.float64, device=dev)
+        send_c = torch.zeros((k_pad,), dtype=torch.int64, device=dev)
+        send_m[:k_local] = means
+        send_c[:k_local] = counts
+        parts_m = [torch.empty_like(send_m) for _ in range(world)]
+        parts_c = [torch.empty_like(send_c) for _ in range(world)]
+        dist.all_gather(parts_m, send_m, group=group)
+        dist.all_gather(parts_c, send_c, group=group)
+        scatter = scatter.contiguous()
+        dist.all_reduce(scatter, op=dist.ReduceOp.SUM, group=group)
+        means = torch.cat([p[:k] for p, k in zip(parts_m, all_k)], dim=0).contiguous()
+        counts = torch.cat([p[:k] for p, k in zip(parts_c, all_k)], dim=0).contiguous()
+    k_global = int(means.shape[0])
+    em_block(means, counts, scatter, int(iters))
+    return k_global
+
+
+def gpu_fit_blocks(engine):
+    """(stats_block, em_block) over MPlda.fit_stats_dev / fit_em_dev for HBM-resident tensors."""
+    def stats_block(X, dense, k):
+        X = X.contiguous()
+        lab = dense.to(torch.int64).contiguous()     # non-negative: same bits as the u64 the ABI reads
+        n, d = X.shape
+        means = torch.empty((k, d), dtype=torch.float64, device=X.device)
+        counts = torch.empty((k,), dtype=torch.int64, device=X.device)
+        scatter = torch.empty((d, d), dtype=torch.float64, device=X.device)
+        engine.fit_stats_dev(X.data_ptr(), n, d, lab.data_ptr(), k)
+        engine.fit_get_stats_dev(means.data_ptr(), counts.data_ptr(), scatter.data_ptr())
+        return means, counts, scatter
+
+    def em_block(means, counts, scatter, iters):
+        engine.fit_em_dev(means.data_ptr(), counts.data_ptr(), means.shape[0], scatter.data_ptr(),
+                          means.shape[1], iters)
+    return stats_block, em_block
 
 
 def gpu_znorm_block(engine, dbkg, nb, din):

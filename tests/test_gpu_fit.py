@@ -214,3 +214,55 @@ def test_maximum_feature_dim_is_reported():
     x = np.random.default_rng(0).random((40, 1025))
     with pytest.raises(RuntimeError, match="1024"):
         PLDA().fit(x, (np.arange(40) % 4).astype(np.uint64), 1)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_fit_sharded_by_speaker_matches_single_fit(oracle, world):
+    """SURVEY.md section 8e "fit statistics": per-shard plda_fit_stats_dev, summed scatter + concatenated centroids,
+    then plda_fit_em_dev must equal the one-call fit.  The shards run one after another on this
+    GPU through plda_amd.sharding.fit_sharded's own blocks (the collective step is emulated by
+    the sum/concat it performs; the gloo world-2 test covers the real exchange)."""
+    import torch
+    from plda_amd import MPlda
+    from plda_amd.sharding import gpu_fit_blocks, speaker_shard
+    x, y = make_data(31, 2600, 48, 37, skew=True, scale_between=0.4)
+    dev = torch.device("cuda:0")
+    dx = torch.from_numpy(x).to(dev)
+    ty = torch.from_numpy(y.astype(np.int64))
+    eng = MPlda(0)
+    stats_block, em_block = gpu_fit_blocks(eng)
+    means, counts, scatter = [], [], torch.zeros((48, 48), dtype=torch.float64, device=dev)
+    for r in range(world):
+        mask = speaker_shard(ty, world, r)
+        _, dense = torch.unique(ty[mask], sorted=True, return_inverse=True)
+        m, c, s = stats_block(dx[mask.to(dev)], dense.to(dev), int(dense.max()) + 1)
+        means.append(m); counts.append(c); scatter += s
+    means, counts = torch.cat(means).contiguous(), torch.cat(counts).contiguous()
+    assert means.shape[0] == 37 and int(counts.sum()) == 2600
+    em_block(means, counts, scatter, 6)
+    torch.cuda.synchronize()
+    got = eng.get_model()
+    one = MPlda(0)
+    one.fit(x, y, 6)
+    ref = one.get_model()
+    assert np.abs(got["psi"] - ref["psi"]).max() <= 1e-9 * ref["psi"].max()
+    assert _rel(got["transform"].T @ got["transform"], ref["transform"].T @ ref["transform"]) < 1e-9
+    assert _rel(got["mean"], ref["mean"]) < 1e-13
+    orc = oracle.fit(x, y, 6)
+    assert np.abs(got["psi"] - orc["psi"]).max() <= 1e-8 * orc["psi"].max()
+
+
+def test_fit_em_dev_rejects_bad_statistics():
+    import torch
+    from plda_amd import MPlda
+    from plda_amd._native import PldaError
+    dev = torch.device("cuda:0")
+    eng = MPlda(0)
+    means = torch.zeros((3, 4), dtype=torch.float64, device=dev)
+    scatter = torch.eye(4, dtype=torch.float64, device=dev)
+    bad = torch.tensor([2, 0, 1], dtype=torch.int64, device=dev)
+    with pytest.raises(PldaError):
+        eng.fit_em_dev(means.data_ptr(), bad.data_ptr(), 3, scatter.data_ptr(), 4, 2)
+    one = torch.tensor([5], dtype=torch.int64, device=dev)
+    with pytest.raises(ValueError, match="Number of speakers is 1"):
+        eng.fit_em_dev(means.data_ptr(), one.data_ptr(), 1, scatter.data_ptr(), 4, 2)

@@ -98,6 +98,61 @@ def _znorm_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _fit_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import plda_oracle_np as onp
+    from conftest import make_data
+    from plda_amd.sharding import fit_sharded, speaker_shard
+    x, y = make_data(71, 300, 8, 13, scale_between=0.7)      # 13 speakers, unequal counts, uneven split
+    mask = speaker_shard(torch.from_numpy(y.astype(np.int64)), world, rank).numpy()
+    got = {}
+
+    def stats_block(X, dense, k):
+        st = onp.stats(X.numpy(), dense.numpy())
+        assert st["means"].shape[0] == k
+        return (torch.from_numpy(st["means"]), torch.from_numpy(st["counts"].astype(np.int64)),
+                torch.from_numpy(st["scatter"]))
+
+    def em_block(means, counts, scatter, iters):
+        means, counts = means.numpy(), counts.numpy()
+        w = 1.0 / counts
+        st = dict(means=means, counts=counts, scatter=scatter.numpy(), sum=(means * w[:, None]).sum(0),
+                  class_weight=w.sum(), example_weight=float(len(counts)))
+        d = means.shape[1]
+        W, B = np.eye(d), np.eye(d)
+        for _ in range(iters):
+            W, B = onp.em_iter(st, W, B)
+        got.update(onp.get_output(st, W, B))
+
+    k = fit_sharded(stats_block, em_block, torch.from_numpy(x[mask]), torch.from_numpy(y[mask].astype(np.int64)), iters=4)
+    ref = onp.fit(x, y, 4)
+    T, R = got["transform"], ref["transform"]
+    ok = (k == 13 and np.allclose(got["psi"], ref["psi"], rtol=1e-10, atol=1e-12)
+          and np.allclose(T.T @ T, R.T @ R, rtol=1e-9, atol=1e-11) and np.allclose(got["mean"], ref["mean"], atol=1e-13))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_fit_gloo_world2(oracle):
+    """fit statistics sharded by speaker: all-reduce of the scatter + all-gather of the centroids, then the
+    replica EM, must reproduce the single-process fit on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
 def test_sharded_znorm_gloo_world2(oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
