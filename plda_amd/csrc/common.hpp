@@ -62,6 +62,8 @@ struct plda_handle {
   bool simdiag_has_vr = false;
 
   int gemm_variant = 0;
+  int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
+  int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
   bool bt_attr_set = false;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
 
   // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
@@ -104,13 +106,16 @@ int model_to_device(plda_handle *h);
 // A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; exactly one of (sam,sak)
 // and one of (sbk,sbn) must be 1.  kw nullable.  Uses split-K with a
 // deterministic second-stage reduction when K is long and M*N small.
+int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
+                     int64_t sak, int64_t strideA, const double *B, int64_t sbk, int64_t sbn, int64_t strideB,
+                     const double *kw, double beta, double *C, int64_t ldc, int64_t strideC, int batch);
 int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
              int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,
              const double *kw, double beta, double *C, int64_t ldc);
 // in-place lower Cholesky (upper triangle zeroed); *dflag (device int) set to 1 on failure
-int cholesky_f64(plda_handle *h, double *A, int D, int *dflag);
+int cholesky_f64(plda_handle *h, double *A, int D, int *dflag, int batch = 1);
 // X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
-int tri_invert_f64(plda_handle *h, const double *L, double *X, int D);
+int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch = 1);
 // symmetric eigendecomposition of G (row-major, destroyed): eigenvalues sorted
 // descending in s[D] (floored at 0), eigenvectors in the ROWS of Vrows.
 int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,

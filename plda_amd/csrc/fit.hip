@@ -10,6 +10,7 @@
 //            GetOutput                 -> K6/K7 Cholesky + triangular inverse + Jacobi eig
 #include "common.hpp"
 
+#include <algorithm>
 #include <chrono>
 
 namespace plda {
@@ -261,6 +262,52 @@ __global__ void em_mstep_kernel(const double *__restrict__ S, const double *__re
   B[a] = 0.5 * (Bu[a] + Bu[b]) / cntB;
 }
 
+// ---- grouped closed-form EM (see fit_em_device) ----
+__global__ void gather_center_kernel(const double *__restrict__ means, const double *__restrict__ mu,
+                                     const int *__restrict__ cls, int64_t K, int D, double *__restrict__ out) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= K * D) return;
+  const int64_t r = idx / D;
+  const int d = (int)(idx % D);
+  out[idx] = means[(int64_t)cls[r] * D + d] - mu[d];
+}
+
+// A_g = W + n_g B
+__global__ void em_group_A_kernel(const double *__restrict__ W, const double *__restrict__ B,
+                                  const double *__restrict__ gn, int64_t DD, double *__restrict__ A) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= DD) return;
+  A[(int64_t)blockIdx.y * DD + idx] = fma(gn[blockIdx.y], B[idx], W[idx]);
+}
+
+// M-step from the per-group matrices (i <= j computes both (i,j) and (j,i), then symmetrises):
+//   W_stats = S + sum_g [ K_g Mx_g + C_g - n_g (QC_g + QC_g^T) + n_g^2 QCQ_g ]
+//   B_stats =     sum_g [ (K_g / n_g) Mx_g + n_g QCQ_g ]
+__global__ void em_group_mstep_kernel(const double *__restrict__ S, const double *__restrict__ Csum,
+                                      const double *__restrict__ Mx, const double *__restrict__ QC,
+                                      const double *__restrict__ QCQ, const double *__restrict__ gn,
+                                      const double *__restrict__ gk, int G, int D, double cntW, double cntB,
+                                      double *__restrict__ W, double *__restrict__ B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * D) return;
+  const int i = idx / D, j = idx % D;
+  if (i > j) return;
+  const size_t ij = (size_t)i * D + j, ji = (size_t)j * D + i, DD = (size_t)D * D;
+  double wij = S[ij] + Csum[ij], wji = S[ji] + Csum[ji], bij = 0.0, bji = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const double n = gn[g], k = gk[g];
+    const double *mx = Mx + g * DD, *qc = QC + g * DD, *qcq = QCQ + g * DD;
+    const double cross = n * (qc[ij] + qc[ji]);
+    wij += k * mx[ij] - cross + n * n * qcq[ij];
+    wji += k * mx[ji] - cross + n * n * qcq[ji];
+    bij += (k / n) * mx[ij] + n * qcq[ij];
+    bji += (k / n) * mx[ji] + n * qcq[ji];
+  }
+  const double w = 0.5 * (wij / cntW + wji / cntW), b = 0.5 * (bij / cntB + bji / cntB);
+  W[ij] = w; W[ji] = w;
+  B[ij] = b; B[ji] = b;
+}
+
 __global__ void set_identity2_kernel(double *W, double *B, int D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < D * D) { const double v = (idx / D == idx % D) ? 1.0 : 0.0; W[idx] = v; B[idx] = v; }
@@ -447,18 +494,83 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   const double example_weight = (double)K;  // sum_k w_k n_k with w_k = 1/n_k
 
   // ---------------- EM (K3) ----------------
+  // Group the classes by their count n.  Inside one group every class shares
+  //   A = W + nB,  mixed = (B^-1 + n W^-1)^-1 = W A^-1 B,  w_k = mixed n W^-1 m_k = n Q m_k,  Q = B A^-1,
+  // so the sums over the classes of the group collapse onto C_g = sum_k m_k m_k^T, which never changes:
+  //   sum_k w_k w_k^T = n^2 Q C_g Q^T,   sum_k (m_k - w_k)(m_k - w_k)^T = C_g - n(Q C_g + (Q C_g)^T) + n^2 Q C_g Q^T.
+  // One iteration is then D x D work only -- per group one Cholesky, one triangular inverse and five
+  // GEMMs, all batched over the groups -- with no inverse of W or B (B may be singular) and no
+  // eigendecomposition.  Same estimator as SURVEY.md A.2, different association of the sums.
+  std::vector<int64_t> hcounts((size_t)K);
+  PLDA_HIP(h, hipMemcpyAsync(hcounts.data(), h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  std::vector<int> cls((size_t)K);
+  for (int64_t k = 0; k < K; ++k) cls[k] = (int)k;
+  std::stable_sort(cls.begin(), cls.end(), [&](int a, int b) { return hcounts[a] < hcounts[b]; });
+  std::vector<int64_t> goff;   // group g = sorted positions goff[g] .. goff[g+1]
+  std::vector<double> gn, gk;
+  for (int64_t r = 0; r < K; ++r)
+    if (r == 0 || hcounts[cls[r]] != hcounts[cls[r - 1]]) { goff.push_back(r); gn.push_back((double)hcounts[cls[r]]); }
+  goff.push_back(K);
+  const int G = (int)gn.size();
+  for (int g = 0; g < G; ++g) gk.push_back((double)(goff[g + 1] - goff[g]));
+  const double cntW = (example_weight - class_weight) + class_weight;  // = K
+  const double cntB = class_weight;
+  const unsigned gDD = (unsigned)ceil_div((int64_t)DD, 256);
+  const unsigned gKD = (unsigned)ceil_div(K * (int64_t)D, 256);
+  set_identity2_kernel<<<gDD, 256, 0, h->stream>>>(W, B, D);
+  PLDA_LAUNCH_CHECK(h);
+  const size_t group_bytes = (size_t)G * DD * 8 * 5;
+  const bool grouped = h->em_variant != 1 && group_bytes <= ((size_t)24 << 30) && G <= 16384;
+  h->em_groups = grouped ? G : 0;
+  if (grouped) {
+    PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 + (size_t)K * 4 + 64));
+    PLDA_HIP(h, h->w[6].reserve(group_bytes + DD * 8 + (size_t)G * 16 + 64));
+    double *Mg = h->w[5].as<double>();
+    int *dcls = reinterpret_cast<int *>(Mg + (size_t)K * D);
+    double *Cg = h->w[6].as<double>(), *b0 = Cg + (size_t)G * DD, *b1 = b0 + (size_t)G * DD,
+           *b2 = b1 + (size_t)G * DD, *b3 = b2 + (size_t)G * DD, *Csum = b3 + (size_t)G * DD, *dgn = Csum + DD,
+           *dgk = dgn + G;
+    int *dflag = reinterpret_cast<int *>(dgk + G);
+    PLDA_HIP(h, hipMemcpyAsync(dcls, cls.data(), (size_t)K * 4, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dgn, gn.data(), (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dgk, gk.data(), (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemsetAsync(dflag, 0, 4, h->stream));
+    gather_center_kernel<<<gKD, 256, 0, h->stream>>>(means, mu, dcls, K, D, Mg);
+    PLDA_LAUNCH_CHECK(h);
+    for (int g = 0; g < G; ++g) {
+      const double *rows = Mg + (size_t)goff[g] * D;
+      PLDA_TRY(gemm_f64(h, D, D, goff[g + 1] - goff[g], 1.0, rows, 1, D, rows, D, 1, nullptr, 0.0, Cg + (size_t)g * DD, D));
+    }
+    if (G == 1) PLDA_HIP(h, hipMemcpyAsync(Csum, Cg, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+    else PLDA_TRY(gemm_f64(h, D, D, K, 1.0, Mg, 1, D, Mg, D, 1, nullptr, 0.0, Csum, D));
+    const int64_t sDD = (int64_t)DD;
+    for (int it = 0; it < iters; ++it) {
+      em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0);
+      PLDA_LAUNCH_CHECK(h);
+      PLDA_TRY(cholesky_f64(h, b0, D, dflag, G));                                   // b0 = L
+      PLDA_TRY(tri_invert_f64(h, b0, b1, D, G));                                    // b1 = L^-1
+      // b2 = A^-1 = L^-T L^-1 ; b0 = Q = B A^-1 ; b1 = Mx = W Q^T ; b2 = QC = Q C_g ; b3 = QCQ = QC Q^T
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b1, 1, D, sDD, b1, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, B, D, 1, 0, b2, D, 1, sDD, nullptr, 0.0, b0, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, W, D, 1, 0, b0, 1, D, sDD, nullptr, 0.0, b1, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b0, D, 1, sDD, Cg, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b2, D, 1, sDD, b0, 1, D, sDD, nullptr, 0.0, b3, D, sDD, G));
+      em_group_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, b1, b2, b3, dgn, dgk, G, D, cntW, cntB, W, B);
+      PLDA_LAUNCH_CHECK(h);
+    }
+    int hflag = 0;
+    PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, 4, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (hflag) return fail(h, PLDA_E_NUMERIC, "fit: W + nB is not positive definite");
+  } else {
   PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3));   // Mc / P, Y1, Y2
   PLDA_HIP(h, h->w[6].reserve(DD * 8 * 7 + (size_t)D * 8));
   double *Mc = h->w[5].as<double>(), *Y1 = Mc + (size_t)K * D, *Y2 = Y1 + (size_t)K * D;
   double *T = h->w[6].as<double>(), *Tinv = T + DD, *Bt = Tinv + DD, *Wt = Bt + DD, *tmp = Wt + DD,
          *Bu = tmp + DD, *Wu = Bu + DD, *psi = Wu + DD;
-  const unsigned gDD = (unsigned)ceil_div((int64_t)DD, 256);
-  const unsigned gKD = (unsigned)ceil_div(K * (int64_t)D, 256);
-  set_identity2_kernel<<<gDD, 256, 0, h->stream>>>(W, B, D);
   center_kernel<<<gKD, 256, 0, h->stream>>>(means, mu, K, D, Mc);
   PLDA_LAUNCH_CHECK(h);
-  const double cntW = (example_weight - class_weight) + class_weight;  // = K
-  const double cntB = class_weight;
   for (int it = 0; it < iters; ++it) {
     PLDA_TRY(simdiag_f64(h, W, B, D, T, Tinv, psi, it > 0));
     // P = Mc T^T  (reuse Y1 as P, then scale into Y1/Y2)
@@ -476,6 +588,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, Tinv, 1, D, nullptr, 0.0, Wu, D));
     em_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Wu, Bu, D, cntW, cntB, W, B);
     PLDA_LAUNCH_CHECK(h);
+  }
   }
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t2 = now_ms();

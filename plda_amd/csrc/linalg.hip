@@ -71,14 +71,20 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
                                                        const double *__restrict__ B, int64_t sbk,
                                                        int64_t sbn, const double *__restrict__ kw,
                                                        double beta, double *__restrict__ C, int64_t ldc,
-                                                       double *__restrict__ part) {
+                                                       double *__restrict__ part, int splits, int64_t strideA,
+                                                       int64_t strideB, int64_t strideC) {
+  // blockIdx.z = batch * splits + split; batched calls run with splits == 1
+  const int zb = (int)blockIdx.z / splits, zs = (int)blockIdx.z % splits;
+  A += (int64_t)zb * strideA;
+  B += (int64_t)zb * strideB;
+  C += (int64_t)zb * strideC;
   __shared__ double As[2][GK * LDM];
   __shared__ double Bs[2][GK * LDM];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * GB, n0 = (int64_t)blockIdx.x * GB;
-  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kbeg = (int64_t)zs * kchunk;
   const int64_t kend = min(K, kbeg + kchunk);
 
   f64x4 acc[2][2];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
         const int64_t col = n0 + wn * 32 + tn * 16 + (lane & 15);
         if (row < M && col < N) {
           if (part) {
-            part[((int64_t)blockIdx.z * M + row) * N + col] = acc[tm][tn][r];
+            part[((int64_t)zs * M + row) * N + col] = acc[tm][tn][r];
           } else {
             double *c = C + row * ldc + col;
             *c = alpha * acc[tm][tn][r] + (beta != 0.0 ? beta * *c : 0.0);
@@ -152,17 +158,19 @@ __global__ void splitk_reduce_kernel(const double *__restrict__ part, int splits
   *c = alpha * s + (beta != 0.0 ? beta * *c : 0.0);
 }
 
-int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
-             int64_t sak, const double *B, int64_t sbk, int64_t sbn, const double *kw, double beta,
-             double *C, int64_t ldc) {
-  if (M <= 0 || N <= 0) return PLDA_OK;
+// batch > 1: `batch` independent products with operand strides (a stride of 0 shares the operand);
+// no split-K in that case -- the batch supplies the parallelism.
+int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
+                     int64_t sak, int64_t strideA, const double *B, int64_t sbk, int64_t sbn, int64_t strideB,
+                     const double *kw, double beta, double *C, int64_t ldc, int64_t strideC, int batch) {
+  if (M <= 0 || N <= 0 || batch <= 0) return PLDA_OK;
   if (K <= 0) return fail(h, PLDA_E_INVAL, "gemm_f64: K <= 0");
   const bool akc = (sak == 1), bkc = (sbk == 1);
   if ((!akc && sam != 1) || (!bkc && sbn != 1))
     return fail(h, PLDA_E_INVAL, "gemm_f64: operands need one unit stride");
   const int64_t tiles = ceil_div(M, GB) * ceil_div(N, GB);
   int splits = 1;
-  if (tiles < 512 && K >= 1024) {
+  if (batch == 1 && tiles < 512 && K >= 1024) {
     splits = (int)std::min<int64_t>(ceil_div(K, 256), std::max<int64_t>(1, 1024 / tiles));
   }
   int64_t kchunk = round_up(ceil_div(K, splits), GK);
@@ -172,10 +180,12 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * M * N * 8));
     part = h->w[15].as<double>();
   }
-  const dim3 grid((unsigned)ceil_div(N, GB), (unsigned)ceil_div(M, GB), (unsigned)splits);
+  if ((int64_t)splits * batch > 65535) return fail(h, PLDA_E_INVAL, "gemm_f64: batch %d too large", batch);
+  const dim3 grid((unsigned)ceil_div(N, GB), (unsigned)ceil_div(M, GB), (unsigned)(splits * batch));
 #define GEMM_LAUNCH(AK, BK)                                                                          \
   gemm_f64_kernel<AK, BK><<<grid, 256, 0, h->stream>>>(M, N, K, kchunk, alpha, A, sam, sak, B, sbk, \
-                                                       sbn, kw, beta, C, ldc, part)
+                                                       sbn, kw, beta, C, ldc, part, splits, strideA, \
+                                                       strideB, strideC)
   if (akc && bkc) GEMM_LAUNCH(true, true);
   else if (akc && !bkc) GEMM_LAUNCH(true, false);
   else if (!akc && bkc) GEMM_LAUNCH(false, true);
@@ -190,6 +200,12 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
   return PLDA_OK;
 }
 
+int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
+             int64_t sak, const double *B, int64_t sbk, int64_t sbn, const double *kw, double beta,
+             double *C, int64_t ldc) {
+  return gemm_f64_batched(h, M, N, K, alpha, A, sam, sak, 0, B, sbk, sbn, 0, kw, beta, C, ldc, 0, 1);
+}
+
 // ------------------------------------------------------------------------------------
 // Cholesky (TpMatrix::Cholesky) -- one workgroup of 1024 threads
 // ------------------------------------------------------------------------------------
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double *__restrict__ A, 
   extern __shared__ __attribute__((aligned(16))) double col[];  // [D]
   __shared__ double sdiag;
   const int t = threadIdx.x, nt = blockDim.x;
+  A += (size_t)blockIdx.x * D * D;   // one matrix per workgroup
   for (int j = 0; j < D; ++j) {
     if (t == 0) {
       double d = A[(size_t)j * D + j];
@@ -230,8 +247,8 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double *__restrict__ A, 
   }
 }
 
-int cholesky_f64(plda_handle *h, double *A, int D, int *dflag) {
-  cholesky_kernel<<<1, 1024, (size_t)D * 8, h->stream>>>(A, D, dflag);
+int cholesky_f64(plda_handle *h, double *A, int D, int *dflag, int batch) {
+  cholesky_kernel<<<batch, 1024, (size_t)D * 8, h->stream>>>(A, D, dflag);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
 }
@@ -246,6 +263,8 @@ template <int E>
 __global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D) {
   const int j = blockIdx.x;
   const int lane = threadIdx.x;
+  L += (size_t)blockIdx.y * D * D;
+  X += (size_t)blockIdx.y * D * D;
   double x[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = 0.0;
@@ -270,9 +289,9 @@ __global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict
   }
 }
 
-int tri_invert_f64(plda_handle *h, const double *L, double *X, int D) {
+int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch) {
   const int E = (int)ceil_div(D, 64);
-#define TI(EE) tri_invert_kernel<EE><<<D, 64, 0, h->stream>>>(L, X, D)
+#define TI(EE) tri_invert_kernel<EE><<<dim3(D, batch), 64, 0, h->stream>>>(L, X, D)
   if (E <= 1) TI(1);
   else if (E <= 2) TI(2);
   else if (E <= 4) TI(4);
