@@ -61,6 +61,7 @@ struct plda_handle {
   int simdiag_D = 0;
   bool simdiag_has_vr = false;
 
+  bool panel_attr_set[4] = {false, false, false, false};
   int gemm_variant = 0;
   int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
@@ -115,6 +116,8 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
 // in-place lower Cholesky (upper triangle zeroed); *dflag (device int) set to 1 on failure
 int cholesky_f64(plda_handle *h, double *A, int D, int *dflag, int batch = 1);
 // X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
+int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
+                    int *dflag, int batch);
 int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch = 1);
 // symmetric eigendecomposition of G (row-major, destroyed): eigenvalues sorted
 // descending in s[D] (floored at 0), eigenvectors in the ROWS of Vrows.

@@ -546,12 +546,16 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     else PLDA_TRY(gemm_f64(h, D, D, K, 1.0, Mg, 1, D, Mg, D, 1, nullptr, 0.0, Csum, D));
     const int64_t sDD = (int64_t)DD;
     for (int it = 0; it < iters; ++it) {
-      em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0);
-      PLDA_LAUNCH_CHECK(h);
-      PLDA_TRY(cholesky_f64(h, b0, D, dflag, G));                                   // b0 = L
-      PLDA_TRY(tri_invert_f64(h, b0, b1, D, G));                                    // b1 = L^-1
-      // b2 = A^-1 = L^-T L^-1 ; b0 = Q = B A^-1 ; b1 = Mx = W Q^T ; b2 = QC = Q C_g ; b3 = QCQ = QC Q^T
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b1, 1, D, sDD, b1, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));
+      // b2 = A^-1 ; b0 = Q = B A^-1 ; b1 = Mx = W Q^T ; b2 = QC = Q C_g ; b3 = QCQ = QC Q^T
+      if (D <= 256) {
+        PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, b2, dflag, G));                     // registers, one CU per group
+      } else {
+        em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0);
+        PLDA_LAUNCH_CHECK(h);
+        PLDA_TRY(cholesky_f64(h, b0, D, dflag, G));                                   // b0 = L
+        PLDA_TRY(tri_invert_f64(h, b0, b1, D, G));                                    // b1 = L^-1
+        PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b1, 1, D, sDD, b1, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));
+      }
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, B, D, 1, 0, b2, D, 1, sDD, nullptr, 0.0, b0, D, sDD, G));
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, W, D, 1, 0, b0, 1, D, sDD, nullptr, 0.0, b1, D, sDD, G));
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b0, D, 1, sDD, Cg, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));

@@ -158,6 +158,69 @@ __global__ void splitk_reduce_kernel(const double *__restrict__ part, int splits
   *c = alpha * s + (beta != 0.0 ? beta * *c : 0.0);
 }
 
+// Small products (the D x D x D GEMMs of the EM, K <= 256): the 64 x 64 kernel above would put 16
+// workgroups on the chip and walk K in 13 dependent load -> LDS -> MFMA rounds.  Here a workgroup owns a
+// 32 x 32 tile, pulls the WHOLE K extent of both operand panels into LDS with every load in flight at
+// once (one memory latency), then runs the MFMAs back to back.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f64_panel_kernel(int M, int N, int K, double alpha,
+                                                             const double *__restrict__ A, int64_t sam, int64_t sak,
+                                                             const double *__restrict__ B, int64_t sbk, int64_t sbn,
+                                                             double beta, double *__restrict__ C, int64_t ldc,
+                                                             int64_t strideA, int64_t strideB, int64_t strideC) {
+  extern __shared__ __attribute__((aligned(16))) double panel[];   // As[32][ld], Bs[32][ld]
+  const int Kp = (K + 3) & ~3, ld = Kp + 1;
+  double *As = panel, *Bs = panel + 32 * ld;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  A += (int64_t)blockIdx.z * strideA;
+  B += (int64_t)blockIdx.z * strideB;
+  C += (int64_t)blockIdx.z * strideC;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int total = 32 * Kp;
+  // batches of 8 + 8 independent loads per thread are issued before any of them is consumed
+  for (int base = 0; base < total; base += 8 * 256) {
+    double ra[8], rb[8];
+    int la[8], lb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + t;
+      int m, k;
+      if (AKC) { m = idx / Kp; k = idx - m * Kp; } else { k = idx >> 5; m = idx & 31; }
+      const int gm = m0 + m;
+      la[u] = idx < total ? m * ld + k : -1;
+      ra[u] = (idx < total && gm < M && k < K) ? A[gm * sam + k * sak] : 0.0;
+      int n, kb;
+      if (BKC) { n = idx / Kp; kb = idx - n * Kp; } else { kb = idx >> 5; n = idx & 31; }
+      const int gn = n0 + n;
+      lb[u] = idx < total ? n * ld + kb : -1;
+      rb[u] = (idx < total && gn < N && kb < K) ? B[gn * sbn + kb * sbk] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (la[u] >= 0) As[la[u]] = ra[u];
+      if (lb[u] >= 0) Bs[lb[u]] = rb[u];
+    }
+  }
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1, fi = lane & 15, fk = lane >> 4;
+  const double *ap = As + (wm * 16 + fi) * ld + fk, *bp = Bs + (wn * 16 + fi) * ld + fk;
+  f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  int kk = 0;
+  for (; kk + 8 <= Kp; kk += 8) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk + 4], bp[kk + 4], acc1, 0, 0, 0);
+  }
+  if (kk < Kp) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc0, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + wm * 16 + fk + 4 * r, col = n0 + wn * 16 + fi;
+    if (row < M && col < N) {
+      double *c = C + (int64_t)row * ldc + col;
+      *c = alpha * (acc0[r] + acc1[r]) + (beta != 0.0 ? beta * *c : 0.0);
+    }
+  }
+}
+
 // batch > 1: `batch` independent products with operand strides (a stride of 0 shares the operand);
 // no split-K in that case -- the batch supplies the parallelism.
 int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
@@ -169,6 +232,30 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
   if ((!akc && sam != 1) || (!bkc && sbn != 1))
     return fail(h, PLDA_E_INVAL, "gemm_f64: operands need one unit stride");
   const int64_t tiles = ceil_div(M, GB) * ceil_div(N, GB);
+  if (K <= 256 && M <= 1024 && N <= 1024 && !kw) {
+    const size_t lds = (size_t)2 * 32 * (((K + 3) & ~3) + 1) * 8;
+    const dim3 pgrid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), (unsigned)batch);
+    if (batch > 65535) return fail(h, PLDA_E_INVAL, "gemm_f64: batch %d too large", batch);
+#define PANEL_LAUNCH(AK, BK)                                                                                  \
+  do {                                                                                                        \
+    bool &attr_done = h->panel_attr_set[(AK ? 2 : 0) + (BK ? 1 : 0)];                                         \
+    if (!attr_done) {                                                                                         \
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f64_panel_kernel<AK, BK>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 257 * 8));          \
+      attr_done = true;                                                                                       \
+    }                                                                                                         \
+    gemm_f64_panel_kernel<AK, BK><<<pgrid, 256, lds, h->stream>>>((int)M, (int)N, (int)K, alpha, A, sam, sak, \
+                                                                  B, sbk, sbn, beta, C, ldc, strideA, strideB, \
+                                                                  strideC);                                   \
+  } while (0)
+    if (akc && bkc) PANEL_LAUNCH(true, true);
+    else if (akc && !bkc) PANEL_LAUNCH(true, false);
+    else if (!akc && bkc) PANEL_LAUNCH(false, true);
+    else PANEL_LAUNCH(false, false);
+#undef PANEL_LAUNCH
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
   int splits = 1;
   if (batch == 1 && tiles < 512 && K >= 1024) {
     splits = (int)std::min<int64_t>(ceil_div(K, 256), std::max<int64_t>(1, 1024 / tiles));
@@ -303,18 +390,6 @@ int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch)
   return PLDA_OK;
 }
 
-// ------------------------------------------------------------------------------------
-// symmetric eigensolver: one-sided (Hestenes) block Jacobi on the rows of A (= G), V = I.
-// After convergence A = V G has mutually orthogonal rows, so the rows of V are the
-// eigenvectors of G and lambda_p = a_p . v_p.
-// ------------------------------------------------------------------------------------
-// Block form of the one-sided Jacobi round: rows are grouped in blocks of JB = 4; a launch
-// is one OUTER tournament round over the blocks; each workgroup takes one block pair,
-// stages its 8 rows of A and of V in LDS and runs the full INNER tournament on them
-// (7 rounds x 4 disjoint pairs, one wave per pair, __syncthreads between rounds), so 28
-// rotations are applied per round trip to L2 instead of one.
-constexpr int JB = 4;
-
 // fp64 reciprocal / reciprocal square root: hardware estimate refined by Newton steps to full
 // double precision (the inputs here are well inside the normal range)
 __device__ __forceinline__ double rcp_nr(double x) {
@@ -329,6 +404,132 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   y = y * fma(-0.5 * x * y, y, 1.5);
   return y;
 }
+
+// ------------------------------------------------------------------------------------
+// SPD inverse by symmetric sweeps, matrix resident in registers (D <= 256), one matrix per workgroup.
+// Computes (W + n_g B)^-1 for the grouped EM.  Sweep k of the (Goodnight) sweep operator:
+//   d = A_kk;  A_ij -= A_ik A_kj / d (i, j != k);  A_ik = A_ki = A_ik / d;  A_kk = -1/d;
+// after all D sweeps the matrix holds -A^-1.  For an SPD matrix every pivot is positive and no
+// pivoting is needed.  The 1024 threads form a 32 x 32 grid; thread (ty, tx) owns the lower-triangle
+// elements (i, j) = (32a + ty, 32b + tx), a >= b, so a sweep is NB(NB+1)/2 FMAs per thread on
+// registers plus one LDS broadcast of column k (double-buffered: one barrier per sweep).
+// ------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(1024) void spd_inverse_sweep_kernel(const double *__restrict__ W,
+                                                                 const double *__restrict__ B,
+                                                                 const double *__restrict__ gn, int D,
+                                                                 double *__restrict__ out, int *flag) {
+  constexpr int NE = NB * (NB + 1) / 2;
+  __shared__ double v[2][NB * 32];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const double n = gn ? gn[blockIdx.x] : 0.0;
+  out += (size_t)blockIdx.x * D * D;
+  double r[NE];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 32 + ty, j = b * 32 + tx;
+      double x = 0.0;
+      if (i < D && j <= i) {
+        x = W[(size_t)i * D + j];
+        if (B) x = fma(n, B[(size_t)i * D + j], x);
+      }
+      r[a * (a + 1) / 2 + b] = x;
+    }
+  bool bad = false;
+  // the block index kb of the pivot is a compile-time constant inside the unrolled outer loop, so the
+  // owners of column / row k are named registers: r[e(a, kb)], a >= kb, and r[e(kb, b)], b <= kb
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    for (int kl = 0; kl < 32; ++kl) {
+      const int k = kb * 32 + kl;
+      if (k >= D) break;
+      double *vv = v[k & 1];
+      if (tx == kl) {   // column k, rows >= k
+#pragma unroll
+        for (int a = kb; a < NB; ++a)
+          if (a > kb || ty >= kl) vv[a * 32 + ty] = r[a * (a + 1) / 2 + kb];
+      }
+      if (ty == kl) {   // row k, columns < k
+#pragma unroll
+        for (int b = 0; b <= kb; ++b)
+          if (b < kb || tx < kl) vv[b * 32 + tx] = r[kb * (kb + 1) / 2 + b];
+      }
+      __syncthreads();
+      const double d = vv[k];
+      if (!(d > 0.0)) bad = true;
+      const double inv = rcp_nr(d);
+      double ui[NB], vj[NB];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) ui[a] = -vv[a * 32 + ty] * inv;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) vj[b] = vv[b * 32 + tx];
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) r[a * (a + 1) / 2 + b] = fma(ui[a], vj[b], r[a * (a + 1) / 2 + b]);
+      // owners overwrite column / row k with v / d, the pivot with -1/d
+      if (tx == kl) {
+#pragma unroll
+        for (int a = kb; a < NB; ++a) {
+          if (a > kb || ty > kl) r[a * (a + 1) / 2 + kb] = -ui[a];
+          else if (ty == kl) r[a * (a + 1) / 2 + kb] = -inv;
+        }
+      }
+      if (ty == kl) {
+#pragma unroll
+        for (int b = 0; b <= kb; ++b)
+          if (b < kb || tx < kl) r[kb * (kb + 1) / 2 + b] = vj[b] * inv;
+      }
+    }
+  }
+  if (bad && t == 0) *flag = 1;
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 32 + ty, j = b * 32 + tx;
+      if (i < D && j <= i) {
+        const double x = -r[a * (a + 1) / 2 + b];
+        out[(size_t)i * D + j] = x;
+        out[(size_t)j * D + i] = x;
+      }
+    }
+}
+
+// out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: plain W^-1); D <= 256
+int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
+                    int *dflag, int batch) {
+  const int nb = (int)ceil_div(D, 32);
+#define SW(NBB) spd_inverse_sweep_kernel<NBB><<<batch, 1024, 0, h->stream>>>(W, B, gn, D, out, dflag)
+  switch (nb) {
+    case 1: SW(1); break;
+    case 2: SW(2); break;
+    case 3: SW(3); break;
+    case 4: SW(4); break;
+    case 5: SW(5); break;
+    case 6: SW(6); break;
+    case 7: SW(7); break;
+    case 8: SW(8); break;
+    default: return fail(h, PLDA_E_INVAL, "spd_inverse: D=%d > 256 unsupported", D);
+  }
+#undef SW
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// symmetric eigensolver: one-sided (Hestenes) block Jacobi on the rows of A (= G), V = I.
+// After convergence A = V G has mutually orthogonal rows, so the rows of V are the
+// eigenvectors of G and lambda_p = a_p . v_p.
+// ------------------------------------------------------------------------------------
+// Block form of the one-sided Jacobi round: rows are grouped in blocks of JB = 4; a launch
+// is one OUTER tournament round over the blocks; each workgroup takes one block pair,
+// stages its 8 rows of A and of V in LDS and runs the full INNER tournament on them
+// (7 rounds x 4 disjoint pairs, one wave per pair, __syncthreads between rounds), so 28
+// rotations are applied per round trip to L2 instead of one.
+constexpr int JB = 4;
 
 template <int E>
 __global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ A, double *__restrict__ V,
