@@ -191,6 +191,38 @@ int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn,
                    double *out);
 
+/* ---- LDA: replaces the reference's second model, the pure-Python
+ * class LDA of python/liblda/lda.py (used by scoring/scoreLDA.py:175,224,241), on the same
+ * handle.  All fp64.  solver: 0 = 'svd' (lda.py:171-209), 1 = 'eigen' (:134-169),
+ * 2 = 'lsqr' (:211-240).  labels dense 0..K-1 (the shim compacts np.unique order, :112-116);
+ * priors: K host doubles or NULL = class frequencies (:113-119), renormalised when their sum
+ * is not exactly 1 (:121-122).  A singular within-class covariance with the eigen solver
+ * returns PLDA_E_NUMERIC (the reference raises LinAlgError from scipy.linalg.eigh, :157).
+ *   plda_lda_dims        K, D, rank (columns of scalings: svd = retained rank, eigen = D,
+ *                        lsqr = 0), solver
+ *   plda_lda_get_model   priors[K], means[K,D], xbar[D] (svd), scalings[D,rank] (svd, eigen),
+ *                        coef[K,D], intercept[K], explained_variance_ratio[D] (eigen); any NULL
+ *   plda_lda_set_model   restores a saved model (the reference cannot persist one)
+ *   plda_lda_predict     out[N,K]; mode 0 decision_function (:242-270), 1 predict_log_proba
+ *                        (:296-314), 2 the logistic of the decision values (first half of
+ *                        predict_proba, :283-287), 3 the same one-vs-rest normalised (:292)
+ *   plda_lda_transform   out[N,ncomp] = X scalings[:, :ncomp] (eigen, :333-334) or
+ *                        (X - xbar) scalings[:, :ncomp] (svd, :331-332); lsqr -> PLDA_E_INVAL ---- */
+int plda_lda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels,
+                 int32_t solver, const double *priors);
+int plda_lda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels,
+                     int64_t K, int32_t solver, const double *priors);
+int plda_lda_dims(plda_handle *h, int64_t *K, int32_t *D, int32_t *rank, int32_t *solver);
+int plda_lda_get_model(plda_handle *h, double *priors, double *means, double *xbar, double *scalings,
+                       double *coef, double *intercept, double *evr);
+int plda_lda_set_model(plda_handle *h, int32_t solver, int64_t K, int32_t D, int32_t rank,
+                       const double *priors, const double *means, const double *xbar,
+                       const double *scalings, const double *coef, const double *intercept);
+int plda_lda_predict(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t mode, double *out);
+int plda_lda_predict_dev(plda_handle *h, const double *dX, int64_t N, int32_t mode, double *dout);
+int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t ncomp, double *out);
+int plda_lda_transform_dev(plda_handle *h, const double *dX, int64_t N, int32_t ncomp, double *dout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,9 +2,9 @@
 
 `from liblda import PLDA` works as in RicherMans/PLDA; the object underneath is the
 MI355X engine (plda_amd.MPlda) instead of the Kaldi-backed CPython-2 extension.
-The reference also exports `LDA` (a NumPy/SciPy class, CPU only); it is outside the
-accelerated path (out of scope) and is not provided here.
+`LDA` (python/liblda/lda.py) runs on the same engine.
 """
 from .plda import PLDA
+from .lda import LDA
 
-__all__ = ["PLDA"]
+__all__ = ["PLDA", "LDA"]

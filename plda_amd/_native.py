@@ -36,6 +36,15 @@ SIGNATURES = {
     "plda_fit_stats_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64]),
     "plda_fit_get_stats_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "plda_fit_em_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32]),
+    "plda_lda_fit": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "plda_lda_fit_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
+    "plda_lda_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "plda_lda_get_model": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plda_lda_set_model": (C.c_int, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plda_lda_predict": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "plda_lda_predict_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "plda_lda_transform": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "plda_lda_transform_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "plda_fit_timings": (C.c_int, [_vp, _vp]),
     "plda_fit_get_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plda_fit_num_classes": (C.c_int, [_vp, C.POINTER(_i64)]),

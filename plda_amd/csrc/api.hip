@@ -127,7 +127,8 @@ int plda_destroy(plda_handle *h) {
   (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                     &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
-                    &h->s_rscale, &h->s_cbias};
+                    &h->s_rscale, &h->s_cbias, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
+                    &h->l_coef, &h->l_intercept, &h->l_evr};
   for (DevBuf *b : bufs) b->release();
   for (auto &b : h->w) b.release();
   if (h->jac_exec) (void)hipGraphExecDestroy(h->jac_exec);
@@ -535,6 +536,136 @@ int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t
   PLDA_HIP(h, dOut.alloc((size_t)U * D * 8));
   PLDA_TRY(dvector_pool_device(h, dF.p, dtype, T, D, dO.as<int64_t>(), U, method, l2norm, dOut.as<double>()));
   PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, (size_t)U * D * 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+// ---------------------------------------------------------------- LDA (python/liblda/lda.py)
+int plda_lda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
+                     int32_t solver, const double *priors) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return lda_fit_device(h, dX, N, D, dlabels, K, solver, priors);
+}
+
+int plda_lda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels, int32_t solver,
+                 const double *priors) {
+  if (!h) return PLDA_E_INVAL;
+  if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "lda_fit: bad argument");
+  uint64_t mx = 0;
+  for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
+  if (mx >= (uint64_t)N) return fail(h, PLDA_E_LABELS, "lda_fit: labels must be dense 0..K-1");
+  PLDA_TRY(set_device(h));
+  Tmp dX, dL;
+  PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
+  PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
+  return lda_fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), (int64_t)mx + 1, solver, priors);
+}
+
+int plda_lda_dims(plda_handle *h, int64_t *K, int32_t *D, int32_t *rank, int32_t *solver) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+  if (K) *K = h->lda_K;
+  if (D) *D = h->lda_D;
+  if (rank) *rank = h->lda_rank;
+  if (solver) *solver = h->lda_solver;
+  return PLDA_OK;
+}
+
+int plda_lda_get_model(plda_handle *h, double *priors, double *means, double *xbar, double *scalings, double *coef,
+                       double *intercept, double *evr) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+  PLDA_TRY(set_device(h));
+  const size_t K = (size_t)h->lda_K, D = (size_t)h->lda_D, R = (size_t)h->lda_rank;
+  auto get = [&](double *dst, const DevBuf &src, size_t n) -> hipError_t {
+    return (dst && n) ? hipMemcpyAsync(dst, src.p, n * 8, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+  };
+  PLDA_HIP(h, get(priors, h->l_priors, K));
+  PLDA_HIP(h, get(means, h->l_means, K * D));
+  PLDA_HIP(h, get(coef, h->l_coef, K * D));
+  PLDA_HIP(h, get(intercept, h->l_intercept, K));
+  if (h->lda_solver == 0) PLDA_HIP(h, get(xbar, h->l_xbar, D));
+  if (h->lda_solver != 2) PLDA_HIP(h, get(scalings, h->l_scalings, D * R));
+  if (h->lda_solver == 1) PLDA_HIP(h, get(evr, h->l_evr, D));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
+int plda_lda_set_model(plda_handle *h, int32_t solver, int64_t K, int32_t D, int32_t rank, const double *priors,
+                       const double *means, const double *xbar, const double *scalings, const double *coef,
+                       const double *intercept) {
+  if (!h) return PLDA_E_INVAL;
+  if (solver < 0 || solver > 2 || K <= 0 || D <= 0 || rank < 0 || rank > D || !coef || !intercept)
+    return fail(h, PLDA_E_INVAL, "lda_set_model: bad argument");
+  if (solver != 2 && (!scalings || rank == 0)) return fail(h, PLDA_E_INVAL, "lda_set_model: scalings required");
+  if (solver == 0 && !xbar) return fail(h, PLDA_E_INVAL, "lda_set_model: xbar required for the svd solver");
+  PLDA_TRY(set_device(h));
+  auto put = [&](DevBuf &dst, const double *src, size_t n) -> hipError_t {
+    hipError_t e = dst.reserve((n ? n : 1) * 8);
+    if (e != hipSuccess || !src || !n) return e;
+    return hipMemcpyAsync(dst.p, src, n * 8, hipMemcpyHostToDevice, h->stream);
+  };
+  const size_t k = (size_t)K, d = (size_t)D;
+  PLDA_HIP(h, put(h->l_priors, priors, k));
+  PLDA_HIP(h, put(h->l_means, means, k * d));
+  PLDA_HIP(h, put(h->l_xbar, xbar, d));
+  PLDA_HIP(h, put(h->l_scalings, scalings, d * (size_t)rank));
+  PLDA_HIP(h, put(h->l_coef, coef, k * d));
+  PLDA_HIP(h, put(h->l_intercept, intercept, k));
+  PLDA_HIP(h, h->l_evr.reserve(d * 8));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  h->lda_fitted = true; h->lda_solver = solver; h->lda_K = K; h->lda_D = D; h->lda_rank = rank;
+  return PLDA_OK;
+}
+
+int plda_lda_predict_dev(plda_handle *h, const double *dX, int64_t N, int32_t mode, double *dout) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return lda_predict_device(h, dX, N, mode, dout);
+}
+
+int plda_lda_predict(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t mode, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+  if (D != h->lda_D)
+    return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);   // lda.py:264-266
+  if (N <= 0) return PLDA_OK;
+  if (!X || !out) return fail(h, PLDA_E_INVAL, "lda_predict: bad argument");
+  PLDA_TRY(set_device(h));
+  // row slabs bound the device footprint of the [N, K] result
+  const int64_t slab = std::max<int64_t>(1, std::min<int64_t>(N, ((int64_t)1 << 28) / std::max<int64_t>(h->lda_K, D)));
+  Tmp dX, dO;
+  PLDA_HIP(h, dX.alloc((size_t)slab * D * 8));
+  PLDA_HIP(h, dO.alloc((size_t)slab * h->lda_K * 8));
+  for (int64_t r0 = 0; r0 < N; r0 += slab) {
+    const int64_t r = std::min(slab, N - r0);
+    PLDA_HIP(h, hipMemcpyAsync(dX.p, X + r0 * D, (size_t)r * D * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_TRY(lda_predict_device(h, dX.as<double>(), r, mode, dO.as<double>()));
+    PLDA_HIP(h, hipMemcpyAsync(out + r0 * h->lda_K, dO.p, (size_t)r * h->lda_K * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  return PLDA_OK;
+}
+
+int plda_lda_transform_dev(plda_handle *h, const double *dX, int64_t N, int32_t ncomp, double *dout) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return lda_transform_device(h, dX, N, ncomp, dout);
+}
+
+int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t ncomp, double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+  if (D != h->lda_D) return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);
+  if (N <= 0 || ncomp <= 0) return PLDA_OK;
+  if (!X || !out) return fail(h, PLDA_E_INVAL, "lda_transform: bad argument");
+  PLDA_TRY(set_device(h));
+  Tmp dX, dO;
+  PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
+  PLDA_HIP(h, dO.alloc((size_t)N * ncomp * 8));
+  PLDA_TRY(lda_transform_device(h, dX.as<double>(), N, ncomp, dO.as<double>()));
+  PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)N * ncomp * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   return PLDA_OK;
 }

@@ -48,6 +48,12 @@ struct plda_handle {
   plda::DevBuf f_means, f_counts, f_scatter, f_sum, f_W, f_B;
   double fit_ms[4] = {0, 0, 0, 0};
 
+  // ---- LDA model (lda.hip; /root/reference/python/liblda/lda.py) ----
+  bool lda_fitted = false;
+  int lda_solver = 0, lda_D = 0, lda_rank = 0;
+  int64_t lda_K = 0;
+  plda::DevBuf l_means, l_priors, l_xbar, l_scalings, l_coef, l_intercept, l_evr;
+
   // ---- scoring workspace ----
   plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias;
   int64_t last_M = 0, last_Nt = 0;
@@ -60,6 +66,7 @@ struct plda_handle {
   long jac_total_sweeps = 0;
   int simdiag_D = 0;
   bool simdiag_has_vr = false;
+  bool eig_keep_sign = false;   // LDA: keep negative eigenvalues (PLDA floors them, Kaldi ApplyFloor)
 
   bool panel_attr_set[4] = {false, false, false, false};
   int gemm_variant = 0;
@@ -133,6 +140,12 @@ int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t 
                         const int64_t *doffsets, int64_t U, int method, int l2norm, double *dout);
 
 // ---- fit.hip ----
+int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
+                       int64_t Ku, double *dmeans, int32_t *dcounts32);
+int lda_fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K,
+                   int solver, const double *priors_host);
+int lda_predict_device(plda_handle *h, const double *dX, int64_t N, int mode, double *dout);
+int lda_transform_device(plda_handle *h, const double *dX, int64_t N, int ncomp, double *dout);
 int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K);
 int fit_em_device(plda_handle *h, int64_t K, int D, int iters);
 int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels,

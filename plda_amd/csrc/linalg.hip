@@ -637,7 +637,7 @@ __global__ void eig_values_kernel(const double *__restrict__ A, const double *__
 
 // rank sort descending (SortSvd), floor at zero (ApplyFloor), permute eigenvector rows
 __global__ void eig_sort_kernel(const double *__restrict__ lam, const double *__restrict__ V, int D,
-                                double *__restrict__ s, double *__restrict__ Vsorted) {
+                                double *__restrict__ s, double *__restrict__ Vsorted, bool floor_at_zero) {
   const int p = blockIdx.x;
   const double lp = lam[p];
   __shared__ int rank_s;
@@ -651,7 +651,7 @@ __global__ void eig_sort_kernel(const double *__restrict__ lam, const double *__
   if (cnt) atomicAdd(&rank_s, cnt);
   __syncthreads();
   const int r = rank_s;
-  if (threadIdx.x == 0) s[r] = lp > 0.0 ? lp : 0.0;
+  if (threadIdx.x == 0) s[r] = (lp > 0.0 || !floor_at_zero) ? lp : 0.0;
   for (int d = threadIdx.x; d < D; d += blockDim.x) Vsorted[(size_t)r * D + d] = V[(size_t)p * D + d];
 }
 
@@ -750,7 +750,7 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
   if (sweeps_out) *sweeps_out = sweeps + 1;
   h->jac_total_sweeps += sweeps + 1;
   eig_values_kernel<<<(unsigned)ceil_div(D, 4), 256, 0, h->stream>>>(A, V, D, lam);
-  eig_sort_kernel<<<D, 64, 0, h->stream>>>(lam, V, D, s, Vrows);
+  eig_sort_kernel<<<D, 64, 0, h->stream>>>(lam, V, D, s, Vrows, !h->eig_keep_sign);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
 }
