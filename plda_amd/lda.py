@@ -102,6 +102,23 @@ class LDA(object):
         """lda.py:296-314."""
         return self._predict(sample, 1)
 
+    # ---- HBM-resident variants (raw device addresses, e.g. torch tensors' data_ptr()) ----
+    def fit_dev(self, dX, n, d, dlabels, k, classes=None):
+        """fit on device-resident X [n, d] fp64 and dense labels 0..k-1 (u64/non-negative i64)."""
+        pri = None if self.priors is None else np.ascontiguousarray(self.priors, dtype=np.float64)
+        rc = self._lib.plda_lda_fit_dev(self._h, C.c_void_p(int(dX)), int(n), int(d), C.c_void_p(int(dlabels)), int(k),
+                                        _SOLVERS[self.solver], _ptr(pri) if pri is not None else None)
+        if rc == N.PLDA_E_NUMERIC and self.solver == "eigen":
+            raise np.linalg.LinAlgError(N.last_error(self._h))
+        N.check(self._h, rc)
+        self._classes = np.arange(k) if classes is None else np.asarray(classes)
+        self._pull()
+
+    def predict_dev(self, dX, n, mode, dout):
+        """mode 0 decision, 1 log-proba, 2 logistic, 3 one-vs-rest proba; dout [n, K] fp64 on the device."""
+        N.check(self._h, self._lib.plda_lda_predict_dev(self._h, C.c_void_p(int(dX)), int(n), int(mode),
+                                                        C.c_void_p(int(dout))))
+
     # ------------------------------------------------------------------ transform (lda.py:317-338)
     def transform(self, X, n_components=None):
         if self.solver == "lsqr":

@@ -76,3 +76,48 @@ def score_trial_list(plda, testreference, enroltransform, testtransform, enrolsp
     if errors > 0:
         log.warning("Overall %i errors occured during the testing phase!", errors)
     return len(rows), errors
+
+
+def score_trial_list_lda(lda, testreferences, spktonum, testtofeature, scoreoutfile, chunk=8192):
+    """The scoring loop of scoring/scoreLDA.py:228-248 in batched form.
+
+    The reference calls `lda.predict_log_proba(testdvector[np.newaxis, :])[0]` once per trial
+    (:240-241) and keeps the entry of the enrol model's speaker (:244); here every distinct test
+    utterance goes through ONE predict_log_proba per chunk of utterances (a [chunk, K] GEMM +
+    log-softmax on the GPU) and the trial's entry is gathered.  Output lines are byte-identical:
+    "{} {}-{} {:.3f}\\n".format(enrolemodel, targetmdl, testutt, finalscore) (:245-246).
+    `lda`: liblda.LDA fitted on the speaker-numbered d-vectors; `spktonum`: {speaker: class index}
+    (scoreLDA.py:215-217); `testtofeature`: {utterance: d-vector}.  Returns (n_scored, n_errors)."""
+    rows, utts, upos = [], [], {}
+    errors = 0
+    for enrolemodel, vals in testreferences.items():
+        if enrolemodel not in spktonum:                            # scoreLDA.py:229-232
+            errors += 1
+            log.warning("Enrolemodel %s not found in the labels", enrolemodel)
+            continue
+        curspk = spktonum[enrolemodel]
+        for testutt, targetmdl in vals:
+            if testutt not in testtofeature:                       # :235-238
+                log.warning("Utterance %s not found in the testset", testutt)
+                errors += 1
+                continue
+            if testutt not in upos:
+                upos[testutt] = len(utts)
+                utts.append(testutt)
+            rows.append((enrolemodel, targetmdl, testutt, curspk, upos[testutt]))
+    if rows:
+        picked = {}
+        by_utt = {}
+        for r, (_, _, _, spk, u) in enumerate(rows):
+            by_utt.setdefault(u, []).append((r, spk))
+        for c0 in range(0, len(utts), chunk):
+            feats = np.stack([np.asarray(testtofeature[u], dtype=np.float64) for u in utts[c0:c0 + chunk]])
+            lp = lda.predict_log_proba(feats)
+            for u in range(c0, min(len(utts), c0 + chunk)):
+                for r, spk in by_utt.get(u, ()):
+                    picked[r] = lp[u - c0, spk]
+        for r, (enrolemodel, targetmdl, testutt, _, _) in enumerate(rows):
+            scoreoutfile.write("{} {}-{} {:.3f}\n".format(enrolemodel, targetmdl, testutt, picked[r]))
+    if errors > 0:
+        log.warning("Overall %i happened while processing the testutterances. The scores may not be complete", errors)
+    return len(rows), errors

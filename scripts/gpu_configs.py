@@ -227,7 +227,35 @@ def frontend():
     return res
 
 
-for name, fn in (("C3", c3), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
+def lda_c2():
+    """LDA row at the C2 shape (scoring/scoreLDA.py's workload): svd fit on 100k x 200 / 5k speakers, then
+    predict_log_proba of 100k test d-vectors against the 5k classes (5e8 scores)."""
+    from plda_amd.lda import LDA
+    N, D, K, Nt = 100_000, 200, 5000, 100_000
+    rng = np.random.default_rng(2)
+    y = np.arange(N) % K
+    X = torch.from_numpy(rng.random((N, D)) + 0.8 * rng.standard_normal((K, D))[y]).to(dev)
+    yy = torch.from_numpy(y.astype(np.int64)).to(dev)
+    Xt = torch.from_numpy(rng.random((Nt, D))).to(dev)
+    out = torch.empty((Nt, K), dtype=torch.float64, device=dev)
+    res = {}
+    for solver in ("svd", "eigen", "lsqr"):
+        lda = LDA(solver)
+        lda.fit_dev(X.data_ptr(), N, D, yy.data_ptr(), K)
+        res["fit_%s_ms" % solver] = 1e3 * timed(lambda: lda.fit_dev(X.data_ptr(), N, D, yy.data_ptr(), K), 2)
+    lda = LDA("svd"); lda.fit_dev(X.data_ptr(), N, D, yy.data_ptr(), K)
+    for mode, name in ((0, "decision"), (1, "log_proba")):
+        ms = 1e3 * timed(lambda: lda.predict_dev(Xt.data_ptr(), Nt, mode, out.data_ptr()), 3)
+        res["%s_ms" % name] = ms
+        res["%s_scores_per_s" % name] = Nt * K / (ms / 1e3)
+    res["log_proba_fp64_tflops"] = 2.0 * D * Nt * K / (res["log_proba_ms"] / 1e3) / 1e12
+    res["row_logsumexp_max_abs"] = float(torch.logsumexp(out[:2048], dim=1).abs().max())
+    ref = torch.log_softmax(Xt[:2048] @ torch.from_numpy(lda._coef).to(dev).T + torch.from_numpy(lda._intercept).to(dev), dim=1)
+    res["check_max_err"] = float((out[:2048] - ref).abs().max())
+    return res
+
+
+for name, fn in (("C3", c3), ("lda", lda_c2), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     t0 = time.perf_counter()

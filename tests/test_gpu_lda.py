@@ -145,3 +145,44 @@ def test_lda_c2_sized_properties():
     assert (cen.argmax(1) == np.arange(1000)).all()
     assert (lp.argmax(1) == y[:4096]).mean() > 0.95
     del torch
+
+
+def test_lda_trial_list_scores_match_per_trial_loop(tmp_path):
+    """scoring/scoreLDA.py:228-248: the batched trial-list scorer writes the same file as the
+    reference's one-predict-per-trial loop run on the oracle."""
+    import io
+    from oracle import lda_oracle_np as lo
+    from liblda import LDA
+    from plda_amd.trials import parse_trial_ref, score_trial_list_lda
+    rng = np.random.default_rng(77)
+    spk = ["spk%02d" % i for i in range(9)]
+    spktonum = {s: i for i, s in enumerate(sorted(spk))}
+    labels = rng.integers(0, 9, 600)
+    X = rng.random((600, 12)) + 0.7 * rng.standard_normal((9, 12))[labels]
+    testtofeature = {"utt-%03d" % i: rng.random(12) + 0.7 * rng.standard_normal(12) for i in range(40)}
+    lines = []
+    for t in range(150):
+        u = "utt-%03d" % rng.integers(0, 42)                     # two utterances are missing on purpose
+        m = spk[rng.integers(0, 9)] if t % 37 else "ghost"
+        lines.append("%s %s-%s %d\n" % (m, spk[rng.integers(0, 9)], u, rng.integers(0, 2)))
+    ref_path = tmp_path / "test_ref"
+    ref_path.write_text("".join(lines))
+    refs = parse_trial_ref(str(ref_path))
+    lda = LDA("svd")
+    lda.fit(X, labels)
+    got = io.StringIO()
+    n, err = score_trial_list_lda(lda, refs, spktonum, testtofeature, got, chunk=16)
+    model = lo.fit(X, labels, "svd")
+    want, werr = io.StringIO(), 0
+    for enrolemodel, vals in refs.items():
+        if enrolemodel not in spktonum:
+            werr += 1
+            continue
+        for testutt, targetmdl in vals:
+            if testutt not in testtofeature:
+                werr += 1
+                continue
+            score = lo.predict_log_proba(model, testtofeature[testutt][np.newaxis, :])[0]
+            want.write("{} {}-{} {:.3f}\n".format(enrolemodel, targetmdl, testutt, score[spktonum[enrolemodel]]))
+    assert err == werr and n == len(want.getvalue().splitlines())
+    assert got.getvalue() == want.getvalue()
