@@ -21,51 +21,62 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------
 // gemm_f64
 // ------------------------------------------------------------------------------------
-constexpr int GB = 64;    // block tile (square)
+constexpr int GB = 64;    // block tile (square), small variant
 constexpr int GK = 16;    // k per LDS stage
 constexpr int LDK = 17;   // leading dim of an [m][k] tile (k-contiguous source)
-constexpr int LDM = 80;   // leading dim of a  [k][m] tile (m-contiguous source)
 
-template <bool KC>
-__device__ __forceinline__ int tile_idx(int m, int k) { return KC ? m * LDK + k : k * LDM + m; }
+// LDS index of element (m, k) of a TB x 16 operand tile: [m][k] for a k-contiguous source, [k][m] otherwise
+template <bool KC, int TB>
+__device__ __forceinline__ int tile_idx(int m, int k) { return KC ? m * LDK + k : k * (TB + 16) + m; }
 
-// A 64 (m) x 16 (k) tile of op(A) is fetched global -> registers (4 doubles per thread) and
+// A TB (m) x 16 (k) tile of op(A) is fetched global -> registers (TB/16 doubles per thread) and
 // later written registers -> LDS, so that the fetch of tile t+1 overlaps the MFMAs of tile t.
-// element (m,k) = A[m*sm + k*sk] * kw[k]
-template <bool KC>
-__device__ __forceinline__ void fetch_tile(double (&r)[4], const double *__restrict__ A, int64_t sm, int64_t sk,
-                                           int64_t m0, int64_t M, int64_t k0, int64_t Kend,
-                                           const double *__restrict__ kw, int t) {
+// element (m,k) = A[m*sm + k*sk] * kw[k].  The loads are UNCONDITIONAL on clamped indices (a
+// predicated load becomes a branch + wait per load, which serialises the whole fetch); the
+// out-of-range elements are zeroed when the tile is written to LDS.
+template <bool KC, int TB>
+__device__ __forceinline__ void fetch_tile(double (&r)[TB / 16], double (&w)[KC ? 1 : TB / 16],
+                                           const double *__restrict__ A, int64_t sm, int64_t sk, int64_t m0,
+                                           int64_t M, int64_t k0, int64_t Kend, const double *__restrict__ kw,
+                                           int t) {
   if (KC) {
-    const int k = t & 15;
-    const int64_t gk = k0 + k;
-    const double wk = (gk < Kend) ? (kw ? kw[gk] : 1.0) : 0.0;
+    const int64_t gk = min(k0 + (t & 15), Kend - 1);
+    w[0] = kw ? kw[gk] : 1.0;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int64_t gm = m0 + (t >> 4) + pass * 16;
-      r[pass] = (gm < M && gk < Kend) ? A[gm * sm + gk * sk] * wk : 0.0;
+    for (int pass = 0; pass < TB / 16; ++pass) {
+      const int64_t gm = min(m0 + (t >> 4) + pass * 16, M - 1);
+      r[pass] = A[gm * sm + gk * sk];
     }
   } else {
-    const int64_t gm = m0 + (t & 63);
+    const int64_t gm = min(m0 + (t & (TB - 1)), M - 1);
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int64_t gk = k0 + (t >> 6) + pass * 4;
-      r[pass] = (gm < M && gk < Kend) ? A[gm * sm + gk * sk] * (kw ? kw[gk] : 1.0) : 0.0;
+    for (int pass = 0; pass < TB / 16; ++pass) {
+      const int64_t gk = min(k0 + t / TB + pass * (256 / TB), Kend - 1);
+      r[pass] = A[gm * sm + gk * sk];
+      w[pass] = kw ? kw[gk] : 1.0;
     }
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(double *lds, const double (&r)[4], int t) {
+template <bool KC, int TB>
+__device__ __forceinline__ void store_tile(double *lds, const double (&r)[TB / 16], const double (&w)[KC ? 1 : TB / 16],
+                                           int64_t m0, int64_t M, int64_t k0, int64_t Kend, int t) {
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    if (KC) lds[tile_idx<true>((t >> 4) + pass * 16, t & 15)] = r[pass];
-    else lds[tile_idx<false>(t & 63, (t >> 6) + pass * 4)] = r[pass];
+  for (int pass = 0; pass < TB / 16; ++pass) {
+    if (KC) {
+      const bool ok = (m0 + (t >> 4) + pass * 16 < M) && (k0 + (t & 15) < Kend);
+      lds[tile_idx<true, TB>((t >> 4) + pass * 16, t & 15)] = ok ? r[pass] * w[0] : 0.0;
+    } else {
+      const bool ok = (m0 + (t & (TB - 1)) < M) && (k0 + t / TB + pass * (256 / TB) < Kend);
+      lds[tile_idx<false, TB>(t & (TB - 1), t / TB + pass * (256 / TB))] = ok ? r[pass] * w[pass] : 0.0;
+    }
   }
 }
 
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, int64_t kchunk,
+// TB = 64: 4 waves x (32 x 32); TB = 128: 4 waves x (64 x 64) -- 16 MFMAs per 8 fragment reads, for the
+// large products (the scatter SYRK at D = 512, the LDA decision matrix), chosen when it still fills the chip.
+template <bool AKC, bool BKC, int TB>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t M, int64_t N, int64_t K, int64_t kchunk,
                                                        double alpha, const double *__restrict__ A,
                                                        int64_t sam, int64_t sak,
                                                        const double *__restrict__ B, int64_t sbk,
@@ -73,69 +84,71 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int64_t M, int64_t N, int
                                                        double beta, double *__restrict__ C, int64_t ldc,
                                                        double *__restrict__ part, int splits, int64_t strideA,
                                                        int64_t strideB, int64_t strideC) {
+  constexpr int TM = TB / 32;                   // 16 x 16 MFMA tiles per wave and dimension
+  constexpr int TILE = GK * (TB + 16);          // doubles per operand stage (covers both layouts)
   // blockIdx.z = batch * splits + split; batched calls run with splits == 1
   const int zb = (int)blockIdx.z / splits, zs = (int)blockIdx.z % splits;
   A += (int64_t)zb * strideA;
   B += (int64_t)zb * strideB;
   C += (int64_t)zb * strideC;
-  __shared__ double As[2][GK * LDM];
-  __shared__ double Bs[2][GK * LDM];
+  __shared__ double As[2][TILE];
+  __shared__ double Bs[2][TILE];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * GB, n0 = (int64_t)blockIdx.x * GB;
+  const int64_t m0 = (int64_t)blockIdx.y * TB, n0 = (int64_t)blockIdx.x * TB;
   const int64_t kbeg = (int64_t)zs * kchunk;
   const int64_t kend = min(K, kbeg + kchunk);
 
-  f64x4 acc[2][2];
+  f64x4 acc[TM][TM];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < TM; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   const int fi = lane & 15, fk = lane >> 4;
-  double ra[4], rb[4];
-  fetch_tile<AKC>(ra, A, sam, sak, m0, M, kbeg, kend, kw, t);
-  fetch_tile<BKC>(rb, B, sbn, sbk, n0, N, kbeg, kend, nullptr, t);
-  store_tile<AKC>(As[0], ra, t);
-  store_tile<BKC>(Bs[0], rb, t);
+  double ra[TB / 16], rb[TB / 16], wa[AKC ? 1 : TB / 16], wb[BKC ? 1 : TB / 16];
+  fetch_tile<AKC, TB>(ra, wa, A, sam, sak, m0, M, kbeg, kend, kw, t);
+  fetch_tile<BKC, TB>(rb, wb, B, sbn, sbk, n0, N, kbeg, kend, nullptr, t);
+  store_tile<AKC, TB>(As[0], ra, wa, m0, M, kbeg, kend, t);
+  store_tile<BKC, TB>(Bs[0], rb, wb, n0, N, kbeg, kend, t);
   __syncthreads();
   int cur = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
     const bool more = k0 + GK < kend;
     if (more) {   // next tile's global loads are in flight during this tile's MFMAs
-      fetch_tile<AKC>(ra, A, sam, sak, m0, M, k0 + GK, kend, kw, t);
-      fetch_tile<BKC>(rb, B, sbn, sbk, n0, N, k0 + GK, kend, nullptr, t);
+      fetch_tile<AKC, TB>(ra, wa, A, sam, sak, m0, M, k0 + GK, kend, kw, t);
+      fetch_tile<BKC, TB>(rb, wb, B, sbn, sbk, n0, N, k0 + GK, kend, nullptr, t);
     }
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
-      double a[2], b[2];
+      double a[TM], b[TM];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) a[tm] = As[cur][tile_idx<AKC>(wm * 32 + tm * 16 + fi, kk * 4 + fk)];
+      for (int tm = 0; tm < TM; ++tm) a[tm] = As[cur][tile_idx<AKC, TB>(wm * (TB / 2) + tm * 16 + fi, kk * 4 + fk)];
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) b[tn] = Bs[cur][tile_idx<BKC>(wn * 32 + tn * 16 + fi, kk * 4 + fk)];
+      for (int tn = 0; tn < TM; ++tn) b[tn] = Bs[cur][tile_idx<BKC, TB>(wn * (TB / 2) + tn * 16 + fi, kk * 4 + fk)];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < TM; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
     if (more) {
-      store_tile<AKC>(As[cur ^ 1], ra, t);
-      store_tile<BKC>(Bs[cur ^ 1], rb, t);
+      store_tile<AKC, TB>(As[cur ^ 1], ra, wa, m0, M, k0 + GK, kend, t);
+      store_tile<BKC, TB>(Bs[cur ^ 1], rb, wb, n0, N, k0 + GK, kend, t);
     }
     __syncthreads();
     cur ^= 1;
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < TM; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + wm * 32 + tm * 16 + (lane >> 4) + 4 * r;
-        const int64_t col = n0 + wn * 32 + tn * 16 + (lane & 15);
+        const int64_t row = m0 + wm * (TB / 2) + tm * 16 + (lane >> 4) + 4 * r;
+        const int64_t col = n0 + wn * (TB / 2) + tn * 16 + (lane & 15);
         if (row < M && col < N) {
           if (part) {
             part[((int64_t)zs * M + row) * N + col] = acc[tm][tn][r];
@@ -256,9 +269,15 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
   }
+  // 128 x 128 tiles when they still give every CU work (after split-K), 64 x 64 otherwise
+  const int64_t tiles128 = ceil_div(M, 128) * ceil_div(N, 128);
+  const bool big = h->gemm64_variant != 1 && M >= 128 && N >= 128 &&
+                   tiles128 * (K >= 1024 ? std::min<int64_t>(ceil_div(K, 256), 64) : 1) * batch >= 192;
+  const int TBsel = big ? 128 : 64;
+  const int64_t tl = big ? tiles128 : tiles;
   int splits = 1;
-  if (batch == 1 && tiles < 512 && K >= 1024) {
-    splits = (int)std::min<int64_t>(ceil_div(K, 256), std::max<int64_t>(1, 1024 / tiles));
+  if (batch == 1 && tl < 512 && K >= 1024) {
+    splits = (int)std::min<int64_t>(ceil_div(K, 256), std::max<int64_t>(1, 1024 / tl));
   }
   int64_t kchunk = round_up(ceil_div(K, splits), GK);
   splits = (int)ceil_div(K, kchunk);
@@ -268,11 +287,18 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
     part = h->w[15].as<double>();
   }
   if ((int64_t)splits * batch > 65535) return fail(h, PLDA_E_INVAL, "gemm_f64: batch %d too large", batch);
-  const dim3 grid((unsigned)ceil_div(N, GB), (unsigned)ceil_div(M, GB), (unsigned)(splits * batch));
-#define GEMM_LAUNCH(AK, BK)                                                                          \
-  gemm_f64_kernel<AK, BK><<<grid, 256, 0, h->stream>>>(M, N, K, kchunk, alpha, A, sam, sak, B, sbk, \
-                                                       sbn, kw, beta, C, ldc, part, splits, strideA, \
-                                                       strideB, strideC)
+  const dim3 grid((unsigned)ceil_div(N, TBsel), (unsigned)ceil_div(M, TBsel), (unsigned)(splits * batch));
+#define GEMM_LAUNCH(AK, BK)                                                                                   \
+  do {                                                                                                        \
+    if (big)                                                                                                  \
+      gemm_f64_kernel<AK, BK, 128><<<grid, 256, 0, h->stream>>>(M, N, K, kchunk, alpha, A, sam, sak, B, sbk,  \
+                                                                sbn, kw, beta, C, ldc, part, splits, strideA, \
+                                                                strideB, strideC);                            \
+    else                                                                                                      \
+      gemm_f64_kernel<AK, BK, 64><<<grid, 256, 0, h->stream>>>(M, N, K, kchunk, alpha, A, sam, sak, B, sbk,   \
+                                                               sbn, kw, beta, C, ldc, part, splits, strideA,  \
+                                                               strideB, strideC);                             \
+  } while (0)
   if (akc && bkc) GEMM_LAUNCH(true, true);
   else if (akc && !bkc) GEMM_LAUNCH(true, false);
   else if (!akc && bkc) GEMM_LAUNCH(false, true);
