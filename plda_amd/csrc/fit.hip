@@ -550,11 +550,10 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       if (D <= 256) {
         PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, b2, dflag, G));                     // registers, one CU per group
       } else {
+        // block elimination down to <= 256-row sweeps (b1 is free here: scratch)
         em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0);
         PLDA_LAUNCH_CHECK(h);
-        PLDA_TRY(cholesky_f64(h, b0, D, dflag, G));                                   // b0 = L
-        PLDA_TRY(tri_invert_f64(h, b0, b1, D, G));                                    // b1 = L^-1
-        PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b1, 1, D, sDD, b1, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));
+        PLDA_TRY(spd_inverse_blocked(h, b0, D, D, sDD, b2, D, sDD, b1, sDD, dflag, G));
       }
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, B, D, 1, 0, b2, D, 1, sDD, nullptr, 0.0, b0, D, sDD, G));
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, W, D, 1, 0, b0, 1, D, sDD, nullptr, 0.0, b1, D, sDD, G));

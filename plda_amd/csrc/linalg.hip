@@ -443,13 +443,16 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 template <int NB>
 __global__ __launch_bounds__(1024) void spd_inverse_sweep_kernel(const double *__restrict__ W,
                                                                  const double *__restrict__ B,
-                                                                 const double *__restrict__ gn, int D,
-                                                                 double *__restrict__ out, int *flag) {
+                                                                 const double *__restrict__ gn, int D, int ldin,
+                                                                 int64_t stride_in, double *__restrict__ out,
+                                                                 int ldout, int64_t stride_out, int *flag) {
   constexpr int NE = NB * (NB + 1) / 2;
   __shared__ double v[2][NB * 32];
   const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
   const double n = gn ? gn[blockIdx.x] : 0.0;
-  out += (size_t)blockIdx.x * D * D;
+  W += (int64_t)blockIdx.x * stride_in;      // stride_in == 0: W (and B) shared by the batch, only n differs
+  if (B) B += (int64_t)blockIdx.x * stride_in;
+  out += (int64_t)blockIdx.x * stride_out;
   double r[NE];
 #pragma unroll
   for (int a = 0; a < NB; ++a)
@@ -458,8 +461,8 @@ __global__ __launch_bounds__(1024) void spd_inverse_sweep_kernel(const double *_
       const int i = a * 32 + ty, j = b * 32 + tx;
       double x = 0.0;
       if (i < D && j <= i) {
-        x = W[(size_t)i * D + j];
-        if (B) x = fma(n, B[(size_t)i * D + j], x);
+        x = W[(size_t)i * ldin + j];
+        if (B) x = fma(n, B[(size_t)i * ldin + j], x);
       }
       r[a * (a + 1) / 2 + b] = x;
     }
@@ -518,17 +521,19 @@ __global__ __launch_bounds__(1024) void spd_inverse_sweep_kernel(const double *_
       const int i = a * 32 + ty, j = b * 32 + tx;
       if (i < D && j <= i) {
         const double x = -r[a * (a + 1) / 2 + b];
-        out[(size_t)i * D + j] = x;
-        out[(size_t)j * D + i] = x;
+        out[(size_t)i * ldout + j] = x;
+        out[(size_t)j * ldout + i] = x;
       }
     }
 }
 
-// out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: plain W^-1); D <= 256
-int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
-                    int *dflag, int batch) {
+// out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: W[g]^-1 with batch stride `stride_in`); D <= 256
+int spd_inverse_small(plda_handle *h, const double *W, const double *B, const double *gn, int D, int ldin,
+                      int64_t stride_in, double *out, int ldout, int64_t stride_out, int *dflag, int batch) {
   const int nb = (int)ceil_div(D, 32);
-#define SW(NBB) spd_inverse_sweep_kernel<NBB><<<batch, 1024, 0, h->stream>>>(W, B, gn, D, out, dflag)
+#define SW(NBB)                                                                                              \
+  spd_inverse_sweep_kernel<NBB><<<batch, 1024, 0, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout, \
+                                                               stride_out, dflag)
   switch (nb) {
     case 1: SW(1); break;
     case 2: SW(2); break;
@@ -541,6 +546,55 @@ int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const doub
     default: return fail(h, PLDA_E_INVAL, "spd_inverse: D=%d > 256 unsupported", D);
   }
 #undef SW
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
+                    int *dflag, int batch) {
+  return spd_inverse_small(h, W, B, gn, D, D, 0, out, D, (int64_t)D * D, dflag, batch);
+}
+
+__global__ void copy_block_kernel(const double *__restrict__ src, int lds, int64_t strides, double *__restrict__ dst,
+                                  int ldd, int64_t strided, int rows, int cols, bool transpose) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, c = idx % cols;
+  const double v = src[(int64_t)blockIdx.y * strides + (int64_t)r * lds + c];
+  double *d = dst + (int64_t)blockIdx.y * strided;
+  if (transpose) d[(int64_t)c * ldd + r] = v;
+  else d[(int64_t)r * ldd + c] = v;
+}
+
+// SPD inverse of any size by block elimination on top of the register-resident sweep:
+//   A = [A11 A12; A12^T A22],  X11 = A11^-1,  Y = X11 A12,  S = A22 - A12^T Y,
+//   A^-1 = [X11 + Y S^-1 Y^T,  -Y S^-1;  (.)^T,  S^-1].
+// A11 and the Schur complement S are SPD, so the recursion bottoms out in sweeps of <= 256 rows; everything
+// else is GEMMs with K <= n/2 (the panel-resident kernel).  A: [batch] matrices, leading dimension lda, batch
+// stride sa; out likewise; `scr`: n * n doubles of scratch per batch entry (stride sscr) cover all levels
+// (a level uses n2 * n <= n^2 / 2 of it, the next level starts behind that).
+int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
+                        int64_t so, double *scr, int64_t sscr, int *dflag, int batch) {
+  if (n <= 256) return spd_inverse_small(h, A, nullptr, nullptr, n, lda, sa, out, ldo, so, dflag, batch);
+  const int n1 = (int)round_up((int64_t)ceil_div(n, 2), 32), n2 = n - n1;
+  const double *A12 = A + n1, *A22 = A + (int64_t)n1 * lda + n1;
+  double *O11 = out, *O12 = out + n1, *O21 = out + (int64_t)n1 * ldo, *O22 = out + (int64_t)n1 * ldo + n1;
+  double *Y = scr;                                 // [n1][n2]
+  double *S = scr + (int64_t)n1 * n2;              // [n2][n2]
+  double *sub = scr + (int64_t)n2 * n;             // scratch of the next level
+  const dim3 g22((unsigned)ceil_div((int64_t)n2 * n2, 256), (unsigned)batch);
+  const dim3 g12((unsigned)ceil_div((int64_t)n1 * n2, 256), (unsigned)batch);
+  PLDA_TRY(spd_inverse_blocked(h, A, n1, lda, sa, O11, ldo, so, sub, sscr, dflag, batch));           // O11 = X11
+  PLDA_TRY(gemm_f64_batched(h, n1, n2, n1, 1.0, O11, ldo, 1, so, A12, lda, 1, sa, nullptr, 0.0, Y, n2, sscr, batch));
+  copy_block_kernel<<<g22, 256, 0, h->stream>>>(A22, lda, sa, S, n2, sscr, n2, n2, false);
+  PLDA_LAUNCH_CHECK(h);
+  // S -= A12^T Y : (m, k) of A12^T = A12[k][m]
+  PLDA_TRY(gemm_f64_batched(h, n2, n2, n1, -1.0, A12, 1, lda, sa, Y, n2, 1, sscr, nullptr, 1.0, S, n2, sscr, batch));
+  PLDA_TRY(spd_inverse_blocked(h, S, n2, n2, sscr, O22, ldo, so, sub, sscr, dflag, batch));           // O22 = S^-1
+  PLDA_TRY(gemm_f64_batched(h, n1, n2, n2, -1.0, Y, n2, 1, sscr, O22, ldo, 1, so, nullptr, 0.0, O12, ldo, so, batch));
+  // O11 = X11 - O12 Y^T : (k, n) of Y^T = Y[n][k]
+  PLDA_TRY(gemm_f64_batched(h, n1, n1, n2, -1.0, O12, ldo, 1, so, Y, 1, n2, sscr, nullptr, 1.0, O11, ldo, so, batch));
+  copy_block_kernel<<<g12, 256, 0, h->stream>>>(O12, ldo, so, O21, ldo, so, n1, n2, true);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
 }

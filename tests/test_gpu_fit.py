@@ -266,3 +266,19 @@ def test_fit_em_dev_rejects_bad_statistics():
     one = torch.tensor([5], dtype=torch.int64, device=dev)
     with pytest.raises(ValueError, match="Number of speakers is 1"):
         eng.fit_em_dev(means.data_ptr(), one.data_ptr(), 1, scatter.data_ptr(), 4, 2)
+
+
+@pytest.mark.parametrize("d,k", [(288, 40), (512, 30), (700, 24)])
+def test_fit_large_dim_blocked_inverse(oracle, d, k):
+    """D > 256: (W + nB)^-1 by block elimination over the register-resident sweep (one and two levels);
+    skewed counts give several groups in the batch."""
+    from plda_amd import MPlda
+    x, y = make_data(40 + d, 3 * d, d, k, skew=True, scale_between=0.3)
+    eng = MPlda(0)
+    eng.fit(x, y, 3)
+    ref = oracle.fit(x, y, 3)
+    it = eng.fit_internals()
+    assert _rel(it["W"], ref["W"]) < 1e-8, _rel(it["W"], ref["W"])
+    assert _rel(it["B"], ref["B"]) < 1e-8, _rel(it["B"], ref["B"])
+    g = eng.get_model()
+    assert np.abs(g["psi"] - ref["psi"]).max() <= 1e-8 * max(ref["psi"].max(), 1e-12)
