@@ -117,6 +117,7 @@ int plda_create(int device, plda_handle **out) {
   h->stream = h->own_stream;
   if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
   if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
+  if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
   if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
   *out = h;
   return PLDA_OK;

@@ -71,6 +71,7 @@ struct plda_handle {
   bool panel_attr_set[4] = {false, false, false, false};
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
+  int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
   int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
   bool bt_attr_set = false;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
