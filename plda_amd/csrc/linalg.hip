@@ -373,11 +373,12 @@ int cholesky_f64(plda_handle *h, double *A, int D, int *dflag, int batch) {
 // L, E FMAs and one wave reduction per step; nothing goes through memory until the end.
 // ------------------------------------------------------------------------------------
 template <int E>
-__global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D) {
+__global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D,
+                                                        int ldx, int64_t stride_x) {
   const int j = blockIdx.x;
   const int lane = threadIdx.x;
   L += (size_t)blockIdx.y * D * D;
-  X += (size_t)blockIdx.y * D * D;
+  X += (int64_t)blockIdx.y * stride_x;
   double x[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = 0.0;
@@ -398,13 +399,13 @@ __global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int k = lane + e * 64;
-    if (k < D) X[(size_t)k * D + j] = x[e];   // rows k < j are the zeros x[] was initialised with
+    if (k < D) X[(size_t)k * ldx + j] = x[e];   // rows k < j are the zeros x[] was initialised with
   }
 }
 
-int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch) {
+int tri_invert_ld(plda_handle *h, const double *L, double *X, int D, int ldx, int64_t stride_x, int batch) {
   const int E = (int)ceil_div(D, 64);
-#define TI(EE) tri_invert_kernel<EE><<<dim3(D, batch), 64, 0, h->stream>>>(L, X, D)
+#define TI(EE) tri_invert_kernel<EE><<<dim3(D, batch), 64, 0, h->stream>>>(L, X, D, ldx, stride_x)
   if (E <= 1) TI(1);
   else if (E <= 2) TI(2);
   else if (E <= 4) TI(4);
@@ -414,6 +415,10 @@ int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch)
 #undef TI
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
+}
+
+int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch) {
+  return tri_invert_ld(h, L, X, D, D, (int64_t)D * D, batch);
 }
 
 // fp64 reciprocal / reciprocal square root: hardware estimate refined by Newton steps to full
@@ -555,6 +560,95 @@ int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const doub
   return spd_inverse_small(h, W, B, gn, D, D, 0, out, D, (int64_t)D * D, dflag, batch);
 }
 
+// Cholesky factor in registers (D <= 256), same ownership as the sweep kernel: thread (ty, tx) of the 32 x 32
+// grid owns the lower-triangle elements (32a + ty, 32b + tx).  Column k: the owners publish it through LDS,
+// everyone scales by 1/sqrt(A_kk) and applies the rank-1 update to the trailing blocks (a, b >= kb; rows or
+// columns <= k get a zero factor, so there is no per-element branch).  L (zeros above the diagonal) goes
+// to `out`.  One matrix per workgroup.
+template <int NB>
+__global__ __launch_bounds__(1024) void chol_small_kernel(const double *__restrict__ A, int D, int ldin,
+                                                          int64_t stride_in, double *__restrict__ out, int ldout,
+                                                          int64_t stride_out, int *flag) {
+  constexpr int NE = NB * (NB + 1) / 2;
+  __shared__ double v[2][NB * 32];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  A += (int64_t)blockIdx.x * stride_in;
+  out += (int64_t)blockIdx.x * stride_out;
+  double r[NE];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 32 + ty, j = b * 32 + tx;
+      r[a * (a + 1) / 2 + b] = (i < D && j <= i) ? A[(size_t)i * ldin + j] : 0.0;
+    }
+  bool bad = false;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    for (int kl = 0; kl < 32; ++kl) {
+      const int k = kb * 32 + kl;
+      if (k >= D) break;
+      double *vv = v[k & 1];
+      if (tx == kl) {   // column k, rows >= k
+#pragma unroll
+        for (int a = kb; a < NB; ++a)
+          if (a > kb || ty >= kl) vv[a * 32 + ty] = r[a * (a + 1) / 2 + kb];
+      }
+      __syncthreads();
+      const double d = vv[k];
+      if (!(d > 0.0)) bad = true;
+      const double inv = rsqrt_nr(d);
+      double ui[NB], vj[NB];
+#pragma unroll
+      for (int a = kb; a < NB; ++a) ui[a] = (a * 32 + ty > k) ? -vv[a * 32 + ty] * inv : 0.0;
+#pragma unroll
+      for (int b = kb; b < NB; ++b) vj[b] = (b * 32 + tx > k) ? vv[b * 32 + tx] * inv : 0.0;
+#pragma unroll
+      for (int a = kb; a < NB; ++a)
+#pragma unroll
+        for (int b = kb; b <= a; ++b) r[a * (a + 1) / 2 + b] = fma(ui[a], vj[b], r[a * (a + 1) / 2 + b]);
+      if (tx == kl) {   // column k of L
+#pragma unroll
+        for (int a = kb; a < NB; ++a) {
+          if (a > kb || ty > kl) r[a * (a + 1) / 2 + kb] = -ui[a];
+          else if (ty == kl) r[a * (a + 1) / 2 + kb] = d * inv;
+        }
+      }
+    }
+  }
+  if (bad && t == 0) *flag = 1;
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = a * 32 + ty, j = b * 32 + tx;
+      if (i < D && j < D) {
+        if (b <= a && j <= i) out[(size_t)i * ldout + j] = r[(a * (a + 1) / 2 + b) < NE ? a * (a + 1) / 2 + b : 0];
+        else out[(size_t)i * ldout + j] = 0.0;
+      }
+    }
+}
+
+int chol_small(plda_handle *h, const double *A, int D, int ldin, int64_t stride_in, double *out, int ldout,
+               int64_t stride_out, int *dflag, int batch) {
+  const int nb = (int)ceil_div(D, 32);
+#define CS(NBB) chol_small_kernel<NBB><<<batch, 1024, 0, h->stream>>>(A, D, ldin, stride_in, out, ldout, stride_out, dflag)
+  switch (nb) {
+    case 1: CS(1); break;
+    case 2: CS(2); break;
+    case 3: CS(3); break;
+    case 4: CS(4); break;
+    case 5: CS(5); break;
+    case 6: CS(6); break;
+    case 7: CS(7); break;
+    case 8: CS(8); break;
+    default: return fail(h, PLDA_E_INVAL, "chol_small: D=%d > 256 unsupported", D);
+  }
+#undef CS
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 __global__ void copy_block_kernel(const double *__restrict__ src, int lds, int64_t strides, double *__restrict__ dst,
                                   int ldd, int64_t strided, int rows, int cols, bool transpose) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -596,6 +690,32 @@ int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t
   PLDA_TRY(gemm_f64_batched(h, n1, n1, n2, -1.0, O12, ldo, 1, so, Y, 1, n2, sscr, nullptr, 1.0, O11, ldo, so, batch));
   copy_block_kernel<<<g12, 256, 0, h->stream>>>(O12, ldo, so, O21, ldo, so, n1, n2, true);
   PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// Whitening factor T (lower triangular, T A T^T = I, i.e. T = chol(A)^-1) of an SPD matrix of any size by
+// block elimination over the register-resident Cholesky:
+//   T11 = whiten(A11),  Y = T11 A12,  S = A22 - Y^T Y,  T22 = whiten(S),  T21 = -T22 Y^T T11.
+// `scr`: 2 n^2 doubles.
+int whiten_blocked(plda_handle *h, const double *A, int n, int lda, double *T, int ldt, double *scr, int *dflag) {
+  if (n <= 256) {
+    PLDA_TRY(chol_small(h, A, n, lda, 0, scr, n, 0, dflag, 1));
+    return tri_invert_ld(h, scr, T, n, ldt, 0, 1);
+  }
+  const int n1 = (int)round_up((int64_t)ceil_div(n, 2), 32), n2 = n - n1;
+  const double *A12 = A + n1, *A22 = A + (int64_t)n1 * lda + n1;
+  double *T11 = T, *T12 = T + n1, *T21 = T + (int64_t)n1 * ldt, *T22 = T + (int64_t)n1 * ldt + n1;
+  double *Y = scr, *S = Y + (int64_t)n1 * n2, *tmp = S + (int64_t)n2 * n2, *sub = tmp + (int64_t)n2 * n1;
+  PLDA_TRY(whiten_blocked(h, A, n1, lda, T11, ldt, sub, dflag));
+  PLDA_TRY(gemm_f64(h, n1, n2, n1, 1.0, T11, ldt, 1, A12, lda, 1, nullptr, 0.0, Y, n2));
+  copy_block_kernel<<<dim3((unsigned)ceil_div((int64_t)n2 * n2, 256), 1), 256, 0, h->stream>>>(A22, lda, 0, S, n2, 0,
+                                                                                           n2, n2, false);
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_TRY(gemm_f64(h, n2, n2, n1, -1.0, Y, 1, n2, Y, n2, 1, nullptr, 1.0, S, n2));
+  PLDA_TRY(whiten_blocked(h, S, n2, n2, T22, ldt, sub, dflag));
+  PLDA_TRY(gemm_f64(h, n2, n1, n1, 1.0, Y, 1, n2, T11, ldt, 1, nullptr, 0.0, tmp, n1));
+  PLDA_TRY(gemm_f64(h, n2, n1, n2, -1.0, T22, ldt, 1, tmp, n1, 1, nullptr, 0.0, T21, ldt));
+  PLDA_HIP(h, hipMemset2DAsync(T12, (size_t)ldt * 8, 0, (size_t)n2 * 8, (size_t)n1, h->stream));
   return PLDA_OK;
 }
 
@@ -1010,17 +1130,18 @@ __global__ void symmetrize_kernel(double *G, int D) {
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv,
                 double *psi, bool warm_start) {
   const size_t DD = (size_t)D * D;
-  const bool fresh = h->w[13].cap < DD * 8 * 5 + 64 || h->simdiag_D != D;
-  PLDA_HIP(h, h->w[13].reserve(DD * 8 * 5 + 64));
+  const size_t need = DD * 8 * 6 + 64;
+  const bool fresh = h->w[13].cap < need || h->simdiag_D != D;
+  PLDA_HIP(h, h->w[13].reserve(need));
   h->simdiag_D = D;
-  double *Cc = h->w[13].as<double>();
-  double *T1 = Cc + DD, *tmp = T1 + DD, *G = tmp + DD, *Vr = G + DD;   // Vr persists: next call's warm start
+  double *scr = h->w[13].as<double>();                                    // 2 DD: whitening scratch
+  double *T1 = scr + 2 * DD, *tmp = T1 + DD, *G = tmp + DD, *Vr = G + DD;   // Vr persists: next call's warm start
   int *dflag = reinterpret_cast<int *>(Vr + DD);
   const bool warm = warm_start && !fresh && h->simdiag_has_vr;
   PLDA_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(Cc, W, DD * 8, hipMemcpyDeviceToDevice, h->stream));
-  PLDA_TRY(cholesky_f64(h, Cc, D, dflag));
-  PLDA_TRY(tri_invert_f64(h, Cc, T1, D));
+  // T1 = chol(W)^-1.  (Any T1 with T1 W T1^T = I gives the same final transform up to row signs; this is
+  // the Cholesky one, as in the reference's GetOutput.)
+  PLDA_TRY(whiten_blocked(h, W, D, D, T1, D, scr, dflag));
   // tmp = T1 B ; G = tmp T1^T
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, T1, D, 1, B, D, 1, nullptr, 0.0, tmp, D));
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
@@ -1033,9 +1154,9 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
-  // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = C Vr^T
+  // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = T^-1 = W T^T (from T W T^T = I)
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));
-  if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Cc, D, 1, Vr, 1, D, nullptr, 0.0, Tinv, D));
+  if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, W, D, 1, T, 1, D, nullptr, 0.0, Tinv, D));
   return PLDA_OK;
 }
 
