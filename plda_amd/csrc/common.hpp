@@ -123,13 +123,11 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
              int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,
              const double *kw, double beta, double *C, int64_t ldc);
 // in-place lower Cholesky (upper triangle zeroed); *dflag (device int) set to 1 on failure
-int cholesky_f64(plda_handle *h, double *A, int D, int *dflag, int batch = 1);
 // X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
 int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
                     int *dflag, int batch);
 int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
                         int64_t so, double *scr, int64_t sscr, int *dflag, int batch);
-int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch = 1);
 // symmetric eigendecomposition of G (row-major, destroyed): eigenvalues sorted
 // descending in s[D] (floored at 0), eigenvectors in the ROWS of Vrows.
 int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,

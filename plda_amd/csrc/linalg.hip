@@ -3,13 +3,16 @@
 // These replace the Kaldi matrix-library / ATLAS calls that the reference reaches
 // through PldaStats / PldaEstimator: AddMat2 (syrk), AddMatMat
 // (gemm), AddMat2Sp (congruence), TpMatrix::Cholesky / Invert, SpMatrix::Eig + SortSvd.
-//   gemm_f64      v_mfma_f64_16x16x4_f64, LDS-staged 64x64 tiles, optional per-k
-//                 weights (weighted SYRK X^T diag(w) X), deterministic split-K
-//   cholesky_f64  right-looking, one workgroup, column staged in LDS
+//   gemm_f64      v_mfma_f64_16x16x4_f64: LDS-staged 64x64 or 128x128 tiles with register prefetch,
+//                 optional per-k weights (weighted SYRK X^T diag(w) X), deterministic split-K, batching;
+//                 a panel-resident 32x32 kernel for the small K <= 256 products of the EM
+//   chol_small / spd_inverse_small   Cholesky factor / SPD inverse with the matrix resident in the
+//                 registers of one workgroup (D <= 256); whiten_blocked / spd_inverse_blocked extend
+//                 them to any size by block elimination (GEMMs on the panel kernel)
 //   tri_invert    forward substitution, one wave per column, solution held in registers
-//   sym_eig_f64   one-sided (Hestenes) Jacobi with round-robin pair ordering, one
-//                 wave per row pair, one launch per tournament round; a sweep's launches
-//                 are replayed from a hipGraph; warm start from the previous eigenvectors
+//   sym_eig_f64   one-sided (Hestenes) block Jacobi: one workgroup per pair of 4-row blocks and outer
+//                 round (Gram matrix on the MFMA pipe, 8x8 two-sided sweep in one wave, one apply pass);
+//                 a sweep's launches are replayed from a hipGraph; optional warm start
 #include "common.hpp"
 
 #include <algorithm>
@@ -320,53 +323,6 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
 }
 
 // ------------------------------------------------------------------------------------
-// Cholesky (TpMatrix::Cholesky) -- one workgroup of 1024 threads
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void cholesky_kernel(double *__restrict__ A, int D, int *flag) {
-  extern __shared__ __attribute__((aligned(16))) double col[];  // [D]
-  __shared__ double sdiag;
-  const int t = threadIdx.x, nt = blockDim.x;
-  A += (size_t)blockIdx.x * D * D;   // one matrix per workgroup
-  for (int j = 0; j < D; ++j) {
-    if (t == 0) {
-      double d = A[(size_t)j * D + j];
-      if (!(d > 0.0)) { *flag = 1; d = 1.0; }
-      d = sqrt(d);
-      A[(size_t)j * D + j] = d;
-      sdiag = d;
-    }
-    __syncthreads();
-    const double inv = 1.0 / sdiag;
-    for (int i = j + 1 + t; i < D; i += nt) {
-      const double v = A[(size_t)i * D + j] * inv;
-      A[(size_t)i * D + j] = v;
-      col[i] = v;
-    }
-    __syncthreads();
-    // trailing update of the lower triangle: A[i][k] -= col[i] col[k], j < k <= i
-    const int rem = D - j - 1;
-    const int tx = t & 31, ty = t >> 5, ny = nt >> 5;
-    for (int ii = ty; ii < rem; ii += ny) {
-      const int i = j + 1 + ii;
-      const double ci = col[i];
-      double *row = A + (size_t)i * D;
-      for (int k = j + 1 + tx; k <= i; k += 32) row[k] -= ci * col[k];
-    }
-    __syncthreads();
-  }
-  for (int idx = t; idx < D * D; idx += nt) {
-    const int i = idx / D, k = idx % D;
-    if (k > i) A[idx] = 0.0;
-  }
-}
-
-int cholesky_f64(plda_handle *h, double *A, int D, int *dflag, int batch) {
-  cholesky_kernel<<<batch, 1024, (size_t)D * 8, h->stream>>>(A, D, dflag);
-  PLDA_LAUNCH_CHECK(h);
-  return PLDA_OK;
-}
-
-// ------------------------------------------------------------------------------------
 // triangular inverse (TpMatrix::Invert): one WAVE per column j of X = L^{-1}.
 // Forward substitution x_i = (delta_ij - sum_{k=j}^{i-1} L[i][k] x_k) / L[i][i]; lane l keeps
 // x_k for k = l (mod 64) in registers, so the dot product is E coalesced loads of row i of
@@ -415,10 +371,6 @@ int tri_invert_ld(plda_handle *h, const double *L, double *X, int D, int ldx, in
 #undef TI
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
-}
-
-int tri_invert_f64(plda_handle *h, const double *L, double *X, int D, int batch) {
-  return tri_invert_ld(h, L, X, D, D, (int64_t)D * D, batch);
 }
 
 // fp64 reciprocal / reciprocal square root: hardware estimate refined by Newton steps to full
