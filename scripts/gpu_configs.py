@@ -255,7 +255,26 @@ def lda_c2():
     return res
 
 
-for name, fn in (("C3", c3), ("lda", lda_c2), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
+def vendor_sgemm():
+    """Yardstick only (not part of the product): the vendor fp32 GEMM (torch.mm -> hipBLASLt / rocBLAS) on the
+    C2 trials shape, 100k x 200 @ 200 x 100k -> 100k x 100k fp32, without the bias terms the trials kernel fuses."""
+    M = Nt = 100_000
+    res = {}
+    for D in (200, 150, 512):
+        m = M if D != 512 else 10_000
+        n = Nt if D != 512 else 1_000_000
+        a = torch.randn((m, D), dtype=torch.float32, device=dev)
+        b = torch.randn((n, D), dtype=torch.float32, device=dev)
+        out = torch.empty((m, n), dtype=torch.float32, device=dev)
+        s = timed(lambda: torch.mm(a, b.T, out=out), 3)
+        res["D%d_ms" % D] = 1e3 * s
+        res["D%d_tflops" % D] = 2.0 * D * m * n / s / 1e12
+        del a, b, out
+        torch.cuda.empty_cache()
+    return res
+
+
+for name, fn in (("C3", c3), ("lda", lda_c2), ("vendor_sgemm", vendor_sgemm), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     t0 = time.perf_counter()
