@@ -179,6 +179,24 @@ int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, in
                           const int64_t *doffsets, int64_t U, int32_t method, int32_t l2norm,
                           double *dout);
 
+/* ---- HTK feature files (the data format in front of the path): replaces the reference's reader
+ * chtk::htk_load (chtk/chtk.cpp:38-88, called at src/kaldi-utils.hpp:22; header layout
+ * chtk/chtk.h:52-57).  A call decodes a BATCH of U files whose DATA sections (everything after
+ * the 12-byte header) sit in one blob: file u starts at 32-bit word file_off[u] of the blob and
+ * has frame_off[u+1] - frame_off[u] frames of `samplesize` bytes (a multiple of 4); a file
+ * shorter than its header claims must be zero-padded to that size, which is what the
+ * reference's zero-initialised read buffer yields (chtk.cpp:56-57).  out [T, (2 frm_ext + 1) *
+ * samplesize / 4] float32, T = frame_off[U]: every word byte-swapped (big-endian floats), frame
+ * i = frames clamp(i - frm_ext .. i + frm_ext, 0, n - 1) of its file concatenated (:71-86).
+ * Bit-exact with the reference; the output feeds plda_dvector_pool_dev with the same
+ * frame_off. ---- */
+int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const int64_t *file_off,
+                    const int64_t *frame_off, int64_t U, int32_t samplesize, int32_t frm_ext,
+                    float *out);
+int plda_htk_frames_dev(plda_handle *h, const void *dblob, const int64_t *dfile_off,
+                        const int64_t *dframe_off, int64_t U, int64_t T, int32_t samplesize,
+                        int32_t frm_ext, float *dout);
+
 /* ---- equal error rate (the step after the path): replaces scoring/eer.py:68-73
  * (bob.measure.eer_threshold + farfrr; bob is absent and un-pinned, its published
  * definition is restated: FAR = #{impostor >= t}/Nn, FRR = #{target < t}/Np, t = the

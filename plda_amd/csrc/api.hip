@@ -672,6 +672,43 @@ int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, in
   return PLDA_OK;
 }
 
+// ---------------------------------------------------------------- HTK feature files
+int plda_htk_frames_dev(plda_handle *h, const void *dblob, const int64_t *dfile_off, const int64_t *dframe_off,
+                        int64_t U, int64_t T, int32_t samplesize, int32_t frm_ext, float *dout) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_TRY(set_device(h));
+  return htk_frames_device(h, dblob, dfile_off, dframe_off, U, T, samplesize, frm_ext, dout);
+}
+
+int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const int64_t *file_off,
+                    const int64_t *frame_off, int64_t U, int32_t samplesize, int32_t frm_ext, float *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (U <= 0) return PLDA_OK;
+  if (!blob || !file_off || !frame_off || !out || blob_bytes < 0 || samplesize <= 0 || frm_ext < 0)
+    return fail(h, PLDA_E_INVAL, "htk_frames: bad argument");
+  if (samplesize % 4) return fail(h, PLDA_E_INVAL, "htk_frames: samplesize %d is not a multiple of 4", samplesize);
+  const int64_t W = samplesize / 4;
+  for (int64_t u = 0; u < U; ++u) {
+    const int64_t n = frame_off[u + 1] - frame_off[u];
+    if (n < 0 || file_off[u] < 0 || (file_off[u] + n * W) * 4 > blob_bytes)
+      return fail(h, PLDA_E_INVAL, "htk_frames: file %lld does not fit the blob (pad short files with zeros)", (long long)u);
+  }
+  const int64_t T = frame_off[U] - frame_off[0];
+  if (frame_off[0] != 0) return fail(h, PLDA_E_INVAL, "htk_frames: frame_off[0] must be 0");
+  if (T <= 0) return PLDA_OK;
+  PLDA_TRY(set_device(h));
+  Tmp dB, dF, dO, dOut;
+  PLDA_TRY(upload(h, dB, blob, (size_t)blob_bytes));
+  PLDA_TRY(upload(h, dF, file_off, (size_t)U * 8));
+  PLDA_TRY(upload(h, dO, frame_off, (size_t)(U + 1) * 8));
+  const size_t obytes = (size_t)T * (2 * frm_ext + 1) * samplesize;
+  PLDA_HIP(h, dOut.alloc(obytes));
+  PLDA_TRY(htk_frames_device(h, dB.p, dF.as<int64_t>(), dO.as<int64_t>(), U, T, samplesize, frm_ext, dOut.as<float>()));
+  PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, obytes, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
 // ---------------------------------------------------------------- EER
 int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
                         const int64_t *denrol_spk, const int64_t *dtest_spk, double *out) {

@@ -138,6 +138,8 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
                 double *Tinv, double *psi, bool warm_start);
 
 // ---- frontend.hip ----
+int htk_frames_device(plda_handle *h, const void *dblob, const int64_t *dfile_off, const int64_t *dframe_off,
+                      int64_t U, int64_t T, int samplesize, int frm_ext, float *dout);
 int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t T, int D,
                         const int64_t *doffsets, int64_t U, int method, int l2norm, double *dout);
 

@@ -194,4 +194,52 @@ int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t 
   return PLDA_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// HTK feature files (the data format in front of the path): replaces the reference's reader
+// chtk::htk_load (/root/reference/chtk/chtk.cpp:38-88; used at src/kaldi-utils.hpp:22).  HBM-bound byte
+// work: every 32-bit word of a frame is byte-swapped (big-endian floats) and frame i of the output is the
+// concatenation of the file's frames clamp(i - F .. i + F, 0, n - 1).  A call decodes a whole BATCH of
+// files from one blob (the data sections, 4-byte aligned, short files zero-padded by the caller the way
+// the reference's zero-initialised read buffer behaves): one wave per output frame; the wave locates its
+// file by a uniform binary search of the frame offsets, lanes stride over the frame's words.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void htk_frames_kernel(const uint32_t *__restrict__ blob,
+                                                         const int64_t *__restrict__ file_off,
+                                                         const int64_t *__restrict__ frame_off, int64_t U, int64_t T,
+                                                         int W, int F, uint32_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  int64_t lo = 0, hi = U - 1;          // largest u with frame_off[u] <= t
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (frame_off[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  const int64_t f0 = frame_off[lo], n = frame_off[lo + 1] - f0, i = t - f0;
+  const uint32_t *src = blob + file_off[lo];
+  const int rowW = (2 * F + 1) * W;
+  uint32_t *dst = out + t * rowW;
+  for (int o = lane; o < rowW; o += 64) {
+    const int jj = o / W, w = o - jj * W;
+    int64_t fr = i + jj - F;
+    fr = fr < 0 ? 0 : (fr > n - 1 ? n - 1 : fr);
+    dst[o] = __builtin_bswap32(src[fr * W + w]);
+  }
+}
+
+int htk_frames_device(plda_handle *h, const void *dblob, const int64_t *dfile_off, const int64_t *dframe_off,
+                      int64_t U, int64_t T, int samplesize, int frm_ext, float *dout) {
+  if (U <= 0 || T <= 0) return PLDA_OK;
+  if (!dblob || !dfile_off || !dframe_off || !dout || samplesize <= 0 || frm_ext < 0)
+    return fail(h, PLDA_E_INVAL, "htk_frames: bad argument");
+  if (samplesize % 4) return fail(h, PLDA_E_INVAL, "htk_frames: samplesize %d is not a multiple of 4", samplesize);
+  if ((reinterpret_cast<uintptr_t>(dblob) & 3) != 0) return fail(h, PLDA_E_INVAL, "htk_frames: blob must be 4-byte aligned");
+  if (ceil_div(T, 4) > 0x7fffffffLL) return fail(h, PLDA_E_INVAL, "htk_frames: too many frames in one call");
+  htk_frames_kernel<<<(unsigned)ceil_div(T, 4), 256, 0, h->stream>>>(
+      static_cast<const uint32_t *>(dblob), dfile_off, dframe_off, U, T, samplesize / 4, frm_ext,
+      reinterpret_cast<uint32_t *>(dout));
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 }  // namespace plda

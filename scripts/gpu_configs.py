@@ -255,6 +255,31 @@ def lda_c2():
     return res
 
 
+def htk_decode():
+    """HTK reader row: 20k files, 5M frames, decoded from device-resident bytes (algorithmic bytes = read the
+    file bodies once + write the float32 output once)."""
+    from plda_amd import MPlda as _M
+    eng = _M(0)
+    res = {}
+    for dim, F in ((40, 0), (40, 5), (256, 0), (257, 1)):
+        U = 20000
+        g = torch.Generator(device="cpu").manual_seed(5)
+        counts = torch.randint(100, 400, (U,), generator=g)
+        off = torch.zeros(U + 1, dtype=torch.int64); off[1:] = torch.cumsum(counts, 0)
+        T = int(off[-1])
+        blob = torch.randint(0, 2 ** 31 - 1, (T * dim,), dtype=torch.int32, device=dev)
+        file_off = (off[:-1] * dim).to(dev); doff = off.to(dev)
+        out = torch.empty((T, (2 * F + 1) * dim), dtype=torch.float32, device=dev)
+        run = lambda: eng._ck(eng._lib.plda_htk_frames_dev(eng._h, blob.data_ptr(), file_off.data_ptr(), doff.data_ptr(), U, T,
+                                                           dim * 4, F, out.data_ptr()))
+        s = timed(run, 5)
+        byts = T * dim * 4 * (1 + (2 * F + 1))
+        res["dim%d_F%d" % (dim, F)] = {"ms": 1e3 * s, "GBps": byts / s / 1e9, "frames": T}
+        del blob, out
+        torch.cuda.empty_cache()
+    return res
+
+
 def vendor_sgemm():
     """Yardstick only (not part of the product): the vendor fp32 GEMM (torch.mm -> hipBLASLt / rocBLAS) on the
     C2 trials shape, 100k x 200 @ 200 x 100k -> 100k x 100k fp32, without the bias terms the trials kernel fuses."""
@@ -274,7 +299,7 @@ def vendor_sgemm():
     return res
 
 
-for name, fn in (("C3", c3), ("lda", lda_c2), ("vendor_sgemm", vendor_sgemm), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
+for name, fn in (("C3", c3), ("lda", lda_c2), ("vendor_sgemm", vendor_sgemm), ("htk", htk_decode), ("C4_shard", c4_shard), ("C5", c5), ("frontend", frontend), ("C2_skew", c2_skew), ("pcie", pcie), ("eer", eer_full)):
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         continue
     t0 = time.perf_counter()
