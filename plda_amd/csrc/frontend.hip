@@ -9,6 +9,8 @@
 // DPP wave reduction; the per-wave partial (sum, sum of squares, max) meet in LDS.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace plda {
 
 constexpr int DV_MAXE = 16;   // D <= 1024
@@ -203,27 +205,80 @@ int dvector_pool_device(plda_handle *h, const void *dframes, int dtype, int64_t 
 // the reference's zero-initialised read buffer behaves): one wave per output frame; the wave locates its
 // file by a uniform binary search of the frame offsets, lanes stride over the frame's words.
 // ------------------------------------------------------------------------------------
+constexpr int HTK_MAX_FR = 256;   // output frames per workgroup (upper bound)
+
+// One workgroup per chunk of FR consecutive output frames (about 32 KiB of output).  Wave 0 locates the
+// chunk's first file with a 64-ary search of the frame offsets (three dependent probes for 2.6e5 files
+// instead of eighteen), every frame then walks forward from there; (source base, frame index, frame count)
+// per frame go to LDS and the copy loop runs over 16-byte vectors when the frame size and the file's
+// placement allow it, over single words otherwise.
 __global__ __launch_bounds__(256) void htk_frames_kernel(const uint32_t *__restrict__ blob,
                                                          const int64_t *__restrict__ file_off,
                                                          const int64_t *__restrict__ frame_off, int64_t U, int64_t T,
-                                                         int W, int F, uint32_t *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
-  int64_t lo = 0, hi = U - 1;          // largest u with frame_off[u] <= t
-  while (lo < hi) {
-    const int64_t mid = (lo + hi + 1) >> 1;
-    if (frame_off[mid] <= t) lo = mid; else hi = mid - 1;
+                                                         int W, int F, int FR, int vec_ok, uint32_t *__restrict__ out) {
+  __shared__ int64_t s_base[HTK_MAX_FR];
+  __shared__ int s_i[HTK_MAX_FR], s_n[HTK_MAX_FR];
+  __shared__ int64_t s_u0;
+  const int t = threadIdx.x, lane = t & 63;
+  const int64_t t0 = (int64_t)blockIdx.x * FR;
+  const int nfr = (int)min<int64_t>(FR, T - t0);
+  if (t < 64) {
+    // largest u in [0, U-1] with frame_off[u] <= t0
+    int64_t lo = 0, hi = U - 1;
+    while (lo < hi) {
+      const int64_t span = hi - lo, step = (span + 63) / 64;       // probes lo + (l+1) * step, clipped to hi
+      const int64_t p = min(lo + (int64_t)(lane + 1) * step, hi);
+      const unsigned long long ok = __ballot(frame_off[p] <= t0);
+      const int cnt = __popcll(ok);                                 // monotone: the first cnt probes satisfy it
+      const int64_t nlo = cnt == 0 ? lo : min(lo + (int64_t)cnt * step, hi);
+      const int64_t nhi = cnt == 64 ? hi : min(lo + (int64_t)(cnt + 1) * step, hi) - 1;
+      lo = nlo;
+      hi = max(nlo, nhi);
+    }
+    if (lane == 0) s_u0 = lo;
   }
-  const int64_t f0 = frame_off[lo], n = frame_off[lo + 1] - f0, i = t - f0;
-  const uint32_t *src = blob + file_off[lo];
+  __syncthreads();
+  for (int j = t; j < nfr; j += 256) {
+    int64_t u = s_u0;
+    const int64_t tt = t0 + j;
+    while (u + 1 < U && frame_off[u + 1] <= tt) ++u;               // also steps over empty files
+    const int64_t f0 = frame_off[u];
+    s_base[j] = file_off[u];
+    s_i[j] = (int)(tt - f0);
+    s_n[j] = (int)(frame_off[u + 1] - f0);
+  }
+  __syncthreads();
   const int rowW = (2 * F + 1) * W;
-  uint32_t *dst = out + t * rowW;
-  for (int o = lane; o < rowW; o += 64) {
-    const int jj = o / W, w = o - jj * W;
-    int64_t fr = i + jj - F;
-    fr = fr < 0 ? 0 : (fr > n - 1 ? n - 1 : fr);
-    dst[o] = __builtin_bswap32(src[fr * W + w]);
+  uint32_t *dst = out + t0 * rowW;
+  if (vec_ok) {
+    const int Wv = W >> 2, rowV = rowW >> 2, total = nfr * rowV;
+#pragma unroll 4
+    for (int e = t; e < total; e += 256) {
+      const int fl = e / rowV, o = e - fl * rowV;
+      const int64_t base = s_base[fl];
+      if (base & 3) continue;                                       // unaligned file: word loop below
+      const int jj = o / Wv, wv = o - jj * Wv;
+      int fr = s_i[fl] + jj - F;
+      fr = fr < 0 ? 0 : (fr > s_n[fl] - 1 ? s_n[fl] - 1 : fr);
+      uint4 v = *reinterpret_cast<const uint4 *>(blob + base + (int64_t)fr * W + wv * 4);
+      v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
+      v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+      *reinterpret_cast<uint4 *>(dst + (int64_t)e * 4) = v;
+    }
+  }
+  {
+    const int total = nfr * rowW;
+    const bool vec = vec_ok != 0;
+#pragma unroll 4
+    for (int e = t; e < total; e += 256) {
+      const int fl = e / rowW, o = e - fl * rowW;
+      const int64_t base = s_base[fl];
+      if (vec && (base & 3) == 0) continue;                         // done by the vector loop
+      const int jj = o / W, w = o - jj * W;
+      int fr = s_i[fl] + jj - F;
+      fr = fr < 0 ? 0 : (fr > s_n[fl] - 1 ? s_n[fl] - 1 : fr);
+      dst[e] = __builtin_bswap32(blob[base + (int64_t)fr * W + w]);
+    }
   }
 }
 
@@ -234,9 +289,17 @@ int htk_frames_device(plda_handle *h, const void *dblob, const int64_t *dfile_of
     return fail(h, PLDA_E_INVAL, "htk_frames: bad argument");
   if (samplesize % 4) return fail(h, PLDA_E_INVAL, "htk_frames: samplesize %d is not a multiple of 4", samplesize);
   if ((reinterpret_cast<uintptr_t>(dblob) & 3) != 0) return fail(h, PLDA_E_INVAL, "htk_frames: blob must be 4-byte aligned");
-  if (ceil_div(T, 4) > 0x7fffffffLL) return fail(h, PLDA_E_INVAL, "htk_frames: too many frames in one call");
-  htk_frames_kernel<<<(unsigned)ceil_div(T, 4), 256, 0, h->stream>>>(
-      static_cast<const uint32_t *>(dblob), dfile_off, dframe_off, U, T, samplesize / 4, frm_ext,
+  const int W = samplesize / 4;
+  const int64_t rowW = (int64_t)(2 * frm_ext + 1) * W;
+  if (rowW > (1 << 20)) return fail(h, PLDA_E_INVAL, "htk_frames: output frame of %lld words unsupported", (long long)rowW);
+  const int FR = (int)std::min<int64_t>(HTK_MAX_FR, std::max<int64_t>(1, 8192 / rowW));
+  if (ceil_div(T, FR) > 0x7fffffffLL) return fail(h, PLDA_E_INVAL, "htk_frames: too many frames in one call");
+  // 16-byte path: frame size a multiple of 16 bytes and 16-byte aligned blob / output (files whose data
+  // section is not 16-byte aligned inside the blob fall back to words individually)
+  const int vec_ok = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dblob) & 15) == 0;
+  htk_frames_kernel<<<(unsigned)ceil_div(T, FR), 256, 0, h->stream>>>(
+      static_cast<const uint32_t *>(dblob), dfile_off, dframe_off, U, T, W, frm_ext, FR, vec_ok,
       reinterpret_cast<uint32_t *>(dout));
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;

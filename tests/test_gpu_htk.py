@@ -110,3 +110,37 @@ def test_htk_large_batch_round_trip():
         idx = np.clip(np.arange(i - F, i + F + 1), 0, b - a - 1) + a
         want = x[idx].reshape(-1)
         assert torch.equal(outF[a + i].cpu().view(torch.int32), want.view(torch.int32))
+
+
+def test_htk_unaligned_file_placement_and_empty_files():
+    """Files whose data section is not 16-byte aligned inside the blob take the word path inside the same
+    launch; empty files in the middle of a batch are stepped over."""
+    import torch
+    from oracle import htk_oracle_np as ho
+    from plda_amd import MPlda
+    import struct
+    dev = torch.device("cuda:0")
+    eng = MPlda(0)
+    rng = np.random.default_rng(9)
+    dim, F = 8, 1
+    counts = [5, 0, 0, 33, 1, 0, 12]
+    pads = [0, 0, 0, 1, 3, 0, 2]                       # words of junk in front of each file's data
+    words, file_off, want = [], [], []
+    pos = 0
+    for n, pad in zip(counts, pads):
+        words.append(rng.integers(0, 2 ** 32, pad, dtype=np.uint32)); pos += pad
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        body = x.astype(">f4").view(np.uint32).reshape(-1)
+        file_off.append(pos); words.append(body); pos += body.size
+        raw = struct.pack(">IIHH", n, 1, dim * 4, 9) + body.tobytes()
+        want.append(ho.htk_load(raw, F))
+    blob = torch.from_numpy(np.concatenate(words).astype(np.uint32).view(np.int32)).to(dev)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    T = int(off[-1])
+    out = torch.empty((T, 3 * dim), dtype=torch.float32, device=dev)
+    dfo = torch.tensor(file_off, dtype=torch.int64, device=dev)
+    doff = torch.from_numpy(off).to(dev)
+    eng._ck(eng._lib.plda_htk_frames_dev(eng._h, blob.data_ptr(), dfo.data_ptr(), doff.data_ptr(), len(counts), T, dim * 4, F,
+                                         out.data_ptr()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), np.concatenate(want))
