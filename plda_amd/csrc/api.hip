@@ -133,6 +133,7 @@ int plda_destroy(plda_handle *h) {
                     &h->l_coef, &h->l_intercept, &h->l_evr};
   for (DevBuf *b : bufs) b->release();
   for (auto &b : h->w) b.release();
+  if (h->one_host) (void)hipHostFree(h->one_host);
   if (h->jac_exec) (void)hipGraphExecDestroy(h->jac_exec);
   for (auto &ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -469,6 +470,37 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
     if (n_enrol[i] <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: num_examples must be > 0");
   PLDA_TRY(set_device(h));
   const int D = h->Dout;
+  if (P == 1 && M == 1 && Nt == 1) {
+    // One trial -- the reference's MPlda_score call (pldamodule.cpp:258-277).  No allocation and no copy
+    // engine: the operands go into a host buffer that is mapped into the GPU's address space, the kernel
+    // reads them and writes the score back through that mapping, and one stream synchronisation ends the call.
+    const size_t need = ((size_t)2 * D + 8) * 8;
+    if (h->one_cap < need) {
+      if (h->one_host) (void)hipHostFree(h->one_host);
+      h->one_host = nullptr; h->one_cap = 0;
+      PLDA_HIP(h, hipHostMalloc(&h->one_host, need, hipHostMallocMapped));
+      PLDA_HIP(h, hipHostGetDevicePointer(&h->one_dev, h->one_host, 0));
+      h->one_cap = need;
+    }
+    double *hb = static_cast<double *>(h->one_host);
+    double *db = static_cast<double *>(h->one_dev);
+    // layout: u[D] v[D] zmean zstd out | e_idx t_idx (int64) | n (int32)
+    std::memcpy(hb, U, (size_t)D * 8);
+    std::memcpy(hb + D, V, (size_t)D * 8);
+    const bool zn1 = zmean && zstd;
+    hb[2 * D] = zn1 ? zmean[0] : 0.0;
+    hb[2 * D + 1] = zn1 ? zstd[0] : 0.0;
+    int64_t *hi = reinterpret_cast<int64_t *>(hb + 2 * D + 3);
+    hi[0] = 0; hi[1] = 0;
+    *reinterpret_cast<int32_t *>(hb + 2 * D + 5) = n_enrol[0];
+    PLDA_TRY(score_pairs_device(h, db, reinterpret_cast<const int32_t *>(db + 2 * D + 5), db + D,
+                                reinterpret_cast<const int64_t *>(db + 2 * D + 3),
+                                reinterpret_cast<const int64_t *>(db + 2 * D + 4), 1, zn1 ? db + 2 * D : nullptr,
+                                zn1 ? db + 2 * D + 1 : nullptr, db + 2 * D + 2));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    out[0] = hb[2 * D + 2];
+    return PLDA_OK;
+  }
   Tmp dU, dN, dV, dE, dT, dZm, dZs, dO;
   PLDA_TRY(upload(h, dU, U, (size_t)M * D * 8));
   PLDA_TRY(upload(h, dN, n_enrol, (size_t)M * 4));

@@ -54,6 +54,10 @@ struct plda_handle {
   int64_t lda_K = 0;
   plda::DevBuf l_means, l_priors, l_xbar, l_scalings, l_coef, l_intercept, l_evr;
 
+  // ---- one-trial score(): host buffer mapped into the device address space ----
+  void *one_host = nullptr, *one_dev = nullptr;
+  size_t one_cap = 0;
+
   // ---- scoring workspace ----
   plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias;
   int64_t last_M = 0, last_Nt = 0;

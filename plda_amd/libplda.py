@@ -79,6 +79,7 @@ class MPlda(object):
     # ------------------------------------------------------------------ fit
     def fit(self, x, y, iters=10):
         """MPlda_fit (pldamodule.cpp:42-109).  Returns None."""
+        self._dout = None            # the model dimension may change
         X = _features(x)
         n, d = X.shape
         Y = _labels(y, n)
@@ -125,6 +126,7 @@ class MPlda(object):
         return dict(mean=mean, transform=T, psi=psi, offset=off)
 
     def set_model(self, mean, transform, psi):
+        self._dout = None            # the model dimension may change
         mean = np.ascontiguousarray(mean, np.float64)
         T = np.ascontiguousarray(transform, np.float64)
         psi = np.ascontiguousarray(psi, np.float64)
@@ -149,6 +151,7 @@ class MPlda(object):
 
     def truncate(self, targetdim):
         """Build extension 'targetdim' (SURVEY.md Appendix B Q3): keep the top-psi rows."""
+        self._dout = None            # the model dimension may change
         self._ck(self._lib.plda_truncate(self._h, int(targetdim)))
 
     def smooth(self, factor):
@@ -240,21 +243,35 @@ class MPlda(object):
         against test `yvec=(n, vec)`, z-normalised if `target` has statistics."""
         if not isinstance(xvec, tuple) or not isinstance(yvec, tuple):
             raise TypeError("score(target, (n, vec), (n, vec)): enrol model and test must be tuples")
-        n = np.array([int(xvec[0])], np.int32)
-        u = np.ascontiguousarray(np.asarray(xvec[1], np.float64).reshape(1, -1))
-        v = np.ascontiguousarray(np.asarray(yvec[1], np.float64).reshape(1, -1))
-        dout, _ = self.dims()
-        if u.shape[1] != dout or v.shape[1] != dout:
+        # one trial per call is latency, not throughput: the per-call scratch arrays are kept on the object and
+        # the library's one-trial path (plda_score_pairs with M = Nt = P = 1) copies nothing through the copy engine
+        sc = self.__dict__.get("_score_scratch")
+        if sc is None:
+            sc = self._score_scratch = (np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1), np.zeros(1), np.zeros(1))
+        n, zero, out, zm, zs = sc
+        n[0] = int(xvec[0])
+        u, v = xvec[1], yvec[1]
+        if not (type(u) is np.ndarray and u.dtype == np.float64 and u.ndim == 1 and u.flags.c_contiguous):
+            u = np.ascontiguousarray(np.asarray(u, np.float64).reshape(-1))
+        if not (type(v) is np.ndarray and v.dtype == np.float64 and v.ndim == 1 and v.flags.c_contiguous):
+            v = np.ascontiguousarray(np.asarray(v, np.float64).reshape(-1))
+        dout = self._dout_cached()
+        if u.shape[0] != dout or v.shape[0] != dout:
             raise ValueError("score: vectors must have the model dimension %d" % dout)
-        zero = np.zeros(1, np.int64)
-        out = np.zeros(1)
-        zm = zs = None
         t = int(target)
-        if t in self._meanz:
-            zm, zs = np.array([self._meanz[t]]), np.array([self._stdvz[t]])
-        self._ck(self._lib.plda_score_pairs(self._h, _ptr(u), _ptr(n), 1, _ptr(v), 1, _ptr(zero), _ptr(zero), 1,
-                                            _ptr(zm), _ptr(zs), _ptr(out)))
+        has_z = t in self._meanz
+        if has_z:
+            zm[0], zs[0] = self._meanz[t], self._stdvz[t]
+        self._ck(self._lib.plda_score_pairs(self._h, u.ctypes.data, n.ctypes.data, 1, v.ctypes.data, 1, zero.ctypes.data,
+                                            zero.ctypes.data, 1, zm.ctypes.data if has_z else None,
+                                            zs.ctypes.data if has_z else None, out.ctypes.data))
         return float(out[0])
+
+    def _dout_cached(self):
+        d = self.__dict__.get("_dout")
+        if d is None:
+            d = self._dout = self.dims()[0]
+        return d
 
     def _unpack(self, side):
         """dict {id: (n, vec)} or (counts, vecs[, ids]) -> ids, counts(int32), vecs."""
@@ -326,6 +343,7 @@ class MPlda(object):
         return ms.value, n.value, fl.value
 
     def fit_dev(self, dX, n, d, dlabels, k, iters=10):
+        self._dout = None            # the model dimension may change
         self._ck(self._lib.plda_fit_dev(self._h, C.c_void_p(int(dX)), int(n), int(d), C.c_void_p(int(dlabels)),
                                         int(k), int(iters)))
 
@@ -341,6 +359,7 @@ class MPlda(object):
 
     def fit_em_dev(self, dmeans, dcounts, k, dscatter, d, iters=10):
         """EM + GetOutput (pldamodule.cpp:102-106) on merged statistics."""
+        self._dout = None            # the model dimension may change
         rc = self._lib.plda_fit_em_dev(self._h, C.c_void_p(int(dmeans)), C.c_void_p(int(dcounts)), int(k),
                                        C.c_void_p(int(dscatter)), int(d), int(iters))
         if rc == -2:
