@@ -20,7 +20,8 @@
 namespace plda {
 
 __device__ __forceinline__ unsigned score_key(float f) {
-  const unsigned u = __float_as_uint(f);
+  unsigned u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;      // -0.0 == +0.0 as scores: one candidate threshold, not two
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone: a < b  <=>  key(a) < key(b)
 }
 static inline float key_score(unsigned k) {
@@ -185,11 +186,14 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
   if (k0 < 0 && (Pb + Nb) > 0) k0 = hb[0];
   for (int b = b2 + 1; b < 1024; ++b) if (last[b] | last[EER_BINS + b]) { k2 = (long long)((k1 & ~1023u) | (unsigned)b); break; }
   if (k2 < 0 && (Pb + cP + Nb + cN) < (Np + Nn)) k2 = hb[1];
-  // g(k1) = (Pb + cP)/Np - (Nn - Nb - cN)/Nn >= 0 ; g(prev) = Pb/Np - (Nn - Nb)/Nn < 0 (prev = k0, or the start)
-  const long double g1 = (long double)(Pb + cP) / Np - (long double)(Nn - Nb - cN) / Nn;
-  const long double g0 = (long double)Pb / Np - (long double)(Nn - Nb) / Nn;
+  // g(k1) = (Pb + cP)/Np - (Nn - Nb - cN)/Nn >= 0 ; g(prev) = Pb/Np - (Nn - Nb)/Nn < 0 (prev = k0, or the start).
+  // The choice between the two candidates is made on |FAR - FRR| formed in float64 from the float64 rates,
+  // exactly as the definition evaluates it (an exact tie such as 393/400 vs 394/400 around 787/800 must
+  // stay a tie and go to the later candidate; extended precision breaks it the other way).
+  const double far1 = (double)(Nn - Nb - cN) / (double)Nn, frr1 = (double)(Pb + cP) / (double)Np;
+  const double far0 = (double)(Nn - Nb) / (double)Nn, frr0 = (double)Pb / (double)Np;
   double thr, far, frr;
-  if (fabsl(g1) <= fabsl(g0)) {                     // later candidate wins ties
+  if (fabs(far1 - frr1) <= fabs(far0 - frr0)) {     // later candidate wins ties
     const double s = key_score(k1);
     thr = k2 >= 0 ? s + ((double)key_score((unsigned)k2) - s) / 2.0 : s + 1e-8;
     far = (double)(Nn - Nb - cN) / (double)Nn; frr = (double)(Pb + cP) / (double)Np;
