@@ -118,6 +118,8 @@ def get_output(st, W, B):
 
 def transform_ivector(model, x, n, normalize_length=True, simple_length_norm=False):
     x = _f64(x)
+    if x.ndim != 1:
+        raise ValueError("transform_ivector takes ONE vector [D]; use plda_oracle_np.transform_ivector for batches")
     D = x.shape[0]
     out = np.zeros(D)
     lib().plda_oracle_transform_ivector(_d(_f64(model["transform"])), _d(_f64(model["offset"])),

@@ -694,7 +694,9 @@ __global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ 
   if (blockIdx.x == 0) { bp = nm1; bq = oround; }
   else { bp = (oround + blockIdx.x) % nm1; bq = (oround - (int)blockIdx.x + nm1) % nm1; }
   if (bp > bq) { const int tt = bp; bp = bq; bq = tt; }
-  if (bq * JB >= D) return;   // bye: the partner block does not exist
+  // bye (the partner block does not exist): the rows of bq are treated as missing and the workgroup still
+  // runs the INTRA-block pairs of bp -- with a single block (D <= 4) that is the only place they are rotated
+  if (bp * JB >= D) return;
   double *lA = rows, *lV = rows + 2 * JB * D;
   // global row of local row r (r < JB: block bp, else block bq); rows >= D do not exist
   auto grow = [&](int r) { return (r < JB ? bp * JB + r : bq * JB + (r - JB)); };
@@ -796,7 +798,9 @@ __global__ __launch_bounds__(256) void jacobi_gram_kernel(double *__restrict__ A
   if (blockIdx.x == 0) { bp = nm1; bq = oround; }
   else { bp = (oround + blockIdx.x) % nm1; bq = (oround - (int)blockIdx.x + nm1) % nm1; }
   if (bp > bq) { const int tt = bp; bp = bq; bq = tt; }
-  if (bq * JB >= D) return;   // bye: the partner block does not exist
+  // bye (the partner block does not exist): the rows of bq are treated as missing and the workgroup still
+  // runs the INTRA-block pairs of bp -- with a single block (D <= 4) that is the only place they are rotated
+  if (bp * JB >= D) return;
   constexpr int NP = 2 * JB;  // 8 rows
   double *lA = rows, *lV = rows + NP * D;
   auto grow = [&](int r) { return (r < JB ? bp * JB + r : bq * JB + (r - JB)); };

@@ -23,6 +23,10 @@ CASES = [
     (3, 60, 6, 5, True, 0.0),         # tiny, unequal n_k
     (4, 3000, 64, 100, True, 0.5),    # many distinct n_k, real speaker structure
     (5, 1200, 33, 40, True, 0.2),     # odd D (Jacobi bye round, tile edges)
+    (6, 615, 3, 32, False, 1.0),      # D <= 4: a single Jacobi block, rotated only inside the bye workgroup
+    (7, 400, 2, 9, True, 0.5),
+    (8, 500, 4, 12, True, 0.7),
+    (9, 300, 1, 7, True, 0.3),
 ]
 
 
