@@ -16,6 +16,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 namespace plda {
 
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(256) void jacobi_gram_kernel(double *__restrict__ A
       mj_t[ir] = j == NP - 1 ? ir : (j == ir ? NP - 1 : (2 * ir - j + 2 * (NP - 1)) % (NP - 1));
     }
     bool ever = false;
+    float relmax = 0.f;   // largest gamma^2 / (alpha beta) this workgroup rotated away
 #pragma unroll 1
     for (int sweep = 0; sweep < JG_MAX_INNER; ++sweep) {
       bool rotated = false;
@@ -875,6 +877,7 @@ __global__ __launch_bounds__(256) void jacobi_gram_kernel(double *__restrict__ A
         for (int w = 0; w < 2; ++w) {
           double c = 1.0, sn = 0.0;
           if (ga[w] != 0.0 && ga[w] * ga[w] > tol * tol * al[w] * be[w]) {
+            relmax = fmaxf(relmax, (float)(ga[w] * ga[w] / (al[w] * be[w])));
             // the same angle as in jacobi_block_kernel through the double angle: with a = (beta - alpha)/2,
             // r = sqrt(a^2 + gamma^2): cos 2t = |a|/r, sin 2t = sign(a) gamma/r, so c^2 = (1 + |a|/r)/2 and
             // s = sin 2t / (2c) -- two dependent rsq instead of rsq -> rcp -> rsq, and c^2 + s^2 = 1 exactly
@@ -898,7 +901,12 @@ __global__ __launch_bounds__(256) void jacobi_gram_kernel(double *__restrict__ A
       if (__ballot(rotated) == 0) break;
       ever = true;
     }
-    if (lane == 0 && ever) { any_rot = 1; atomicAdd(rotations, 1); }
+    for (int o = 32; o > 0; o >>= 1) relmax = fmaxf(relmax, __shfl_xor(relmax, o));
+    if (lane == 0 && ever) {
+      any_rot = 1;
+      atomicAdd(rotations, 1);
+      atomicMax(reinterpret_cast<unsigned *>(rotations) + 1, __float_as_uint(relmax));   // non-negative floats order as uints
+    }
   }
   __syncthreads();
   if (!any_rot) return;
@@ -979,7 +987,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
                                     : E <= 8 ? reinterpret_cast<const void *>(&jacobi_block_kernel<8>)
                                              : reinterpret_cast<const void *>(&jacobi_block_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PLDA_HIP(h, hipMemsetAsync(drot, 0, sizeof(int), h->stream));
+    PLDA_HIP(h, hipMemsetAsync(drot, 0, 2 * sizeof(int), h->stream));
     if (gram) PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_gram_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int round = 0; round < nb_even - 1; ++round) {
@@ -1008,7 +1016,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipGraph_t graph = nullptr;
     PLDA_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-    (void)hipMemsetAsync(drot, 0, sizeof(int), h->stream);
+    (void)hipMemsetAsync(drot, 0, 2 * sizeof(int), h->stream);
     for (int round = 0; round < nb_even - 1; ++round) {
 #define JR(EE) jacobi_block_kernel<EE><<<wgs, 256, lds, h->stream>>>(G, V, D, nb_even, round, tol, drot)
       if (gram) jacobi_gram_kernel<<<wgs, 256, lds, h->stream>>>(G, V, D, nb_even, round, tol, drot);
@@ -1055,10 +1063,16 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
   const int max_sweeps = 40;
   for (; sweeps < max_sweeps && D > 1; ++sweeps) {
     PLDA_TRY(jacobi_sweep_graph(h, A, V, D, tol, drot));
-    int hrot = 0;
-    PLDA_HIP(h, hipMemcpyAsync(&hrot, drot, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    int hrot[2] = {0, 0};
+    PLDA_HIP(h, hipMemcpyAsync(hrot, drot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    if (hrot == 0) break;
+    if (hrot[0] == 0) break;
+    // Quadratic convergence: a sweep whose largest rotated off-diagonal was gamma^2/(alpha beta) <= 1e-18
+    // (|cos| <= 1e-9) leaves every pair far below the threshold tol ~ 1e-14, so the confirming sweep
+    // that would find nothing to rotate is skipped.  (Only the Gram kernel reports the maximum.)
+    float relmax;
+    std::memcpy(&relmax, &hrot[1], 4);
+    if (h->jacobi_variant != 1 && relmax > 0.f && relmax <= 1e-18f) break;
   }
   if (sweeps >= max_sweeps) return fail(h, PLDA_E_NUMERIC, "sym_eig: Jacobi did not converge in %d sweeps", max_sweeps);
   if (sweeps_out) *sweeps_out = sweeps + 1;
