@@ -149,6 +149,19 @@ class MPlda(object):
         self._meanz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_mean"])}
         self._stdvz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_std"])}
 
+    def save_kaldi(self, path, binary=True):
+        """Write the model as a Kaldi `Plda` file (plda_amd/kaldi_io.py: format restated, not pinned)."""
+        from . import kaldi_io
+        m = self.get_model()
+        kaldi_io.write_plda(path, m["mean"], m["transform"], m["psi"], binary)
+
+    def load_kaldi(self, path):
+        """Load a Kaldi `Plda` file (binary or text), e.g. one written by ivector-compute-plda."""
+        from . import kaldi_io
+        mean, transform, psi = kaldi_io.read_plda(path)
+        self.set_model(mean, transform, psi)
+        return self
+
     def truncate(self, targetdim):
         """Build extension 'targetdim' (SURVEY.md Appendix B Q3): keep the top-psi rows."""
         self._dout = None            # the model dimension may change

@@ -144,3 +144,21 @@ def test_fit_degenerate_settings(oracle):
         1e-7 * np.abs(refw["transform"].T @ refw["transform"]).max()
     with pytest.raises(RuntimeError):
         eng.fit(xw, yw, -1)
+
+
+def test_kaldi_file_interchange(tmp_path, oracle):
+    """save_kaldi / load_kaldi: a model written in Kaldi's Plda layout scores identically after reloading
+    into a fresh engine (binary and text)."""
+    from plda_amd import MPlda
+    x, y = make_data(77, 900, 24, 30, scale_between=0.5)
+    a = MPlda(0)
+    a.fit(x, y, 4)
+    enrol = a.transform(x[:100], y[:100])
+    test = a.transform(x[100:160], np.arange(60, dtype=np.uint64))
+    want = a.score_matrix(enrol, test, znorm=False)
+    for binary in (True, False):
+        p = str(tmp_path / ("m%d.plda" % binary))
+        a.save_kaldi(p, binary)
+        b = MPlda(0).load_kaldi(p)
+        np.testing.assert_array_equal(b.get_model()["psi"], a.get_model()["psi"])
+        np.testing.assert_array_equal(b.score_matrix(enrol, test, znorm=False), want)
