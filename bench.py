@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--targetdim", type=int, default=0, help="build extension: keep the top-psi dims (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the targetdim-150 extra measurement (profiling runs: every launch of the trials kernel "
+                         "is then the timed D_eff = 200 workload)")
     ap.add_argument("--gather-rows", type=int, default=2048, help="rows per rank in the separately timed all-gather")
     ap.add_argument("--shard-fit", action="store_true",
                     help="N>1: shard the fit statistics by speaker (all-reduce of the scatter + all-gather of the "
@@ -219,7 +222,7 @@ def main():
 
     # ---- build extension named by BASELINE configs[1]: targetdim = 150 (top-psi dims), same trials ----
     td = None
-    if rank == 0 and world == 1 and not args.targetdim and dout > 150:
+    if rank == 0 and world == 1 and not args.targetdim and dout > 150 and not args.no_extra:
         eng.truncate(150)
         dU150 = torch.empty((M, 150), dtype=torch.float64, device=dev)
         dT150 = torch.empty((Nt, 150), dtype=torch.float64, device=dev)
