@@ -286,3 +286,24 @@ def test_fit_large_dim_blocked_inverse(oracle, d, k):
     assert _rel(it["B"], ref["B"]) < 1e-8, _rel(it["B"], ref["B"])
     g = eng.get_model()
     assert np.abs(g["psi"] - ref["psi"]).max() <= 1e-8 * max(ref["psi"].max(), 1e-12)
+
+
+@pytest.mark.parametrize("env", [{"PLDA_EM_VARIANT": "1"}, {"PLDA_JACOBI_VARIANT": "1"}, {"PLDA_GEMM64_VARIANT": "1"}])
+def test_fit_alternative_arms_agree(oracle, monkeypatch, env):
+    """The non-default arms kept in the library -- EM in the simultaneously-diagonalised basis (also the
+    fallback when the per-group matrices would not fit), the rotation-by-rotation Jacobi round, 64 x 64
+    fp64 GEMM tiles only -- give the same fit (the knobs are read when a handle is created)."""
+    from plda_amd import MPlda
+    x, y = make_data(91, 2500, 72, 90, skew=True, scale_between=0.4)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = MPlda(0)
+    for k in env:
+        monkeypatch.delenv(k)
+    alt.fit(x, y, 5)
+    ref = oracle.fit(x, y, 5)
+    g = alt.get_model()
+    assert np.abs(g["psi"] - ref["psi"]).max() <= 1e-8 * ref["psi"].max()
+    assert _rel(g["transform"].T @ g["transform"], ref["transform"].T @ ref["transform"]) < 1e-8
+    it = alt.fit_internals()
+    assert _rel(it["W"], ref["W"]) < 1e-8 and _rel(it["B"], ref["B"]) < 1e-8
