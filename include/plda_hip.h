@@ -208,6 +208,17 @@ int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_
                         const int64_t *denrol_spk, const int64_t *dtest_spk, double *out);
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn,
                    double *out);
+/* Row-sharded trials matrix (one process per GPU, each holding a slab of enrol rows and ALL test
+ * labels): the same three histogram passes over the local slab; after each pass the library calls
+ * `reduce(ctx, hist, NULL, NULL)` with hist[2 * 2048] host counters to be SUMMED over the ranks in
+ * place, and once at the end `reduce(ctx, NULL, below, above)` with two host words to be replaced
+ * by their MAX resp. MIN over the ranks.  The callback returns 0 on success.  Every rank gets the
+ * global result; scores never leave their GPU (the exchange is 3 x 32 KiB + 8 bytes).
+ * plda_amd/sharding.py:eer_sharded supplies a torch.distributed callback. */
+typedef int (*plda_eer_reduce_fn)(void *ctx, unsigned long long *hist, unsigned *below, unsigned *above);
+int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                                const int64_t *denrol_spk, const int64_t *dtest_spk,
+                                plda_eer_reduce_fn reduce, void *ctx, double *out);
 
 /* ---- LDA: replaces the reference's second model, the pure-Python
  * class LDA of python/liblda/lda.py (used by scoring/scoreLDA.py:175,224,241), on the same

@@ -54,7 +54,8 @@ int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const
                        int64_t Ku, double *dmeans, int32_t *dcounts32);
 int compute_offset_device(plda_handle *h);
 int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
-                      const int64_t *dtspk, double *out);
+                      const int64_t *dtspk, double *out,
+                      int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *) = nullptr, void *ctx = nullptr);
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out);
 
 // simple RAII device temp for host-pointer entry points
@@ -747,6 +748,15 @@ int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_
   if (!h) return PLDA_E_INVAL;
   PLDA_TRY(set_device(h));
   return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
+}
+
+int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                                const int64_t *denrol_spk, const int64_t *dtest_spk, plda_eer_reduce_fn reduce, void *ctx,
+                                double *out) {
+  if (!h) return PLDA_E_INVAL;
+  if (!reduce) return fail(h, PLDA_E_INVAL, "eer_matrix_sharded: a reduction callback is required");
+  PLDA_TRY(set_device(h));
+  return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out, reduce, ctx);
 }
 
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn, double *out) {

@@ -114,6 +114,10 @@ __global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__
 struct EerSource {
   const float *scores; int64_t ld, M, Nt; const int64_t *espk, *tspk;   // matrix + labels, or
   const float *pos; int64_t np; const float *neg; int64_t nn;            // two flat lists
+  // row-sharded matrix: after every local pass the caller's reduction makes the counts global
+  // (hist: sum over ranks; below: max; above: min).  nullptr = single process.
+  int (*reduce)(void *ctx, unsigned long long *hist, unsigned *below, unsigned *above) = nullptr;
+  void *ctx = nullptr;
 };
 
 static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, unsigned prefix, int has_prefix,
@@ -121,8 +125,9 @@ static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, 
   PLDA_HIP(h, hipMemsetAsync(dhist, 0, 2 * EER_BINS * 8, h->stream));
   if (src.scores) {
     const unsigned grid = (unsigned)std::min<int64_t>(src.M, 256 * 16);
-    eer_hist_kernel<true><<<grid, 256, 0, h->stream>>>(src.scores, src.ld, src.M, src.Nt, src.espk, src.tspk, 0, shift,
-                                                       nbits, prefix, has_prefix, dhist, dbelow, dabove);
+    if (grid)
+      eer_hist_kernel<true><<<grid, 256, 0, h->stream>>>(src.scores, src.ld, src.M, src.Nt, src.espk, src.tspk, 0, shift,
+                                                         nbits, prefix, has_prefix, dhist, dbelow, dabove);
   } else {
     for (int c = 0; c < 2; ++c) {
       const float *p = c ? src.pos : src.neg;
@@ -136,6 +141,8 @@ static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, 
   hh.resize(2 * EER_BINS);
   PLDA_HIP(h, hipMemcpyAsync(hh.data(), dhist, 2 * EER_BINS * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (src.reduce && src.reduce(src.ctx, hh.data(), nullptr, nullptr) != 0)
+    return fail(h, PLDA_E_INVAL, "eer: the caller's reduction failed");
   return PLDA_OK;
 }
 
@@ -179,6 +186,8 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
   unsigned hb[2];
   PLDA_HIP(h, hipMemcpyAsync(hb, dbelow, 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (src.reduce && src.reduce(src.ctx, nullptr, &hb[0], &hb[1]) != 0)
+    return fail(h, PLDA_E_INVAL, "eer: the caller's reduction failed");
   // neighbours of k1 among the data keys
   const int b2 = (int)(k1 & 1023u);
   long long k0 = -1, k2 = -1;
@@ -207,9 +216,14 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
 }
 
 int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
-                      const int64_t *dtspk, double *out) {
-  if (!dscores || !despk || !dtspk || !out || M <= 0 || Nt <= 0 || ld < Nt) return fail(h, PLDA_E_INVAL, "eer: bad argument");
-  EerSource s{dscores, ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
+                      const int64_t *dtspk, double *out,
+                      int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *), void *ctx) {
+  // a rank of a sharded call may own no row at all (M == 0): it still takes part in the reductions
+  if (!out || Nt <= 0 || ld < Nt || M < 0 || (M == 0 && !reduce) || (M > 0 && (!dscores || !despk || !dtspk)))
+    return fail(h, PLDA_E_INVAL, "eer: bad argument");
+  EerSource s{M > 0 ? dscores : reinterpret_cast<const float *>(out), ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
+  s.reduce = reduce;
+  s.ctx = ctx;
   return eer_device(h, s, out);
 }
 

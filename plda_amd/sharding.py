@@ -189,6 +189,56 @@ def gpu_fit_blocks(engine):
     return stats_block, em_block
 
 
+def eer_sharded(engine, scores_local, enrol_spk_local, test_spk, group=None):
+    """Equal error rate of a ROW-SHARDED trials matrix without gathering it: every rank histograms its own
+    slab (`scores_local` [m_local, Nt] float32 on its GPU, speaker ids of its enrol rows, all test speaker
+    ids), and the counts are summed over the ranks between the three passes -- 3 x 32 KiB + 8 bytes of
+    traffic for any number of trials.  Returns the 6-vector (threshold, FAR, FRR, EER, #targets,
+    #impostors), identical on every rank and identical to the single-GPU result on the assembled matrix.
+    A rank may own no row (m_local = 0)."""
+    import ctypes as C
+    import numpy as np
+    from . import _native as N
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    on_gpu = world > 1 and dist.get_backend(group) == "nccl"
+    dev = scores_local.device
+
+    def allreduce(t, op):
+        if world == 1:
+            return t
+        if on_gpu:
+            g = t.to(dev)
+            dist.all_reduce(g, op=op, group=group)
+            return g.cpu()
+        dist.all_reduce(t, op=op, group=group)
+        return t
+
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.POINTER(C.c_uint))
+
+    def reduce(ctx, hist, below, above):
+        try:
+            if hist:
+                a = np.ctypeslib.as_array(hist, shape=(4096,))
+                t = allreduce(torch.from_numpy(a.view(np.int64).copy()), dist.ReduceOp.SUM)
+                a[:] = t.numpy().view(np.uint64)
+            else:
+                below[0] = int(allreduce(torch.tensor([below[0]], dtype=torch.int64), dist.ReduceOp.MAX)[0])
+                above[0] = int(allreduce(torch.tensor([above[0]], dtype=torch.int64), dist.ReduceOp.MIN)[0])
+            return 0
+        except Exception:       # never let an exception cross the C boundary
+            return 1
+
+    cb = CB(reduce)
+    m, nt = scores_local.shape
+    out = np.zeros(6)
+    scores_local = scores_local.contiguous()
+    N.check(engine._h, engine._lib.plda_eer_matrix_sharded_dev(
+        engine._h, C.c_void_p(scores_local.data_ptr() if m else 0), nt, m, nt,
+        C.c_void_p(enrol_spk_local.data_ptr() if m else 0), C.c_void_p(test_spk.data_ptr()), C.cast(cb, C.c_void_p),
+        None, C.c_void_p(out.ctypes.data)))
+    return out
+
+
 def gpu_znorm_block(engine, dbkg, nb, din):
     """znorm_block over MPlda.znorm_stats_dev: cohort `dbkg` [nb, din] fp64 tensor resident on this GPU."""
     def fn(models):

@@ -61,3 +61,56 @@ def test_eer_of_a_trials_matrix(eng, oracle):
     assert tuple(out[1:4]) == ref[1:] and out[0] == pytest.approx(ref[0], rel=1e-12)
     assert 0.0 < out[3] < 0.5          # speaker structure => better than chance
     assert eer.format_line(out[1], out[2], out[0]).startswith("EER = ")
+
+
+def _eer_rank(rank, world, port, q):
+    import os
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from plda_amd import MPlda, eer
+    from plda_amd.sharding import eer_sharded, shard_rows
+    dev = torch.device("cuda", 0)                      # both ranks share the one GPU of the test box
+    rng = np.random.default_rng(17)                    # same data on every rank
+    m, nt = 301, 997
+    es, ts = rng.integers(0, 9, m), rng.integers(0, 9, nt)
+    sc = np.round(rng.standard_normal((m, nt)) + 1.2 * (es[:, None] == ts[None, :]), 2).astype(np.float32)
+    # world 3: two real slabs and an EMPTY one, which must still take part in the reductions
+    spans = [shard_rows(m, 2, 0), shard_rows(m, 2, 1), (m, m)] if world == 3 else [shard_rows(m, world, r) for r in range(world)]
+    a, b = spans[rank]
+    eng = MPlda(0)
+    S = torch.from_numpy(sc[a:b].copy()).to(dev)
+    e_l = torch.from_numpy(es[a:b].copy()).to(dev)
+    t_all = torch.from_numpy(ts).to(dev)
+    out = eer_sharded(eng, S, e_l, t_all)
+    full = torch.from_numpy(sc).to(dev)
+    e_all = torch.from_numpy(es).to(dev)
+    ref = eer.eer_from_matrix_dev(eng, full.data_ptr(), nt, m, nt, e_all.data_ptr(), t_all.data_ptr())
+    q.put((rank, bool(np.array_equal(out, ref)), out.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_eer_of_a_row_sharded_matrix(world):
+    """EER over row slabs held by different ranks (gloo group, all ranks on this box's GPU): counts are
+    reduced between the histogram passes, nothing is gathered; the result equals the one-GPU EER of
+    the assembled matrix on every rank, also when a rank owns no row."""
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_eer_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True] * world, res
+    assert all(r[2] == res[0][2] for r in res)
