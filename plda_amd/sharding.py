@@ -172,6 +172,9 @@ def fit_sharded(stats_block, em_block, X_local, labels_local, iters=10, group=No
 
 def gpu_fit_blocks(engine):
     """(stats_block, em_block) over MPlda.fit_stats_dev / fit_em_dev for HBM-resident tensors."""
+    if torch.cuda.is_available():
+        engine.set_stream(torch.cuda.current_stream().cuda_stream)   # same stream as the torch ops around them
+
     def stats_block(X, dense, k):
         X = X.contiguous()
         lab = dense.to(torch.int64).contiguous()     # non-negative: same bits as the u64 the ABI reads
@@ -229,6 +232,8 @@ def eer_sharded(engine, scores_local, enrol_spk_local, test_spk, group=None):
             return 1
 
     cb = CB(reduce)
+    if scores_local.is_cuda:
+        engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)   # the slab was produced on torch's stream
     m, nt = scores_local.shape
     out = np.zeros(6)
     scores_local = scores_local.contiguous()
@@ -241,6 +246,9 @@ def eer_sharded(engine, scores_local, enrol_spk_local, test_spk, group=None):
 
 def gpu_znorm_block(engine, dbkg, nb, din):
     """znorm_block over MPlda.znorm_stats_dev: cohort `dbkg` [nb, din] fp64 tensor resident on this GPU."""
+    if dbkg.is_cuda:
+        engine.set_stream(torch.cuda.current_stream(dbkg.device).cuda_stream)   # same stream as the torch ops around it
+
     def fn(models):
         m = models.shape[0]
         mean = torch.empty(m, dtype=torch.float64, device=models.device)
