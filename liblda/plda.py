@@ -44,3 +44,11 @@ class PLDA(object):
 
     def load(self, path):
         return self._instance.load(path)
+
+    def save_kaldi(self, path, binary=True):
+        """Write the model in Kaldi's `Plda` file layout (plda_amd/kaldi_io.py)."""
+        return self._instance.save_kaldi(path, binary)
+
+    def load_kaldi(self, path):
+        self._instance.load_kaldi(path)
+        return self
