@@ -21,7 +21,10 @@
  *    inputs immediately, kaldi-utils.hpp:99-122).  "_dev" entry points take
  *    pointers into this GPU's HBM and enqueue on the handle's stream without
  *    synchronising.
- *  - one handle = one GPU + one HIP stream; a handle is not thread-safe.
+ *  - one handle = one GPU + one HIP stream.  Every entry point takes the handle's mutex, so calls on
+ *    one handle from several threads are safe and serialised (the reference holds the GIL for the
+ *    whole call, pldamodule.cpp has no threads); use one handle per thread for concurrency.
+ *    plda_destroy must not race with other calls on the same handle.
  *  - there is NO CPU fallback: without a usable gfx950 device plda_create fails.
  */
 #ifndef PLDA_HIP_H_

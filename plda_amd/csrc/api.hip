@@ -3,6 +3,8 @@
 // call the *_device implementations; nothing here computes on the CPU.
 #include "common.hpp"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
@@ -91,6 +93,9 @@ __global__ void smooth_kernel(double *__restrict__ T, double *__restrict__ psi, 
 
 using namespace plda;
 
+// one handle = one GPU + one stream: calls on the same handle from several threads are serialised
+#define PLDA_LOCK(h) std::lock_guard<std::recursive_mutex> plda_lock_guard_((h)->mu)
+
 extern "C" {
 
 int plda_abi_version(void) { return 1; }
@@ -146,18 +151,21 @@ const char *plda_last_error(const plda_handle *h) { return h ? h->err.c_str() : 
 
 int plda_set_stream(plda_handle *h, void *hip_stream) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return PLDA_OK;
 }
 
 int plda_reset_stream(plda_handle *h) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   h->stream = h->own_stream;
   return PLDA_OK;
 }
 
 int plda_synchronize(plda_handle *h) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   return PLDA_OK;
@@ -167,12 +175,14 @@ int plda_synchronize(plda_handle *h) {
 int plda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
                  int32_t iters) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return fit_device(h, dX, N, D, dlabels, K, iters);
 }
 
 int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels, int32_t iters) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
   PLDA_TRY(set_device(h));
   uint64_t mx = 0;
@@ -187,12 +197,14 @@ int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64
 
 int plda_fit_stats_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return fit_stats_device(h, dX, N, D, dlabels, K);
 }
 
 int plda_fit_get_stats_dev(plda_handle *h, double *dmeans, int64_t *dcounts, double *dscatter) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats_dev: no statistics pass has run on this handle");
   PLDA_TRY(set_device(h));
   const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
@@ -206,6 +218,7 @@ int plda_fit_get_stats_dev(plda_handle *h, double *dmeans, int64_t *dcounts, dou
 int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts, int64_t K, const double *dscatter,
                     int32_t D, int32_t iters) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!dmeans || !dcounts || !dscatter || K <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit_em: bad argument");
   if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
   PLDA_TRY(set_device(h));
@@ -237,6 +250,7 @@ int plda_fit_num_classes(plda_handle *h, int64_t *K) {
 int plda_fit_get_stats(plda_handle *h, double *means, int64_t *counts, double *scatter, double *sum,
                        double *W, double *B) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats: no fit has run on this handle");
   PLDA_TRY(set_device(h));
   const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
@@ -253,6 +267,7 @@ int plda_fit_get_stats(plda_handle *h, double *means, int64_t *counts, double *s
 // ---------------------------------------------------------------- model
 int plda_get_dims(plda_handle *h, int32_t *Dout, int32_t *Din) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
   if (Dout) *Dout = h->Dout;
   if (Din) *Din = h->Din;
@@ -261,6 +276,7 @@ int plda_get_dims(plda_handle *h, int32_t *Dout, int32_t *Din) {
 
 int plda_get_model(plda_handle *h, double *mean, double *transform, double *psi, double *offset) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
   if (mean) std::memcpy(mean, h->h_mean.data(), h->h_mean.size() * 8);
   if (transform) std::memcpy(transform, h->h_transform.data(), h->h_transform.size() * 8);
@@ -281,6 +297,7 @@ static int refresh_offset(plda_handle *h) {
 int plda_set_model(plda_handle *h, int32_t Dout, int32_t Din, const double *mean, const double *transform,
                    const double *psi) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (Dout <= 0 || Din <= 0 || Dout > Din || !mean || !transform || !psi)
     return fail(h, PLDA_E_INVAL, "set_model: bad argument");
   PLDA_TRY(set_device(h));
@@ -296,6 +313,7 @@ int plda_set_model(plda_handle *h, int32_t Dout, int32_t Din, const double *mean
 
 int plda_truncate(plda_handle *h, int32_t targetdim) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
   if (targetdim <= 0 || targetdim > h->Dout) return fail(h, PLDA_E_INVAL, "truncate: targetdim %d not in [1,%d]", targetdim, h->Dout);
   PLDA_TRY(set_device(h));
@@ -308,6 +326,7 @@ int plda_truncate(plda_handle *h, int32_t targetdim) {
 
 int plda_smooth(plda_handle *h, double factor) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
   if (!(factor >= 0.0 && factor <= 1.0)) return fail(h, PLDA_E_INVAL, "smooth: factor must be in [0,1]");
   PLDA_TRY(set_device(h));
@@ -322,6 +341,7 @@ int plda_smooth(plda_handle *h, double factor) {
 int plda_transform_rows_dev(plda_handle *h, const double *dXbar, int64_t R, int32_t Din, const int32_t *dn,
                             int32_t n_uniform, double *dout) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
   PLDA_TRY(set_device(h));
   return transform_rows_device(h, dXbar, R, Din, dn, n_uniform, dout);
@@ -330,6 +350,7 @@ int plda_transform_rows_dev(plda_handle *h, const double *dXbar, int64_t R, int3
 int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t Din, const int32_t *num_examples,
                         int32_t n_uniform, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
   if (R <= 0) return PLDA_OK;
   if (!Xbar || !out) return fail(h, PLDA_E_INVAL, "transform_rows: bad argument");
@@ -348,6 +369,7 @@ int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t D
 int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Din, const uint64_t *labels,
                           uint64_t *out_labels, int64_t *out_counts, double *out_vecs, int64_t *Ku) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
   if (!Ku) return fail(h, PLDA_E_INVAL, "transform_groups: Ku is NULL");
   if (N <= 0) { *Ku = 0; return PLDA_OK; }
@@ -385,6 +407,7 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
                           const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
                           int64_t ld_out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return score_matrix_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out);
 }
@@ -393,6 +416,7 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
                       const double *V, int64_t Nt, const double *zmean, const double *zstd, float *out,
                       int64_t ld_out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
   if (M <= 0 || Nt <= 0) return PLDA_OK;
   if (!U || !V || !out || ld_out < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
@@ -428,12 +452,14 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
 
 int plda_profile_enable(plda_handle *h, int32_t on) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   h->prof_on = on != 0;
   return PLDA_OK;
 }
 
 int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double *gemm_flop, int32_t reset) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   double total = 0.0;
@@ -451,6 +477,7 @@ int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double
 
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (M) *M = h->last_M;
   if (Nt) *Nt = h->last_Nt;
   if (gemm_k) *gemm_k = h->last_k;
@@ -461,6 +488,7 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
                      int64_t Nt, const int64_t *e_idx, const int64_t *t_idx, int64_t P, const double *zmean,
                      const double *zstd, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score: model not fitted");
   if (P <= 0) return PLDA_OK;
   if (!U || !n_enrol || !V || !e_idx || !t_idx || !out || M <= 0 || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: bad argument");
@@ -523,6 +551,7 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
 int plda_znorm_stats_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples, int32_t Din,
                          const double *dmodels, int64_t M, double *dout_mean, double *dout_std) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return znorm_stats_device(h, dbkg, Nb, num_examples, Din, dmodels, M, dout_mean, dout_std);
 }
@@ -530,6 +559,7 @@ int plda_znorm_stats_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t
 int plda_znorm_stats(plda_handle *h, const double *bkg, int64_t Nb, int32_t num_examples, int32_t Din,
                      const double *models, int64_t M, double *out_mean, double *out_std) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
   if (!bkg || !models || !out_mean || !out_std || Nb <= 0 || M <= 0) return fail(h, PLDA_E_INVAL, "norm: bad argument");
   if (Din != h->Din) return fail(h, PLDA_E_INVAL, "norm: feature dim %d != model dim %d", Din, h->Din);
@@ -551,6 +581,7 @@ int plda_znorm_stats(plda_handle *h, const double *bkg, int64_t Nb, int32_t num_
 int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, int64_t T, int32_t D,
                           const int64_t *doffsets, int64_t U, int32_t method, int32_t l2norm, double *dout) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return dvector_pool_device(h, dframes, dtype, T, D, doffsets, U, method, l2norm, dout);
 }
@@ -558,6 +589,7 @@ int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, in
 int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t T, int32_t D, const int64_t *offsets,
                       int64_t U, int32_t method, int32_t l2norm, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (U <= 0) return PLDA_OK;
   if (!frames || !offsets || !out || T < 0 || D <= 0 || (dtype != 0 && dtype != 1))
     return fail(h, PLDA_E_INVAL, "dvector_pool: bad argument");
@@ -579,6 +611,7 @@ int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t
 int plda_lda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
                      int32_t solver, const double *priors) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return lda_fit_device(h, dX, N, D, dlabels, K, solver, priors);
 }
@@ -586,6 +619,7 @@ int plda_lda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, con
 int plda_lda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels, int32_t solver,
                  const double *priors) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "lda_fit: bad argument");
   uint64_t mx = 0;
   for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
@@ -599,6 +633,7 @@ int plda_lda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const ui
 
 int plda_lda_dims(plda_handle *h, int64_t *K, int32_t *D, int32_t *rank, int32_t *solver) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
   if (K) *K = h->lda_K;
   if (D) *D = h->lda_D;
@@ -610,6 +645,7 @@ int plda_lda_dims(plda_handle *h, int64_t *K, int32_t *D, int32_t *rank, int32_t
 int plda_lda_get_model(plda_handle *h, double *priors, double *means, double *xbar, double *scalings, double *coef,
                        double *intercept, double *evr) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
   PLDA_TRY(set_device(h));
   const size_t K = (size_t)h->lda_K, D = (size_t)h->lda_D, R = (size_t)h->lda_rank;
@@ -631,6 +667,7 @@ int plda_lda_set_model(plda_handle *h, int32_t solver, int64_t K, int32_t D, int
                        const double *means, const double *xbar, const double *scalings, const double *coef,
                        const double *intercept) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (solver < 0 || solver > 2 || K <= 0 || D <= 0 || rank < 0 || rank > D || !coef || !intercept)
     return fail(h, PLDA_E_INVAL, "lda_set_model: bad argument");
   if (solver != 2 && (!scalings || rank == 0)) return fail(h, PLDA_E_INVAL, "lda_set_model: scalings required");
@@ -656,12 +693,14 @@ int plda_lda_set_model(plda_handle *h, int32_t solver, int64_t K, int32_t D, int
 
 int plda_lda_predict_dev(plda_handle *h, const double *dX, int64_t N, int32_t mode, double *dout) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return lda_predict_device(h, dX, N, mode, dout);
 }
 
 int plda_lda_predict(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t mode, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
   if (D != h->lda_D)
     return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);   // lda.py:264-266
@@ -685,12 +724,14 @@ int plda_lda_predict(plda_handle *h, const double *X, int64_t N, int32_t D, int3
 
 int plda_lda_transform_dev(plda_handle *h, const double *dX, int64_t N, int32_t ncomp, double *dout) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return lda_transform_device(h, dX, N, ncomp, dout);
 }
 
 int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t ncomp, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
   if (D != h->lda_D) return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);
   if (N <= 0 || ncomp <= 0) return PLDA_OK;
@@ -709,6 +750,7 @@ int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, in
 int plda_htk_frames_dev(plda_handle *h, const void *dblob, const int64_t *dfile_off, const int64_t *dframe_off,
                         int64_t U, int64_t T, int32_t samplesize, int32_t frm_ext, float *dout) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return htk_frames_device(h, dblob, dfile_off, dframe_off, U, T, samplesize, frm_ext, dout);
 }
@@ -716,6 +758,7 @@ int plda_htk_frames_dev(plda_handle *h, const void *dblob, const int64_t *dfile_
 int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const int64_t *file_off,
                     const int64_t *frame_off, int64_t U, int32_t samplesize, int32_t frm_ext, float *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (U <= 0) return PLDA_OK;
   if (!blob || !file_off || !frame_off || !out || blob_bytes < 0 || samplesize <= 0 || frm_ext < 0)
     return fail(h, PLDA_E_INVAL, "htk_frames: bad argument");
@@ -746,6 +789,7 @@ int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const 
 int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
                         const int64_t *denrol_spk, const int64_t *dtest_spk, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   PLDA_TRY(set_device(h));
   return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
 }
@@ -754,6 +798,7 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
                                 const int64_t *denrol_spk, const int64_t *dtest_spk, plda_eer_reduce_fn reduce, void *ctx,
                                 double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!reduce) return fail(h, PLDA_E_INVAL, "eer_matrix_sharded: a reduction callback is required");
   PLDA_TRY(set_device(h));
   return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out, reduce, ctx);
@@ -761,6 +806,7 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
 
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn, double *out) {
   if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
   if (!pos || !neg || !out || np <= 0 || nn <= 0)
     return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor score");
   PLDA_TRY(set_device(h));

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct DevBuf {
 }  // namespace plda
 
 struct plda_handle {
+  std::recursive_mutex mu;   // taken by every C-ABI entry point (api.hip)
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;

@@ -8,6 +8,7 @@ kernels on an MI355X.  Batched extensions (`transform_array`, `score_matrix`,
 `score_trials`) expose what the reference's callers loop over in Python.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -258,9 +259,12 @@ class MPlda(object):
             raise TypeError("score(target, (n, vec), (n, vec)): enrol model and test must be tuples")
         # one trial per call is latency, not throughput: the per-call scratch arrays are kept on the object and
         # the library's one-trial path (plda_score_pairs with M = Nt = P = 1) copies nothing through the copy engine
-        sc = self.__dict__.get("_score_scratch")
+        tl = self.__dict__.get("_score_tls")
+        if tl is None:
+            tl = self._score_tls = threading.local()      # per thread: ctypes drops the GIL inside the call
+        sc = getattr(tl, "scratch", None)
         if sc is None:
-            sc = self._score_scratch = (np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1), np.zeros(1), np.zeros(1))
+            sc = tl.scratch = (np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1), np.zeros(1), np.zeros(1))
         n, zero, out, zm, zs = sc
         n[0] = int(xvec[0])
         u, v = xvec[1], yvec[1]

@@ -162,3 +162,41 @@ def test_kaldi_file_interchange(tmp_path, oracle):
         b = MPlda(0).load_kaldi(p)
         np.testing.assert_array_equal(b.get_model()["psi"], a.get_model()["psi"])
         np.testing.assert_array_equal(b.score_matrix(enrol, test, znorm=False), want)
+
+
+def test_one_handle_from_several_threads():
+    """ctypes releases the GIL during a call, so Python threads do reach the library concurrently: calls on one
+    handle are serialised by its mutex and every thread gets the right answers."""
+    import threading
+    from plda_amd import MPlda
+    x, y = make_data(5, 800, 32, 20, scale_between=0.5)
+    eng = MPlda(0)
+    eng.fit(x, y, 3)
+    enrol = eng.transform(x[:60], y[:60])
+    test = eng.transform(x[60:100], np.arange(40, dtype=np.uint64))
+    want_S = eng.score_matrix(enrol, test, znorm=False)
+    ids = sorted(enrol)
+    want = {(i, j): eng.score(i, enrol[i], test[j]) for i in ids[:5] for j in range(8)}
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(40):
+                i, j = ids[int(rng.integers(0, 5))], int(rng.integers(0, 8))
+                if eng.score(i, enrol[i], test[j]) != want[(i, j)]:
+                    errors.append("score mismatch")
+                if seed % 2 and not np.array_equal(eng.score_matrix(enrol, test, znorm=False), want_S):
+                    errors.append("matrix mismatch")
+                if seed % 3 == 0:
+                    t = eng.transform(x[:60], y[:60])
+                    if not all(np.array_equal(t[k][1], enrol[k][1]) for k in enrol):
+                        errors.append("transform mismatch")
+        except Exception as ex:      # noqa: BLE001
+            errors.append(repr(ex))
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
