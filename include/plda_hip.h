@@ -150,6 +150,11 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
 int plda_profile_enable(plda_handle *h, int32_t on);
 int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double *gemm_flop,
                       int32_t reset);
+/* Diagnostic (PLDA_HIP tracing knob): with PLDA_GEMM_VARIANT=31 in the environment at
+ * plda_create, the trials GEMM runs an instrumented instantiation whose workgroup 0 stamps the
+ * shader clock per wave at every stage barrier (arrive, leave) and around every tile epilogue.
+ * out[tile < 8][stage < 16][wave < 8][4] = {arrive, leave, epilogue start, epilogue end (stage 15)}. */
+int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words);
 /* algorithmic work of the last score_matrix call: flop of the trials GEMM and
  * its depth, for roofline accounting */
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k);

@@ -136,7 +136,7 @@ int plda_destroy(plda_handle *h) {
   DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                     &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                     &h->s_rscale, &h->s_cbias, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
-                    &h->l_coef, &h->l_intercept, &h->l_evr};
+                    &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline};
   for (DevBuf *b : bufs) b->release();
   for (auto &b : h->w) b.release();
   if (h->one_host) (void)hipHostFree(h->one_host);
@@ -472,6 +472,17 @@ int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double
   if (launches) *launches = (int64_t)h->prof_used;
   if (gemm_flop) *gemm_flop = h->prof_flop;
   if (reset) { h->prof_used = 0; h->prof_flop = 0.0; }
+  return PLDA_OK;
+}
+
+int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words) {
+  if (!h) return PLDA_E_INVAL;
+  PLDA_LOCK(h);
+  if (!out || cap_words < (int64_t)TIMELINE_WORDS) return fail(h, PLDA_E_CAPACITY, "profile_timeline: need %zu words", TIMELINE_WORDS);
+  if (!h->timeline_valid) return fail(h, PLDA_E_INVAL, "profile_timeline: no PLDA_GEMM_VARIANT=31 launch has run on this handle");
+  PLDA_TRY(set_device(h));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  PLDA_HIP(h, hipMemcpy(out, h->timeline.p, TIMELINE_WORDS * 8, hipMemcpyDeviceToHost));
   return PLDA_OK;
 }
 

@@ -80,6 +80,9 @@ struct plda_handle {
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
   int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
+  bool bt2_attr_set = false;
+  bool timeline_valid = false;   // `timeline` holds the stamps of a PLDA_GEMM_VARIANT=31 launch
+  plda::DevBuf timeline;
   bool bt_attr_set = false;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
 
   // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
@@ -110,6 +113,8 @@ int hip_fail(plda_handle *h, hipError_t e, const char *what, const char *file, i
   } while (0)
 
 #define PLDA_LAUNCH_CHECK(h) PLDA_HIP(h, hipGetLastError())
+
+constexpr size_t TIMELINE_WORDS = 8 * 16 * 8 * 4;   // [tile < 8][stage < 16][wave < 8][4] shader-clock stamps
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }

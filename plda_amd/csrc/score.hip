@@ -637,6 +637,280 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
 #undef BT_MFMA8
 #undef BT_LOAD
 
+// ------------------------------------------------------------------------------------
+// Big-tile form, second generation ("bt2"; product path).  Same 256 x 256 tile, 8 waves of
+// 128 x 64, same operand layout, fragment scheme and k-order as the kernel above (so its
+// scores are bit-identical), but a different pipeline.  What the round-1 kernel lost
+// (82 % MFMA-busy) sat in the stage boundary: after `vmcnt(0) + s_barrier` all 8 waves ran
+// the stage's DMA issue -- ~200 scalar instructions of 64-bit addressing with SGPR spills
+// per wave -- then waited for their first fragment reads, with the matrix pipe idle.  Here
+//   * DMA addressing is two scalar adds per 1 KiB piece: per-wave byte offsets into a buffer
+//     descriptor (soffset) and into LDS (M0) are kept in SGPRs and advanced per stage;
+//   * the stage barrier moves EARLY: it sits in front of the LAST 16-k step of a stage, when
+//     the fragments of that step are already in registers.  Behind it every wave knows (a)
+//     stage g+1 has landed (each wave drained its own DMAs before the barrier) and (b) nobody
+//     reads stage g's buffer any more -- so the step's 32 MFMAs issue at once, the fragments of
+//     stage g+1's first step are fetched under them, and the DMA pieces of stage g+2 are
+//     issued one per two MFMAs into the buffer just freed.  No wave ever stands at a barrier
+//     with nothing queued behind it;
+//   * the pipeline is uniform across tile boundaries: the epilogue owns a separate 16 KiB
+//     staging area (2 KiB per wave, 8 x 64 outputs per round trip), so the DMA stream and the
+//     fragment prefetch of the next tile run through it, and there is no barrier at the
+//     tile boundary at all;
+//   * K is cut into balanced stages of 2..4 steps (25 steps at D = 200 -> 4,4,4,4,3,3,3).
+// LDS: 2 x 64 KiB stage buffers + 16 KiB staging + 3 x 3 KiB bias slots = 153 KiB.
+// Packed operands must be < 4 GiB each (32-bit soffset); larger ones take the kernel above.
+// ------------------------------------------------------------------------------------
+constexpr int BT2_STG = 2 * 65536;                 // byte offset of the epilogue staging area
+constexpr int BT2_BIAS = BT2_STG + 16384;          // 3 slots x 768 floats
+constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
+
+#define BT2_SB __builtin_amdgcn_sched_barrier(0)
+#define BT2_MFMA2(T, S, TM)                                                                         \
+  acc[TM][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[TM][T], S##b[0][T], acc[TM][0], 0, 0, 0);  \
+  acc[TM][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[TM][T], S##b[1][T], acc[TM][1], 0, 0, 0);
+#define BT2_MFMA8(T, S) BT2_MFMA2(T, S, 0) BT2_MFMA2(T, S, 1) BT2_MFMA2(T, S, 2) BT2_MFMA2(T, S, 3)
+#define BT2_LOAD(S, AP, BP)                                                                         \
+  S##a[0] = (AP)[0]; S##a[1] = (AP)[32]; S##a[2] = (AP)[64]; S##a[3] = (AP)[96];                    \
+  S##b[0] = (BP)[0]; S##b[1] = (BP)[32];
+// a step that is not the last of its stage: 32 MFMAs on the current fragments x, the next step's
+// fragments into y underneath, then x <- y (24 register moves per 32 MFMAs, issued in the shadow of
+// the partner wave's MFMAs; one code path for any number of steps, which the register allocator needs:
+// separately unrolled 1/2/3/4-step stage bodies with alternating sets spilled the accumulators)
+#define BT2_XY()                                                                                    \
+  xa[0] = ya[0]; xa[1] = ya[1]; xa[2] = ya[2]; xa[3] = ya[3]; xb[0] = yb[0]; xb[1] = yb[1];
+#define BT2_STEP_MID(AP, BP)                                                                        \
+  BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, AP, BP) BT2_SB;                                               \
+  BT2_MFMA8(1, x) BT2_MFMA8(2, x) BT2_MFMA8(3, x) BT2_SB; BT2_XY() BT2_SB;
+// the last step of a stage: early barrier, then MFMAs with the next stage's first fragments and
+// the DMA pieces of the stage after that underneath
+#define BT2_STEP_LAST()                                                                             \
+  early_barrier(); BT2_SB;                                                                          \
+  BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, An, Bn) BT2_SB;                                               \
+  BT2_MFMA2(1, x, 0) BT2_SB; dma_piece(0); BT2_SB; BT2_MFMA2(1, x, 1) BT2_SB; dma_piece(1); BT2_SB; \
+  BT2_MFMA2(1, x, 2) BT2_SB; dma_piece(2); BT2_SB; BT2_MFMA2(1, x, 3) BT2_SB; dma_piece(3); BT2_SB; \
+  BT2_MFMA2(2, x, 0) BT2_SB; dma_piece(4); BT2_SB; BT2_MFMA2(2, x, 1) BT2_SB; dma_piece(5); BT2_SB; \
+  BT2_MFMA2(2, x, 2) BT2_SB; dma_piece(6); BT2_SB; BT2_MFMA2(2, x, 3) BT2_SB; dma_piece(7); BT2_SB; \
+  dma_advance(); BT2_SB;                                                                            \
+  BT2_MFMA8(3, x) BT2_SB; BT2_XY() BT2_SB;
+
+template <bool ZN, int MODE>
+__global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
+    const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, unsigned Mpad, unsigned Npad, int KQ,
+    const float *__restrict__ rbias, const float *__restrict__ rscale, const float *__restrict__ cbias,
+    float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt, int tilesM, int tilesN, int patchesN,
+    int numPatches, unsigned long long *__restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+  constexpr bool TL = (MODE & 1) != 0;                            // timeline instrumentation (diagnostic)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
+  const int i = lane & 31, hh = lane >> 5;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int lbm = lb / BPC, lbn = lb % BPC;                       // this workgroup's tile inside a patch
+  const int nsteps = KQ >> 1;                                     // 16-k steps per tile
+  const int nst = (nsteps + 3) >> 2;                              // stages per tile
+  const int sbase = nsteps / nst, srem = nsteps - sbase * nst;    // stage j has sbase + (j < srem) steps
+  const int lane16 = lane * 16;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(Apk), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(Bpk), 0, -1, 0x00020000);
+  LDS_AS char *const lds = (LDS_AS char *)smem;
+  (void)numPatches;
+
+  // ---- tile walk (same order as the kernel above: XCD x takes patches x, x + 8, ...; its 32
+  //      workgroups one tile each), stepped without divisions.  Only the DMA cursor walks; the
+  //      compute cursor reads the tiles back from a 3-entry queue (the DMA runs <= 2 tiles ahead).
+  int t_pm = 0, t_pn = xcd;
+  auto tile_valid = [&]() { return t_pm * BPR + lbm < tilesM && t_pn * BPC + lbn < tilesN; };
+  auto tile_norm = [&]() { while (t_pn >= patchesN) { t_pn -= patchesN; ++t_pm; } };
+  auto tile_next = [&]() -> bool {      // false: no tile left (t_pm only grows)
+    for (;;) {
+      t_pn += 8;
+      tile_norm();
+      if (t_pm * BPR >= tilesM) return false;
+      if (tile_valid()) return true;
+    }
+  };
+  tile_norm();
+  bool d_ok = t_pm * BPR < tilesM;
+  if (d_ok && !tile_valid()) d_ok = tile_next();
+  if (!d_ok) return;
+
+  // ---- DMA cursor: the stage fetched next.  This wave moves rows [quarter*64, +64) of k-quads
+  //      kqw, kqw+2, kqw+4, kqw+6 of a stage, A side then B side: 8 pieces of 1 KiB ----
+  const unsigned quarter = wave & 3, kqw = wave >> 2;
+  const unsigned strideA2 = Mpad * 32u, strideB2 = Npad * 32u;    // bytes per 2 k-quad planes
+  const unsigned ldsw = kqw * 4096u + quarter * 1024u;            // this wave's first piece inside a stage buffer
+  int d_st = 0, d_slot = 0;
+  int d_r0 = (t_pm * BPR + lbm) * 256, d_c0 = (t_pn * BPC + lbn) * 256;
+  int q_r0[3] = {d_r0, 0, 0}, q_c0[3] = {d_c0, 0, 0};
+  bool q_ok[3] = {true, false, false};
+  unsigned d_offA = ((unsigned)kqw * Mpad + (unsigned)d_r0 + quarter * 64u) * 16u;
+  unsigned d_offB = ((unsigned)kqw * Npad + (unsigned)d_c0 + quarter * 64u) * 16u;
+  unsigned d_lds = 0;                                             // byte offset of the buffer the DMA cursor fills
+  float *const bias_lds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + BT2_BIAS);
+
+  auto dma_piece = [&](int jj) {
+    if (jj < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void *)(lds + d_lds + ldsw + jj * 8192u), 16, lane16,
+                                               (int)(d_offA + (unsigned)jj * strideA2), 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void *)(lds + d_lds + 32768u + ldsw + (jj - 4) * 8192u), 16,
+                                               lane16, (int)(d_offB + (unsigned)(jj - 4) * strideB2), 0, 0);
+  };
+  // after the 8 pieces of the cursor's stage have been issued: step the cursor to the following
+  // stage.  The common case is a handful of scalar operations (it sits between the MFMAs of the
+  // stage's last step); entering a tile -- its biases (row biases, column biases, row scales ->
+  // slot d_slot) ride with its first stage -- and leaving one are the rare branches.  Past the last
+  // tile the pieces re-fetch the last position; nothing consumes them.
+  auto dma_advance = [&]() {
+    if (d_st == 0 && d_ok) {
+      float *dst = bias_lds + d_slot * 768;
+      if (wave == 0)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rbias + d_r0 + lane * 4), (LDS_AS void *)dst, 16, 0, 0);
+      else if (wave == 1 && cbias)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(cbias + d_c0 + lane * 4), (LDS_AS void *)(dst + 256), 16, 0, 0);
+      else if (wave == 2 && ZN)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rscale + d_r0 + lane * 4), (LDS_AS void *)(dst + 512), 16, 0, 0);
+    }
+    const unsigned npd = (unsigned)(sbase + (d_st < srem ? 1 : 0));
+    d_offA += npd * strideA2;
+    d_offB += npd * strideB2;
+    d_lds ^= 65536u;
+    if (++d_st == nst) {
+      d_st = 0;
+      d_slot = d_slot == 2 ? 0 : d_slot + 1;
+      if (d_ok) d_ok = tile_next();
+      if (d_ok) { d_r0 = (t_pm * BPR + lbm) * 256; d_c0 = (t_pn * BPC + lbn) * 256; }
+      if (d_slot == 0) { q_r0[0] = d_r0; q_c0[0] = d_c0; q_ok[0] = d_ok; }
+      else if (d_slot == 1) { q_r0[1] = d_r0; q_c0[1] = d_c0; q_ok[1] = d_ok; }
+      else { q_r0[2] = d_r0; q_c0[2] = d_c0; q_ok[2] = d_ok; }
+      d_offA = ((unsigned)kqw * Mpad + (unsigned)d_r0 + quarter * 64u) * 16u;
+      d_offB = ((unsigned)kqw * Npad + (unsigned)d_c0 + quarter * 64u) * 16u;
+    }
+  };
+
+  unsigned long long t_arr = 0, t_lv = 0;
+  int tseq = 0, st = 0;
+  auto early_barrier = [&]() {
+    if (TL) t_arr = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (TL) {
+      t_lv = __builtin_amdgcn_s_memtime();
+      if (blockIdx.x == 0 && lane == 0 && tseq < 8 && st < 16) {
+        unsigned long long *p = dbg + (((size_t)tseq * 16 + st) * 8 + wave) * 4;
+        p[0] = t_arr; p[1] = t_lv;
+      }
+    }
+  };
+
+  // ---- prologue: stage 0 of the first tile, barrier, then stage 1 in a burst ----
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
+  dma_advance();
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
+  dma_advance();
+
+  int cur = 0, c_slot = 0;                                         // buffer / queue slot of the compute cursor
+  int r0 = q_r0[0], c0 = q_c0[0];
+  bool have = true;
+  const f32x4 *const Abase = smem + hh * 256 + wm * 128 + i;
+  const f32x4 *const Bbase = smem + 8 * 256 + hh * 256 + wn * 64 + i;
+  f32x4 xa[4], xb[2], ya[4], yb[2];
+  BT2_LOAD(x, Abase, Bbase)
+
+  while (have) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    for (st = 0; st < nst; ++st) {
+      const int np = sbase + (st < srem ? 1 : 0);
+      const f32x4 *Ac = Abase + cur * 4096, *Bc = Bbase + cur * 4096;
+      const f32x4 *An = Abase + (cur ^ 1) * 4096, *Bn = Bbase + (cur ^ 1) * 4096;
+#pragma unroll 1
+      for (int sn = 1; sn < np; ++sn) { BT2_STEP_MID(Ac + sn * 512, Bc + sn * 512) }
+      BT2_STEP_LAST()
+      cur ^= 1;
+    }
+
+    // ---- epilogue: 16 round trips of 8 rows x 64 columns through this wave's 2 KiB of staging ----
+    unsigned long long t_e0 = 0;
+    if (TL) t_e0 = __builtin_amdgcn_s_memtime();
+    {
+      const float *bl = bias_lds + c_slot * 768;
+      float cb[2];
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? bl[256 + wn * 64 + tn * 32 + i] : 0.f;
+      float *stg = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + BT2_STG) + wave * 512;
+      const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+      const int64_t wrow0 = (int64_t)r0 + wm * 128, wcol0 = (int64_t)c0 + wn * 64;
+      const bool interior = ((int64_t)r0 + 256 <= M) && ((int64_t)c0 + 256 <= Nt) && ((ld & 3) == 0) &&
+                            ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+      // the store pointer walks down the wave's 128 rows, 4 rows per store
+      float *dst = out + (wrow0 + rrow) * ld + wcol0 + rcol;
+      int64_t row = wrow0 + rrow;
+      const int64_t ld4 = 4 * ld;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+          f32x4 rs = {1.f, 1.f, 1.f, 1.f};
+          if (ZN) rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[tm][tn][4 * q + e] + cb[tn];
+              v = ZN ? v * rs[e] + rb[e] : v + rb[e];
+              stg[(4 * hh + e) * 64 + tn * 32 + i] = v;
+            }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + k * 256 + lane * 4);
+            if (interior) {
+              __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+            } else if (row < M) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
+            }
+            dst += ld4;
+            row += 4;
+          }
+        }
+      }
+    }
+    if (TL) {
+      const unsigned long long t_e1 = __builtin_amdgcn_s_memtime();
+      if (blockIdx.x == 0 && lane == 0 && tseq < 8) {
+        unsigned long long *p = dbg + (((size_t)tseq * 16 + 15) * 8 + wave) * 4;
+        p[2] = t_e0; p[3] = t_e1;
+      }
+    }
+    ++tseq;
+    c_slot = c_slot == 2 ? 0 : c_slot + 1;
+    r0 = c_slot == 0 ? q_r0[0] : (c_slot == 1 ? q_r0[1] : q_r0[2]);
+    c0 = c_slot == 0 ? q_c0[0] : (c_slot == 1 ? q_c0[1] : q_c0[2]);
+    have = c_slot == 0 ? q_ok[0] : (c_slot == 1 ? q_ok[1] : q_ok[2]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the workgroup has gone
+}
+#undef BT2_STEP_LAST
+#undef BT2_STEP_MID
+#undef BT2_XY
+#undef BT2_LOAD
+#undef BT2_MFMA8
+#undef BT2_MFMA2
+#undef BT2_SB
+
 // finalise fused z-norm statistics: mean = shift + S1/N, std = sqrt(S2/N - (S1/N)^2)
 __global__ void znorm_finalize_kernel(const float *__restrict__ shift, const double *__restrict__ colsum,
                                       const double *__restrict__ colsq, int64_t M, double invN,
@@ -748,8 +1022,9 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   op.KQ = op.Kg / 4;
   op.Mpad = round_up(M, 256);   // 256: the big-tile kernel's block tile (the 128 kernel tolerates it)
   op.Npad = round_up(Nt, 256);
-  PLDA_HIP(h, h->s_Apk.reserve((size_t)op.KQ * op.Mpad * 16));
-  PLDA_HIP(h, h->s_Bpk.reserve((size_t)op.KQ * op.Npad * 16));
+  // 8 spare k-quad planes: the bt2 kernel's branch-free DMA may fetch (never consume) up to one stage past KQ
+  PLDA_HIP(h, h->s_Apk.reserve((size_t)(op.KQ + 8) * op.Mpad * 16));
+  PLDA_HIP(h, h->s_Bpk.reserve((size_t)(op.KQ + 8) * op.Npad * 16));
   PLDA_HIP(h, h->s_rbias.reserve((size_t)op.Mpad * 4));
   PLDA_HIP(h, h->s_rscale.reserve((size_t)op.Mpad * 4));
   PLDA_HIP(h, h->s_cbias.reserve((size_t)op.Npad * 4));
@@ -810,10 +1085,44 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     h->prof_flop += 2.0 * (double)op.Kg_alg * (double)M * (double)Nt;
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
   }
-  // big-tile persistent kernel: when there are enough 256x256 tiles to keep 256 CUs busy
+  // big-tile persistent kernels: when there are enough 256x256 tiles to keep 256 CUs busy
   const int btM = (int)ceil_div(M, 256), btN = (int)(op.Npad / 256);
+  const bool big = EPI == 0 && (int64_t)btM * btN >= 1024;
+  // second-generation kernel (product): needs 32-bit byte offsets into each packed operand
+  const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
+  const bool use_bt2 = EPI == 0 && fits4g && (h->gemm_variant == 30 || h->gemm_variant == 31 || (h->gemm_variant == 0 && big));
+  if (use_bt2) {
+    const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
+    if (!h->bt2_attr_set) {
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<true, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      h->bt2_attr_set = true;
+    }
+#define BT2L(ZN_, MODE_, DBG_)                                                                            \
+  trials_gemm_bt2_kernel<ZN_, MODE_><<<256, 512, BT2_LDS, h->stream>>>(                                   \
+      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
+      h->s_rbias.as<float>(), use_rscale ? h->s_rscale.as<float>() : nullptr,                             \
+      op.mixed ? nullptr : h->s_cbias.as<float>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
+    if (h->gemm_variant == 31 && !ZN) {
+      // diagnostic: per-wave timestamps of workgroup 0 (plda_profile_timeline)
+      PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
+      PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
+      BT2L(false, 1, h->timeline.as<unsigned long long>());
+      h->timeline_valid = true;
+    } else {
+      BT2L(ZN, 0, nullptr);
+    }
+#undef BT2L
+    PLDA_LAUNCH_CHECK(h);
+    if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
+    return PLDA_OK;
+  }
   const bool use_bt = EPI == 0 && h->gemm_variant != 20 &&
-                      (h->gemm_variant == 21 || h->gemm_variant == 28 || (h->gemm_variant == 0 && (int64_t)btM * btN >= 1024));
+                      (h->gemm_variant == 21 || h->gemm_variant == 28 || (h->gemm_variant == 0 && big));
   if (use_bt) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     const size_t lds = (size_t)2 * BT_NKQ * 512 * 16 + 2 * 768 * 4;   // stage buffers + bias slots

@@ -1,0 +1,200 @@
+"""GPU parity of the 256 x 256 trials-GEMM kernels -- the kernels every BASELINE.json config runs --
+against the fp64 oracle (reference semantics: /root/reference/src/pldamodule.cpp:258-277, driven
+M x Nt times by scoring/scorePLDA.py:302-318).
+
+`launch_gemm` (plda_amd/csrc/score.hip) picks a kernel by problem size, so the oracle tests of
+test_gpu_scoring.py (<= 517 columns) only ever reach the 128 x 128 kernel.  Here:
+
+  (i)   forced dispatch (PLDA_GEMM_VARIANT, read at plda_create) on shapes small enough for the
+        per-trial C oracle `score_block`: variant 30 = second-generation big-tile kernel (product),
+        28 / 21 = first-generation kernel with buffer-descriptor / global_load_lds staging (the
+        latter is the product path for packed operands >= 4 GiB); uniform n, mixed n (GEMM depth 2D,
+        no column bias) and the z-norm folded epilogue; ragged edges in both dimensions;
+  (ii)  default dispatch at 8192 x 8192 (exactly the 1024-tile threshold) with the BASELINE shapes'
+        depths -- D = 200 uniform n (C2), D = 512 n = 100 (C3), D = 256 mixed n in 1..5 (C4),
+        D = 200 z-normalised (C5) -- against the fp64 GEMM-form oracle `llr_matrix`;
+  (iii) a packed test operand of 4.3 GB, which default dispatch must route to the global_load_lds
+        instantiation (`fits4g == false`), checked on sampled rows x columns;
+  (iv)  all kernels contract in the same k order, so their fp32 outputs are BIT-identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import score_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(d, seed):
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    T = q * (1.0 + rng.random(d))[:, None]
+    psi = np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy()
+    return rng.random(d), T, psi
+
+
+def _engine(monkeypatch, variant, d, seed=3):
+    from plda_amd import MPlda
+    if variant is None:
+        monkeypatch.delenv("PLDA_GEMM_VARIANT", raising=False)
+    else:
+        monkeypatch.setenv("PLDA_GEMM_VARIANT", str(variant))
+    eng = MPlda(0)
+    mean, T, psi = _model(d, seed)
+    eng.set_model(mean, T, psi)
+    return eng, psi
+
+
+def _vectors(rng, rows, d, scale=1.0):
+    """Rows of the magnitude TransformIvector produces (|t|^2 ~ D), without going through it."""
+    return rng.standard_normal((rows, d)) * scale
+
+
+# ---------------------------------------------------------------- (i) forced dispatch, C oracle
+SHAPES = [(200, 300, 517), (64, 1024, 1024), (33, 257, 769), (200, 1, 700), (8, 513, 255)]
+
+
+@pytest.mark.parametrize("variant", [30, 28, 21])
+@pytest.mark.parametrize("d,m,nt", SHAPES)
+def test_forced_uniform(monkeypatch, oracle, variant, d, m, nt):
+    eng, psi = _engine(monkeypatch, variant, d)
+    rng = np.random.default_rng(100 + d + m)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    for n in (1, 7):
+        ref = oracle.score_block(psi, U, n, V)
+        got = eng.score_matrix((n, U), (1, V))
+        assert (np.abs(got - ref) <= score_tol(ref)).all(), (variant, n, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("variant", [30, 28, 21])
+@pytest.mark.parametrize("d,m,nt", [(96, 300, 517), (256, 700, 300), (20, 1024, 1024)])
+def test_forced_mixed_counts(monkeypatch, oracle, variant, d, m, nt):
+    """enrol counts differ -> GEMM depth 2D ([A1 | A2] x [V | V*V]), cbias == nullptr."""
+    eng, psi = _engine(monkeypatch, variant, d)
+    rng = np.random.default_rng(200 + d)
+    counts = rng.integers(1, 6, m).astype(np.int32)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    ref = oracle.score_block(psi, U, counts, V)
+    got = eng.score_matrix((counts, U), (1, V))
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), (variant, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("variant", [30, 28, 21])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_forced_znorm(monkeypatch, oracle, variant, mixed):
+    """z-norm (pldamodule.cpp:269-273) in the big-tile epilogue; rows without statistics stay raw."""
+    d, m, nt = 120, 300, 517
+    eng, psi = _engine(monkeypatch, variant, d)
+    rng = np.random.default_rng(300 + int(mixed))
+    counts = rng.integers(1, 6, m).astype(np.int32) if mixed else np.full(m, 3, np.int32)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    raw = oracle.score_block(psi, U, counts, V)
+    zm, zs = raw.mean(1), raw.std(1)
+    zs[::17] = 0.0                                   # engine convention: std 0 -> row left un-normalised
+    ids = np.arange(m, dtype=np.int64)
+    eng._meanz = {int(k): float(v) for k, v in zip(ids, zm) if zs[k] != 0.0}
+    eng._stdvz = {int(k): float(v) for k, v in zip(ids, zs) if zs[k] != 0.0}
+    zs_o = np.where(zs == 0.0, 1.0, zs); zm_o = np.where(zs == 0.0, 0.0, zm)
+    ref = oracle.score_block(psi, U, counts, V, zm_o, zs_o)
+    got = eng.score_matrix((counts, U, ids), (1, V))
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), (variant, np.abs(got - ref).max())
+
+
+def test_kernels_bit_identical(monkeypatch):
+    """(iv) the 128 x 128 kernel (variant 20), both first-generation instantiations and the
+    second-generation kernel accumulate each trial in the same k order: same bits."""
+    d, m, nt = 200, 600, 1100
+    rng = np.random.default_rng(7)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    counts = rng.integers(1, 6, m).astype(np.int32)
+    outs = {}
+    for variant in (20, 21, 28, 30):
+        eng, _ = _engine(monkeypatch, variant, d)
+        outs[variant] = (eng.score_matrix((2, U), (1, V)), eng.score_matrix((counts, U), (1, V)))
+    for variant in (21, 28, 30):
+        assert np.array_equal(outs[variant][0], outs[20][0]), variant
+        assert np.array_equal(outs[variant][1], outs[20][1]), variant
+
+
+# ---------------------------------------------------------------- (ii) default dispatch, 8192 x 8192
+def _default_case(monkeypatch, d, n_enrol, znorm, seed):
+    import torch
+    from oracle import plda_oracle_np as onp
+    dev = torch.device("cuda", 0)
+    eng, psi = _engine(monkeypatch, None, d, seed)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.profile_enable(True)
+    m = nt = 8192
+    rng = np.random.default_rng(seed)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    ref = onp.llr_matrix(psi, U, n_enrol, V)
+    dU, dV = torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev)
+    dn = None
+    if np.ndim(n_enrol):
+        dn = torch.from_numpy(np.ascontiguousarray(n_enrol, np.int32)).to(dev)
+    dzm = dzs = None
+    if znorm:
+        zm, zs = ref.mean(1), ref.std(1)
+        ref = (ref - zm[:, None]) / zs[:, None]
+        dzm, dzs = torch.from_numpy(zm).to(dev), torch.from_numpy(zs).to(dev)
+    out = torch.full((m, nt), float("nan"), dtype=torch.float32, device=dev)
+    eng.score_matrix_dev(dU.data_ptr(), dn.data_ptr() if dn is not None else None,
+                         0 if dn is not None else int(n_enrol), m, dV.data_ptr(), nt, out.data_ptr(), nt,
+                         dzm.data_ptr() if znorm else None, dzs.data_ptr() if znorm else None)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    assert (err <= score_tol(ref)).all(), err.max()
+
+
+def test_default_dispatch_c2_uniform(monkeypatch):
+    _default_case(monkeypatch, 200, 1, False, 21)
+
+
+def test_default_dispatch_c3_n100(monkeypatch):
+    _default_case(monkeypatch, 512, 100, False, 22)
+
+
+def test_default_dispatch_c4_mixed(monkeypatch):
+    n = np.random.default_rng(4).integers(1, 6, 8192).astype(np.int32)
+    _default_case(monkeypatch, 256, n, False, 23)
+
+
+def test_default_dispatch_c5_znorm(monkeypatch):
+    _default_case(monkeypatch, 200, 1, True, 24)
+
+
+def test_default_dispatch_small_dims(monkeypatch):
+    _default_case(monkeypatch, 16, 3, False, 25)       # two 16-k steps per tile: one 2-step stage
+    _default_case(monkeypatch, 8, 1, False, 26)        # a single step per tile
+    _default_case(monkeypatch, 150, 2, True, 27)       # targetdim = 150 depth (19 steps: 4,4,4,4,3)
+
+
+# ---------------------------------------------------------------- (iii) packed operand >= 4 GiB
+def test_operand_over_4gib(monkeypatch):
+    """D = 512 with mixed counts packs the test side to 256 k-quads x 16 B per row: 1.02 M rows make it
+    4.3 GB, beyond 32-bit buffer offsets, so the first-generation kernel with global_load_lds staging
+    (64-bit addresses) is the product path.  Checked on every row x 4096 sampled columns (the tail
+    columns included)."""
+    import torch
+    from oracle import plda_oracle_np as onp
+    dev = torch.device("cuda", 0)
+    d, m, nt = 512, 256, 1_017_000
+    eng, psi = _engine(monkeypatch, None, d, 31)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    dV = torch.randn((nt, d), dtype=torch.float64, device=dev, generator=g)
+    dU = torch.randn((m, d), dtype=torch.float64, device=dev, generator=g)
+    n = np.random.default_rng(6).integers(1, 6, m).astype(np.int32)
+    dn = torch.from_numpy(n).to(dev)
+    out = torch.full((m, nt), float("nan"), dtype=torch.float32, device=dev)
+    eng.score_matrix_dev(dU.data_ptr(), dn.data_ptr(), 0, m, dV.data_ptr(), nt, out.data_ptr(), nt)
+    torch.cuda.synchronize()
+    cols = np.unique(np.concatenate([np.random.default_rng(8).integers(0, nt, 4000), np.arange(nt - 96, nt)]))
+    tc = torch.from_numpy(cols).to(dev)
+    ref = onp.llr_matrix(psi, dU.cpu().numpy(), n, dV[tc].cpu().numpy())
+    got = out[:, tc].cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
+    assert bool(torch.isfinite(out[:, ::4099]).all())
