@@ -674,14 +674,18 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
   S##a[0] = (AP)[0]; S##a[1] = (AP)[32]; S##a[2] = (AP)[64]; S##a[3] = (AP)[96];                    \
   S##b[0] = (BP)[0]; S##b[1] = (BP)[32];
 // a step that is not the last of its stage: 32 MFMAs on the current fragments x, the next step's
-// fragments into y underneath, then x <- y (24 register moves per 32 MFMAs, issued in the shadow of
-// the partner wave's MFMAs; one code path for any number of steps, which the register allocator needs:
-// separately unrolled 1/2/3/4-step stage bodies with alternating sets spilled the accumulators)
-#define BT2_XY()                                                                                    \
-  xa[0] = ya[0]; xa[1] = ya[1]; xa[2] = ya[2]; xa[3] = ya[3]; xb[0] = yb[0]; xb[1] = yb[1];
+// fragments into y underneath, and x <- y component by component in the MFMA gaps (6 register moves
+// per gap; one code path for any number of steps, which the register allocator needs: separately
+// unrolled 1/2/3/4-step stage bodies with alternating sets spilled the accumulators)
+// component t of the six fragment registers is free once the t-th group of 8 MFMAs has issued
+#define BT2_XYC(T)                                                                                  \
+  xa[0][T] = ya[0][T]; xa[1][T] = ya[1][T]; xa[2][T] = ya[2][T]; xa[3][T] = ya[3][T];               \
+  xb[0][T] = yb[0][T]; xb[1][T] = yb[1][T];
 #define BT2_STEP_MID(AP, BP)                                                                        \
   BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, AP, BP) BT2_SB;                                               \
-  BT2_MFMA8(1, x) BT2_MFMA8(2, x) BT2_MFMA8(3, x) BT2_SB; BT2_XY() BT2_SB;
+  BT2_MFMA8(1, x) BT2_SB; BT2_XYC(0) BT2_SB; BT2_MFMA8(2, x) BT2_SB; BT2_XYC(1) BT2_SB;             \
+  BT2_MFMA2(3, x, 0) BT2_MFMA2(3, x, 1) BT2_SB; BT2_XYC(2) BT2_SB; BT2_MFMA2(3, x, 2) BT2_MFMA2(3, x, 3) BT2_SB; \
+  BT2_XYC(3) BT2_SB;
 // the last step of a stage: early barrier, then MFMAs with the next stage's first fragments and
 // the DMA pieces of the stage after that underneath
 #define BT2_STEP_LAST()                                                                             \
@@ -689,10 +693,12 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
   BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, An, Bn) BT2_SB;                                               \
   BT2_MFMA2(1, x, 0) BT2_SB; dma_piece(0); BT2_SB; BT2_MFMA2(1, x, 1) BT2_SB; dma_piece(1); BT2_SB; \
   BT2_MFMA2(1, x, 2) BT2_SB; dma_piece(2); BT2_SB; BT2_MFMA2(1, x, 3) BT2_SB; dma_piece(3); BT2_SB; \
+  BT2_XYC(0) BT2_SB;                                                                                \
   BT2_MFMA2(2, x, 0) BT2_SB; dma_piece(4); BT2_SB; BT2_MFMA2(2, x, 1) BT2_SB; dma_piece(5); BT2_SB; \
   BT2_MFMA2(2, x, 2) BT2_SB; dma_piece(6); BT2_SB; BT2_MFMA2(2, x, 3) BT2_SB; dma_piece(7); BT2_SB; \
-  dma_advance(); BT2_SB;                                                                            \
-  BT2_MFMA8(3, x) BT2_SB; BT2_XY() BT2_SB;
+  BT2_XYC(1) BT2_SB;                                                                                \
+  BT2_MFMA2(3, x, 0) BT2_MFMA2(3, x, 1) BT2_SB; dma_advance(); BT2_SB;                              \
+  BT2_MFMA2(3, x, 2) BT2_MFMA2(3, x, 3) BT2_SB; BT2_XYC(2) BT2_XYC(3) BT2_SB;
 
 template <bool ZN, int MODE>
 __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
@@ -765,13 +771,18 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   // tile the pieces re-fetch the last position; nothing consumes them.
   auto dma_advance = [&]() {
     if (d_st == 0 && d_ok) {
+      // buffer (MUBUF) DMA, not global_load_lds: a pending FLAT-encoded LDS load makes the compiler's
+      // waitcnt pass turn every LDS wait of the epilogue into lgkmcnt(0)
       float *dst = bias_lds + d_slot * 768;
       if (wave == 0)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rbias + d_r0 + lane * 4), (LDS_AS void *)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rbias), 0, -1, 0x00020000),
+                                                 (LDS_AS void *)dst, 16, lane16, d_r0 * 4, 0, 0);
       else if (wave == 1 && cbias)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(cbias + d_c0 + lane * 4), (LDS_AS void *)(dst + 256), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cbias), 0, -1, 0x00020000),
+                                                 (LDS_AS void *)(dst + 256), 16, lane16, d_c0 * 4, 0, 0);
       else if (wave == 2 && ZN)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rscale + d_r0 + lane * 4), (LDS_AS void *)(dst + 512), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rscale), 0, -1, 0x00020000),
+                                                 (LDS_AS void *)(dst + 512), 16, lane16, d_r0 * 4, 0, 0);
     }
     const unsigned npd = (unsigned)(sbase + (d_st < srem ? 1 : 0));
     d_offA += npd * strideA2;
@@ -794,7 +805,11 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   int tseq = 0, st = 0;
   auto early_barrier = [&]() {
     if (TL) t_arr = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (the builtin, not inline asm: the compiler's waitcnt pass must see this drain, or it keeps the
+    //  bias DMA -- a FLAT-encoded global_load_lds -- "pending" forever and turns every later LDS wait
+    //  of the epilogue into lgkmcnt(0))
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     if (TL) {
       t_lv = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && lane == 0 && tseq < 8 && st < 16) {
@@ -808,7 +823,8 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
   dma_advance();
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
   dma_advance();
@@ -855,29 +871,60 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
                             ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
       // the store pointer walks down the wave's 128 rows, 4 rows per store
       float *dst = out + (wrow0 + rrow) * ld + wcol0 + rcol;
-      int64_t row = wrow0 + rrow;
       const int64_t ld4 = 4 * ld;
+      // chunk c = 8 rows x 64 columns: W(c) bias + 8 values per lane into the staging tile, R(c) two
+      // 16-byte row reads back, S(c) two 16-byte non-temporal stores (4 rows x 256 B per instruction)
+      auto chunk_w = [&](int c, const f32x4 &rb, const f32x4 &rs) {
+        const int tm = c >> 2, q = c & 3;
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-          f32x4 rs = {1.f, 1.f, 1.f, 1.f};
-          if (ZN) rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[tm][tn][4 * q + e] + cb[tn];
+            v = ZN ? v * rs[e] + rb[e] : v + rb[e];
+            stg[(4 * hh + e) * 64 + tn * 32 + i] = v;
+          }
+      };
+      auto bias_of = [&](int c, f32x4 &rb, f32x4 &rs) {
+        const int tm = c >> 2, q = c & 3;
+        rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+        if (ZN) rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+      };
+      if (interior) {
+        // software pipeline W(c) R(c) S(c-1): a wave's LDS operations execute in order, so W(c) may be
+        // issued behind R(c-1) on the same 2 KiB, and the stores of chunk c-1 wait only for R(c-1)
+        f32x4 pv[2][2];
+        f32x4 rbv[2], rsv[2];
+        rsv[0] = rsv[1] = f32x4{1.f, 1.f, 1.f, 1.f};
+        bias_of(0, rbv[0], rsv[0]);
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
+        for (int c = 0; c < 16; ++c) {
+          if (c + 1 < 16) bias_of(c + 1, rbv[(c + 1) & 1], rsv[(c + 1) & 1]);
+          chunk_w(c, rbv[c & 1], rsv[c & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          pv[c & 1][0] = *reinterpret_cast<const f32x4 *>(stg + lane * 4);
+          pv[c & 1][1] = *reinterpret_cast<const f32x4 *>(stg + 256 + lane * 4);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c > 0) {
+            __builtin_nontemporal_store(pv[(c - 1) & 1][0], reinterpret_cast<f32x4 *>(dst));
+            __builtin_nontemporal_store(pv[(c - 1) & 1][1], reinterpret_cast<f32x4 *>(dst + ld4));
+            dst += 2 * ld4;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_nontemporal_store(pv[1][0], reinterpret_cast<f32x4 *>(dst));
+        __builtin_nontemporal_store(pv[1][1], reinterpret_cast<f32x4 *>(dst + ld4));
+      } else {
+        int64_t row = wrow0 + rrow;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = acc[tm][tn][4 * q + e] + cb[tn];
-              v = ZN ? v * rs[e] + rb[e] : v + rb[e];
-              stg[(4 * hh + e) * 64 + tn * 32 + i] = v;
-            }
+        for (int c = 0; c < 16; ++c) {
+          f32x4 rb, rs = {1.f, 1.f, 1.f, 1.f};
+          bias_of(c, rb, rs);
+          chunk_w(c, rb, rs);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + k * 256 + lane * 4);
-            if (interior) {
-              __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
-            } else if (row < M) {
+            if (row < M) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
@@ -901,11 +948,11 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     c0 = c_slot == 0 ? q_c0[0] : (c_slot == 1 ? q_c0[1] : q_c0[2]);
     have = c_slot == 0 ? q_ok[0] : (c_slot == 1 ? q_ok[1] : q_ok[2]);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may land in LDS after the workgroup has gone
+  __builtin_amdgcn_s_waitcnt(0x0070);   // no DMA may land in LDS after the workgroup has gone
 }
 #undef BT2_STEP_LAST
 #undef BT2_STEP_MID
-#undef BT2_XY
+#undef BT2_XYC
 #undef BT2_LOAD
 #undef BT2_MFMA8
 #undef BT2_MFMA2
