@@ -83,7 +83,6 @@ struct plda_handle {
   bool bt2_attr_set = false;
   bool timeline_valid = false;   // `timeline` holds the stamps of a PLDA_GEMM_VARIANT=31 launch
   plda::DevBuf timeline;
-  bool bt_attr_set = false;  // tuning knob (PLDA_GEMM_VARIANT): stage depth x occupancy instantiation
 
   // ---- profiling (plda_profile_*): event pairs around each trials-GEMM launch ----
   bool prof_on = false;

@@ -23,6 +23,8 @@
 // fragment read is one conflict-free ds_read_b128 per lane that feeds 4 MFMAs.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace plda {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
 //   grid   = 1-D, XCD-aware: block b -> XCD b % 8 (observed dispatch order), and each
 //            XCD walks its own sequence of PM x PN tile patches so that the panels
 //            its resident blocks share stay in that XCD's 4 MiB L2.
-//   EPI 0  : out[i][j] = rscale_i * (acc + cbias_j) + rbias_i, transposed through LDS and
-//            written as 16-byte non-temporal stores
+//   EPI 0  : out[i][j] = acc (started from rbias_i + cbias_j), or rscale_i * acc + rbias_i (started from
+//            cbias_j) with the z-norm map; transposed through LDS, 16-byte non-temporal stores
 //   EPI 1  : fused z-norm statistics -- per column j accumulate sum / sum of squares
 //            of (score - shift_j) over rows i < M into fp64 (no score matrix)
 // ------------------------------------------------------------------------------------
@@ -293,13 +295,15 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? cbias[wcol0 + tn * 32 + i] : 0.f;
 
+  // accumulators start from the bias r_i + q_j (q_j alone when the z-norm map follows): the same
+  // initial value and k order as the 256 x 256 kernel, hence the same bits
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = (ZN && EPI == 0) ? cb[c] : rb[a][r >> 2][r & 3] + cb[c];
 
   const int nst = (KQ + NKQ - 1) / NKQ;
   __syncthreads();
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[tm][tn][r] + cb[tn] + rb[tm][r >> 2][r & 3]));
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[tm][tn][r]));
   } else if (EPI == 0) {
     f32x4 rs[2][4];
     if (ZN) {
@@ -365,8 +369,8 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[tm][tn][r] + cb[tn];
-          v = ZN ? v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3] : v + rb[tm][r >> 2][r & 3];
+          float v = acc[tm][tn][r];
+          if (ZN) v = v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3];
           tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + tn * 32 + i] = v;
         }
       // (same wave wrote and reads: LDS operations of one wave execute in order)
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = wrow0 + 4 * hh + tm * 32 + (r & 3) + 8 * (r >> 2);
-          const float d = (row < M) ? (acc[tm][tn][r] + cb[tn] + rb[tm][r >> 2][r & 3]) - sh : 0.f;
+          const float d = (row < M) ? acc[tm][tn][r] - sh : 0.f;
           s1 += d;
           s2 += d * d;
         }
@@ -410,256 +414,38 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------
-// Big-tile persistent form (EPI 0 only).  The 128x128 kernel above is limited by the
-// global->LDS DMA path (ablation: 93 % of MFMA peak without the in-loop DMA, 84 % with):
-// it moves 8 KiB per 64 MFMAs.  Here a workgroup of 8 waves (2 x 4) owns a 256 x 256 tile,
-// each wave 128 x 64 (4 x 2 MFMA tiles, 128 accumulator registers): 16 KiB per 256 MFMAs,
-// half the DMA bytes per flop, and 6 LDS fragment reads per 32 MFMAs instead of 4 per 16.
-// One workgroup per CU, persistent over tiles:
-//   * tile order: at iteration `it` XCD x works on patch (8 it + x) = BPR x BPC tiles, its
-//     32 workgroups take one tile each, so an XCD's resident tiles share 4 + 8 panels;
-//   * the next tile's first stage is DMA'd during the current tile's LAST stage, into the
-//     stage buffer that has just been freed; the other buffer (read by the last stage)
-//     becomes the wave-private staging area of the transposed epilogue;
-//   * LDS: 2 stages x 8 k-quads x 512 rows x 16 B = 128 KiB (dynamic).
-// ------------------------------------------------------------------------------------
-constexpr int BT_NKQ = 8;
 constexpr int BPR = 4, BPC = 8;   // patch of 256x256 tiles per XCD iteration (32 CUs)
 
-__device__ __forceinline__ void bt_stage(const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk,
-                                         int64_t Mpad, int64_t Npad, int kq0, int KQ, int64_t r0,
-                                         int64_t c0, f32x4 *buf, int wave, int lane) {
-  // 8 NKQ chunks of 64 rows; wave w takes chunks w, w + 8, ...: A rows 0..255 are chunks
-  // (kql, quarter) for c < 4 NKQ, B likewise after that.
-#pragma unroll
-  for (int j = 0; j < BT_NKQ; ++j) {
-    const int c = wave + 8 * j;
-    const bool isB = c >= 4 * BT_NKQ;
-    const int cc = isB ? c - 4 * BT_NKQ : c;
-    const int kql = cc >> 2, quarter = cc & 3;
-    const int kq = kq0 + kql;
-    if (kq < KQ) {
-      const f32x4 *g = isB ? Bpk + ((int64_t)kq * Npad + c0 + quarter * 64 + lane)
-                           : Apk + ((int64_t)kq * Mpad + r0 + quarter * 64 + lane);
-      f32x4 *l = buf + (isB ? BT_NKQ * 256 : 0) + kql * 256 + quarter * 64;
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)g, (LDS_AS void *)l, 16, 0, 0);
-    }
-  }
-}
-
-// Same staging through a buffer descriptor: `buffer_load_dwordx4 ... offen lds` takes ONE
-// loop-invariant VGPR (lane * 16) and a scalar byte offset, so a DMA instruction needs no
-// per-lane 64-bit address arithmetic or operands.  Requires each packed operand < 4 GiB.
-__device__ __forceinline__ void bt_stage_buf(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb_, int64_t Mpad,
-                                             int64_t Npad, int kq0, int KQ, int64_t r0, int64_t c0,
-                                             f32x4 *buf, int wave, int lane16) {
-#pragma unroll
-  for (int j = 0; j < BT_NKQ; ++j) {
-    const int c = wave + 8 * j;
-    const bool isB = c >= 4 * BT_NKQ;
-    const int cc = isB ? c - 4 * BT_NKQ : c;
-    const int kql = cc >> 2, quarter = cc & 3;
-    const int kq = kq0 + kql;
-    if (kq < KQ) {
-      f32x4 *l = buf + (isB ? BT_NKQ * 256 : 0) + kql * 256 + quarter * 64;
-      if (isB) {
-        const unsigned so = (unsigned)(((int64_t)kq * Npad + c0 + quarter * 64) * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (LDS_AS void *)l, 16, lane16, (int)so, 0, 0);
-      } else {
-        const unsigned so = (unsigned)(((int64_t)kq * Mpad + r0 + quarter * 64) * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_AS void *)l, 16, lane16, (int)so, 0, 0);
-      }
-    }
-  }
-}
-
-#define BT_MFMA8(T, S)                                                                           \
-  _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) {                                             \
-    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[tm][T], S##b[0][T], acc[tm][0], 0, 0, 0); \
-    acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(S##a[tm][T], S##b[1][T], acc[tm][1], 0, 0, 0); \
-  }
-#define BT_LOAD(S, OFF)                                                                          \
-  _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) S##a[tm] = Al[(OFF) + tm * 32];              \
-  S##b[0] = Bl[(OFF)]; S##b[1] = Bl[(OFF) + 32];
-
-template <bool ZN, bool BUF>
-__global__ __launch_bounds__(512, 2) void trials_gemm_bigtile_kernel(
-    const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, int64_t Mpad, int64_t Npad,
-    int KQ, const float *__restrict__ rbias, const float *__restrict__ rscale,
-    const float *__restrict__ cbias, float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt,
-    int tilesM, int tilesN, int patchesN, int numPatches) {
-  extern __shared__ __attribute__((aligned(16))) f32x4 smem[];   // 2 * BT_NKQ * 512 float4
-  constexpr int STAGE = BT_NKQ * 512;                             // float4 per stage buffer
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;            // 2 x 4 waves
-  const int i = lane & 31, hh = lane >> 5;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-  const int nst = (KQ + BT_NKQ - 1) / BT_NKQ;
-  const int niter = (numPatches + 7) >> 3;
-  const int lane16 = lane * 16;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(Apk), 0, (int)(KQ * Mpad * 16), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(Bpk), 0, (int)(KQ * Npad * 16), 0x00020000);
-#define BT_STAGE(KQ0, R0, C0, BUFP)                                                        \
-  if (BUF) bt_stage_buf(rsA, rsB, Mpad, Npad, (KQ0), KQ, (R0), (C0), (BUFP), wave, lane16); \
-  else bt_stage(Apk, Bpk, Mpad, Npad, (KQ0), KQ, (R0), (C0), (BUFP), wave, lane);
-
-  auto tile_of = [&](int it, int64_t &r0, int64_t &c0) -> bool {
-    const int patch = it * 8 + xcd;
-    if (patch >= numPatches) return false;
-    const int tm = (patch / patchesN) * BPR + lb / BPC;
-    const int tn = (patch % patchesN) * BPC + lb % BPC;
-    r0 = (int64_t)tm * 256;
-    c0 = (int64_t)tn * 256;
-    return tm < tilesM && tn < tilesN;
-  };
-
-  // per-tile bias area behind the two stage buffers: 2 slots x {256 row biases, 256 column
-  // biases, 256 row scales}; filled by DMA together with the tile's first stage so that the
-  // epilogue reads biases from LDS instead of waiting on global loads four times per tile
-  float *bias_lds = reinterpret_cast<float *>(smem + 2 * STAGE);
-  auto bias_stage = [&](int64_t tr, int64_t tc, int slot) {
-    float *dst = bias_lds + slot * 768;
-    if (wave == 0)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rbias + tr + lane * 4), (LDS_AS void *)dst, 16, 0, 0);
-    else if (wave == 1 && cbias)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(cbias + tc + lane * 4), (LDS_AS void *)(dst + 256), 16, 0, 0);
-    else if (wave == 2 && ZN)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(rscale + tr + lane * 4), (LDS_AS void *)(dst + 512), 16, 0, 0);
-  };
-  int tseq = 0;   // tile sequence number of this workgroup (bias slot = tseq & 1)
-
-  int base = 0;
-  int64_t r0 = 0, c0 = 0;
-  int it = 0;
-  bool have = false;
-  for (; it < niter; ++it)
-    if ((have = tile_of(it, r0, c0))) break;
-  if (have) { BT_STAGE(0, r0, c0, smem + base * STAGE) bias_stage(r0, c0, 0); }
-
-  while (have) {
-    const int64_t wrow0 = r0 + wm * 128, wcol0 = c0 + wn * 64;
-    const int64_t tr0 = r0, tc0 = c0;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-    bool next_have = false;
-    int64_t nr0 = 0, nc0 = 0;
-    for (int st = 0; st < nst; ++st) {
-      __syncthreads();   // stage st landed (vmcnt(0) + barrier); everyone is done with stage st-1
-      f32x4 *other = smem + ((base + st + 1) & 1) * STAGE;
-      if (st + 1 < nst) {
-        BT_STAGE((st + 1) * BT_NKQ, r0, c0, other)
-      } else {
-        // last stage: prefetch the NEXT tile's first stage into the freed buffer
-        for (++it; it < niter; ++it)
-          if ((next_have = tile_of(it, nr0, nc0))) break;
-        if (next_have) { BT_STAGE(0, nr0, nc0, other) bias_stage(nr0, nc0, (tseq + 1) & 1); }
-      }
-      const f32x4 *cur = smem + ((base + st) & 1) * STAGE;
-      const int np = min(BT_NKQ, KQ - st * BT_NKQ) >> 1;
-      const f32x4 *Al = cur + hh * 256 + wm * 128 + i;
-      const f32x4 *Bl = cur + BT_NKQ * 256 + hh * 256 + wn * 64 + i;
-      f32x4 xa[4], xb[2], ya[4], yb[2];
-      BT_LOAD(x, 0)
-      int p = 0;
-#pragma unroll 1
-      for (; p + 1 < np; p += 2) {
-        BT_MFMA8(0, x)
-        __builtin_amdgcn_sched_barrier(0);
-        { const int o1 = (p + 1) * 512; BT_LOAD(y, o1) }
-        __builtin_amdgcn_sched_barrier(0);
-        BT_MFMA8(1, x) BT_MFMA8(2, x) BT_MFMA8(3, x)
-        BT_MFMA8(0, y)
-        __builtin_amdgcn_sched_barrier(0);
-        { const int o2 = min(p + 2, np - 1) * 512; BT_LOAD(x, o2) }
-        __builtin_amdgcn_sched_barrier(0);
-        BT_MFMA8(1, y) BT_MFMA8(2, y) BT_MFMA8(3, y)
-      }
-      if (p < np) { BT_MFMA8(0, x) BT_MFMA8(1, x) BT_MFMA8(2, x) BT_MFMA8(3, x) }
-    }
-
-    // ---- epilogue: staging area = the buffer the last stage read ----
-    __syncthreads();   // all waves are done reading the last stage's buffer
-    const float *bl = bias_lds + (tseq & 1) * 768;
-    float cb[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? bl[256 + wn * 64 + tn * 32 + i] : 0.f;
-    float *tw = reinterpret_cast<float *>(smem + ((base + nst - 1) & 1) * STAGE) + wave * 2048;
-    const int rrow = lane >> 4, rcol = (lane & 15) * 4;
-    const bool interior = (tr0 + 256 <= M) && (tc0 + 256 <= Nt) && ((ld & 3) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      f32x4 rb[4], rs[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rb[q] = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-        if (ZN) rs[q] = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-      }
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[tm][tn][r] + cb[tn];
-          v = ZN ? v * rs[r >> 2][r & 3] + rb[r >> 2][r & 3] : v + rb[r >> 2][r & 3];
-          tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + tn * 32 + i] = v;
-        }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int lr = rrow + 4 * k;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(tw + lr * 64 + rcol);
-        const int64_t row = wrow0 + tm * 32 + lr;
-        float *dst = out + row * ld + wcol0 + rcol;
-        if (interior) {
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
-        } else if (row < M) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
-        }
-      }
-    }
-    base = (base + nst) & 1;
-    ++tseq;
-    have = next_have;
-    r0 = nr0; c0 = nc0;
-  }
-}
-#undef BT_STAGE
-#undef BT_MFMA8
-#undef BT_LOAD
-
 // ------------------------------------------------------------------------------------
-// Big-tile form, second generation ("bt2"; product path).  Same 256 x 256 tile, 8 waves of
-// 128 x 64, same operand layout, fragment scheme and k-order as the kernel above (so its
-// scores are bit-identical), but a different pipeline.  What the round-1 kernel lost
-// (82 % MFMA-busy) sat in the stage boundary: after `vmcnt(0) + s_barrier` all 8 waves ran
-// the stage's DMA issue -- ~200 scalar instructions of 64-bit addressing with SGPR spills
-// per wave -- then waited for their first fragment reads, with the matrix pipe idle.  Here
+// K5, large problems (the product path of every BASELINE.json configuration): persistent 256 x 256
+// form.  A workgroup of 8 waves (2 x 4) owns a 256 x 256 tile, each wave 128 x 64 (4 x 2 MFMA
+// tiles, 128 accumulator registers); one workgroup per CU, persistent over tiles; tile order: at
+// iteration `it` XCD x works on patch (8 it + x) = BPR x BPC tiles, its 32 workgroups one tile
+// each, so an XCD's resident tiles share 4 + 8 operand panels in its L2.  Same operand layout,
+// fragment scheme and k order as the 128 x 128 kernel above, so the scores are bit-identical.
+//
+// Pipeline (round 2; the round-1 kernel of this shape ran at 82 % MFMA-busy and lost the rest at
+// the stage boundary: after `vmcnt(0) + s_barrier` all 8 waves executed the stage's DMA issue --
+// ~200 scalar instructions of 64-bit addressing with SGPR spills per wave -- and then waited for
+// their first fragment reads, with the matrix pipe idle):
 //   * DMA addressing is two scalar adds per 1 KiB piece: per-wave byte offsets into a buffer
-//     descriptor (soffset) and into LDS (M0) are kept in SGPRs and advanced per stage;
-//   * the stage barrier moves EARLY: it sits in front of the LAST 16-k step of a stage, when
-//     the fragments of that step are already in registers.  Behind it every wave knows (a)
-//     stage g+1 has landed (each wave drained its own DMAs before the barrier) and (b) nobody
-//     reads stage g's buffer any more -- so the step's 32 MFMAs issue at once, the fragments of
-//     stage g+1's first step are fetched under them, and the DMA pieces of stage g+2 are
-//     issued one per two MFMAs into the buffer just freed.  No wave ever stands at a barrier
-//     with nothing queued behind it;
-//   * the pipeline is uniform across tile boundaries: the epilogue owns a separate 16 KiB
-//     staging area (2 KiB per wave, 8 x 64 outputs per round trip), so the DMA stream and the
-//     fragment prefetch of the next tile run through it, and there is no barrier at the
-//     tile boundary at all;
+//     descriptor (soffset) and into LDS (M0) live in SGPRs and advance per stage;
+//   * the stage barrier sits EARLY, in front of the LAST 16-k step of a stage, when that step's
+//     fragments are already in registers.  Behind it every wave knows (a) stage g+1 has landed
+//     (each wave drained its own DMAs first) and (b) nobody reads stage g's buffer any more -- so
+//     the step's 32 MFMAs issue at once, the fragments of stage g+1's first step are fetched under
+//     them, and the DMA pieces of stage g+2 go out one per two MFMAs into the buffer just freed.
+//     No wave ever stands at a barrier with nothing queued behind it;
+//   * the pipeline is uniform across tile boundaries: the epilogue owns a separate 16 KiB staging
+//     area (2 KiB per wave, 8 x 64 outputs per round trip, software-pipelined write / read-back /
+//     store), so the DMA stream and the fragment prefetch of the next tile run through it, and
+//     there is no barrier at a tile boundary at all;
+//   * the accumulators start from the bias terms r_i + q_j (staged per tile by DMA) instead of
+//     zero, which costs the same 128 register writes and leaves the epilogue without arithmetic;
 //   * K is cut into balanced stages of 2..4 steps (25 steps at D = 200 -> 4,4,4,4,3,3,3).
 // LDS: 2 x 64 KiB stage buffers + 16 KiB staging + 3 x 3 KiB bias slots = 153 KiB.
-// Packed operands must be < 4 GiB each (32-bit soffset); larger ones take the kernel above.
+// Packed operands must be < 4 GiB each (32-bit soffset) and ld < 2^22 (32-bit store offsets inside a
+// tile); the host splits larger problems into column / row blocks.
 // ------------------------------------------------------------------------------------
 constexpr int BT2_STG = 2 * 65536;                 // byte offset of the epilogue staging area
 constexpr int BT2_BIAS = BT2_STG + 16384;          // 3 slots x 768 floats
@@ -708,6 +494,8 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     int numPatches, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
   constexpr bool TL = (MODE & 1) != 0;                            // timeline instrumentation (diagnostic)
+  constexpr bool EPI_PRIO = (MODE & 2) != 0;                      // tuning arm: s_setprio 3 around the epilogue
+  constexpr bool HALF_PRIO = (MODE & 4) != 0;                     // tuning arm: static s_setprio 1 for waves 4..7
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
@@ -819,6 +607,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     }
   };
 
+  if (HALF_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
   // ---- prologue: stage 0 of the first tile, barrier, then stage 1 in a burst ----
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
@@ -838,13 +627,26 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   BT2_LOAD(x, Abase, Bbase)
 
   while (have) {
+    // accumulators start from the bias: r_i + q_j, or q_j alone when the z-norm map follows
+    // (out = rscale_i (acc) + rbias_i).  The tile's bias slot landed with its first stage.
+    const float *const bl = bias_lds + c_slot * 768;
     f32x16 acc[4][2];
+    {
+      float cb[2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? bl[256 + wn * 64 + tn * 32 + i] : 0.f;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+          f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+          if (!ZN) rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[tm][tn][4 * q + e] = ZN ? cb[tn] : rb[e] + cb[tn];
+        }
+    }
 
     for (st = 0; st < nst; ++st) {
       const int np = sbase + (st < srem ? 1 : 0);
@@ -859,68 +661,62 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     // ---- epilogue: 16 round trips of 8 rows x 64 columns through this wave's 2 KiB of staging ----
     unsigned long long t_e0 = 0;
     if (TL) t_e0 = __builtin_amdgcn_s_memtime();
+    if (EPI_PRIO) __builtin_amdgcn_s_setprio(3);
     {
-      const float *bl = bias_lds + c_slot * 768;
-      float cb[2];
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? bl[256 + wn * 64 + tn * 32 + i] : 0.f;
       float *stg = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + BT2_STG) + wave * 512;
       const int rrow = lane >> 4, rcol = (lane & 15) * 4;
-      const int64_t wrow0 = (int64_t)r0 + wm * 128, wcol0 = (int64_t)c0 + wn * 64;
       const bool interior = ((int64_t)r0 + 256 <= M) && ((int64_t)c0 + 256 <= Nt) && ((ld & 3) == 0) &&
                             ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-      // the store pointer walks down the wave's 128 rows, 4 rows per store
-      float *dst = out + (wrow0 + rrow) * ld + wcol0 + rcol;
-      const int64_t ld4 = 4 * ld;
-      // chunk c = 8 rows x 64 columns: W(c) bias + 8 values per lane into the staging tile, R(c) two
-      // 16-byte row reads back, S(c) two 16-byte non-temporal stores (4 rows x 256 B per instruction)
-      auto chunk_w = [&](int c, const f32x4 &rb, const f32x4 &rs) {
+      // chunk c = 8 rows x 64 columns: W(c) 8 values per lane into the staging tile, R(c) two 16-byte
+      // row reads back, S(c) two 16-byte non-temporal stores (4 rows x 256 B per instruction)
+      auto chunk_w = [&](int c) {
         const int tm = c >> 2, q = c & 3;
+        f32x4 rb, rs;
+        if (ZN) {
+          rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+          rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+        }
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = acc[tm][tn][4 * q + e] + cb[tn];
-            v = ZN ? v * rs[e] + rb[e] : v + rb[e];
-            stg[(4 * hh + e) * 64 + tn * 32 + i] = v;
+            const float v = acc[tm][tn][4 * q + e];
+            stg[(4 * hh + e) * 64 + tn * 32 + i] = ZN ? v * rs[e] + rb[e] : v;
           }
       };
-      auto bias_of = [&](int c, f32x4 &rb, f32x4 &rs) {
-        const int tm = c >> 2, q = c & 3;
-        rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-        if (ZN) rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-      };
       if (interior) {
-        // software pipeline W(c) R(c) S(c-1): a wave's LDS operations execute in order, so W(c) may be
-        // issued behind R(c-1) on the same 2 KiB, and the stores of chunk c-1 wait only for R(c-1)
+        // stores address the tile through a scalar base and a 32-bit lane offset that walks down the
+        // wave's 128 rows, 4 rows per store (the host guarantees 256 ld < 2^30 elements).
+        // Software pipeline W(c) R(c) S(c-1): a wave's LDS operations execute in order, so W(c) may be
+        // issued behind R(c-1) on the same 2 KiB, and the stores of chunk c-1 wait only for R(c-1).
+        char *const tbase = reinterpret_cast<char *>(out + ((int64_t)r0 * ld + c0));
+        const unsigned ldb = (unsigned)ld * 4u;
+        unsigned voff = (unsigned)(wm * 128 + rrow) * ldb + (unsigned)(wn * 64 + rcol) * 4u;
+        asm volatile("" : "+v"(voff));   // opaque: keeps the 32 offsets from being hoisted out of the tile loop as 64 live registers
         f32x4 pv[2][2];
-        f32x4 rbv[2], rsv[2];
-        rsv[0] = rsv[1] = f32x4{1.f, 1.f, 1.f, 1.f};
-        bias_of(0, rbv[0], rsv[0]);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          if (c + 1 < 16) bias_of(c + 1, rbv[(c + 1) & 1], rsv[(c + 1) & 1]);
-          chunk_w(c, rbv[c & 1], rsv[c & 1]);
+          chunk_w(c);
           __builtin_amdgcn_sched_barrier(0);
           pv[c & 1][0] = *reinterpret_cast<const f32x4 *>(stg + lane * 4);
           pv[c & 1][1] = *reinterpret_cast<const f32x4 *>(stg + 256 + lane * 4);
           __builtin_amdgcn_sched_barrier(0);
           if (c > 0) {
-            __builtin_nontemporal_store(pv[(c - 1) & 1][0], reinterpret_cast<f32x4 *>(dst));
-            __builtin_nontemporal_store(pv[(c - 1) & 1][1], reinterpret_cast<f32x4 *>(dst + ld4));
-            dst += 2 * ld4;
+            __builtin_nontemporal_store(pv[(c - 1) & 1][0], reinterpret_cast<f32x4 *>(tbase + voff));
+            __builtin_nontemporal_store(pv[(c - 1) & 1][1], reinterpret_cast<f32x4 *>(tbase + (voff + 4u * ldb)));
+            voff += 8u * ldb;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_nontemporal_store(pv[1][0], reinterpret_cast<f32x4 *>(dst));
-        __builtin_nontemporal_store(pv[1][1], reinterpret_cast<f32x4 *>(dst + ld4));
+        __builtin_nontemporal_store(pv[1][0], reinterpret_cast<f32x4 *>(tbase + voff));
+        __builtin_nontemporal_store(pv[1][1], reinterpret_cast<f32x4 *>(tbase + (voff + 4u * ldb)));
       } else {
+        const int64_t wrow0 = (int64_t)r0 + wm * 128, wcol0 = (int64_t)c0 + wn * 64;
+        float *dst = out + (wrow0 + rrow) * ld + wcol0 + rcol;
         int64_t row = wrow0 + rrow;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          f32x4 rb, rs = {1.f, 1.f, 1.f, 1.f};
-          bias_of(c, rb, rs);
-          chunk_w(c, rb, rs);
+          chunk_w(c);
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + k * 256 + lane * 4);
@@ -929,12 +725,13 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
               for (int e = 0; e < 4; ++e)
                 if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
             }
-            dst += ld4;
+            dst += 4 * ld;
             row += 4;
           }
         }
       }
     }
+    if (EPI_PRIO) { if (HALF_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     if (TL) {
       const unsigned long long t_e1 = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && lane == 0 && tseq < 8) {
@@ -1058,9 +855,11 @@ struct TrialOperands {
   bool mixed;
 };
 
+// doA / doB: (re)build the enrol side (packed A, row biases, row scales) / the test side (packed B,
+// column biases); a blocked call packs each side once per block of its own dimension
 static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform,
                             int64_t M, const double *dV, int64_t Nt, const double *dzmean,
-                            const double *dzstd, TrialOperands &op) {
+                            const double *dzstd, TrialOperands &op, bool doA = true, bool doB = true) {
   const int D = h->Dout;
   const int Dp = (int)round_up(D, 8);
   op.mixed = dn != nullptr;
@@ -1079,32 +878,39 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   const bool zn = dzmean && dzstd;
   const int wpb = 4;
   if (op.mixed) {
-    enrol_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
-        dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
-        zn ? h->s_rscale.as<float>() : nullptr);
+    if (doA)
+      enrol_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
+          dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
+          zn ? h->s_rscale.as<float>() : nullptr);
   } else {
     PLDA_HIP(h, h->w[11].reserve((size_t)(2 * D + 1) * 8));
     double *coef = h->w[11].as<double>();
     uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
-    weighted_sq_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
-        dU, coef, 1.0, coef + 2 * D, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
-        zn ? h->s_rscale.as<float>() : nullptr);
-    weighted_sq_bias_kernel<<<(unsigned)ceil_div(Nt, wpb), wpb * 64, 0, h->stream>>>(
-        dV, coef + D, 0.0, coef + 2 * D, D, Nt, nullptr, nullptr, h->s_cbias.as<float>(), nullptr);
+    if (doA)
+      weighted_sq_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
+          dU, coef, 1.0, coef + 2 * D, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
+          zn ? h->s_rscale.as<float>() : nullptr);
+    if (doB)
+      weighted_sq_bias_kernel<<<(unsigned)ceil_div(Nt, wpb), wpb * 64, 0, h->stream>>>(
+          dV, coef + D, 0.0, coef + 2 * D, D, Nt, nullptr, nullptr, h->s_cbias.as<float>(), nullptr);
   }
   PLDA_LAUNCH_CHECK(h);
   const dim3 ga((unsigned)(op.Mpad / 64), (unsigned)ceil_div(op.Kg, 32));
   const dim3 gb((unsigned)(op.Npad / 64), (unsigned)ceil_div(op.Kg, 32));
   if (op.mixed) {
-    pack_kernel<1><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
-                                              op.KQ, h->s_Apk.as<float>());
-    pack_kernel<3><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
-                                              op.KQ, h->s_Bpk.as<float>());
+    if (doA)
+      pack_kernel<1><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
+                                                op.KQ, h->s_Apk.as<float>());
+    if (doB)
+      pack_kernel<3><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
+                                                op.KQ, h->s_Bpk.as<float>());
   } else {
-    pack_kernel<0><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
-                                              op.KQ, h->s_Apk.as<float>());
-    pack_kernel<2><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
-                                              op.KQ, h->s_Bpk.as<float>());
+    if (doA)
+      pack_kernel<0><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
+                                                op.KQ, h->s_Apk.as<float>());
+    if (doB)
+      pack_kernel<2><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
+                                                op.KQ, h->s_Bpk.as<float>());
   }
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
@@ -1132,12 +938,14 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     h->prof_flop += 2.0 * (double)op.Kg_alg * (double)M * (double)Nt;
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
   }
-  // big-tile persistent kernels: when there are enough 256x256 tiles to keep 256 CUs busy
+  // persistent 256 x 256 kernel: when there are enough tiles to keep 256 CUs busy (PLDA_GEMM_VARIANT=20
+  // forces the 128 x 128 kernel, 30 the 256 x 256 one; 31..35 are its diagnostic / tuning arms)
   const int btM = (int)ceil_div(M, 256), btN = (int)(op.Npad / 256);
   const bool big = EPI == 0 && (int64_t)btM * btN >= 1024;
-  // second-generation kernel (product): needs 32-bit byte offsets into each packed operand
+  // it needs 32-bit byte offsets into each packed operand and into a tile's output rows
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
-  const bool use_bt2 = EPI == 0 && fits4g && (h->gemm_variant == 30 || h->gemm_variant == 31 || (h->gemm_variant == 0 && big));
+  const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
+                       ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || (h->gemm_variant == 0 && big));
   if (use_bt2) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
@@ -1147,6 +955,14 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
                                       hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 6>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
 #define BT2L(ZN_, MODE_, DBG_)                                                                            \
@@ -1154,45 +970,23 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
       h->s_rbias.as<float>(), use_rscale ? h->s_rscale.as<float>() : nullptr,                             \
       op.mixed ? nullptr : h->s_cbias.as<float>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
-    if (h->gemm_variant == 31 && !ZN) {
+    if ((h->gemm_variant == 31 || h->gemm_variant == 35) && !ZN) {
       // diagnostic: per-wave timestamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
-      BT2L(false, 1, h->timeline.as<unsigned long long>());
+      if (h->gemm_variant == 31) BT2L(false, 1, h->timeline.as<unsigned long long>());
+      else BT2L(false, 3, h->timeline.as<unsigned long long>());
       h->timeline_valid = true;
+    } else if (h->gemm_variant == 32 && !ZN) {
+      BT2L(false, 2, nullptr);     // tuning arms (scripts/gemm_sweep.py)
+    } else if (h->gemm_variant == 33 && !ZN) {
+      BT2L(false, 4, nullptr);
+    } else if (h->gemm_variant == 34 && !ZN) {
+      BT2L(false, 6, nullptr);
     } else {
       BT2L(ZN, 0, nullptr);
     }
 #undef BT2L
-    PLDA_LAUNCH_CHECK(h);
-    if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
-    return PLDA_OK;
-  }
-  const bool use_bt = EPI == 0 && h->gemm_variant != 20 &&
-                      (h->gemm_variant == 21 || h->gemm_variant == 28 || (h->gemm_variant == 0 && big));
-  if (use_bt) {
-    const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
-    const size_t lds = (size_t)2 * BT_NKQ * 512 * 16 + 2 * 768 * 4;   // stage buffers + bias slots
-    if (!h->bt_attr_set) {
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bigtile_kernel<true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      h->bt_attr_set = true;
-    }
-    // buffer-descriptor DMA needs 32-bit byte offsets into each packed operand
-    const bool fits32 = (int64_t)op.KQ * op.Mpad * 16 < (1ll << 31) && (int64_t)op.KQ * op.Npad * 16 < (1ll << 31);
-#define BTL(BUF_)                                                                                        \
-  trials_gemm_bigtile_kernel<ZN, BUF_><<<256, 512, lds, h->stream>>>(                                    \
-      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),       \
-      use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout, \
-      ld, M, Nt, btM, btN, pN, pM * pN)
-    if (fits32 && h->gemm_variant != 21) BTL(true); else BTL(false);
-#undef BTL
     PLDA_LAUNCH_CHECK(h);
     if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
     return PLDA_OK;
@@ -1230,11 +1024,29 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
   if (M <= 0 || Nt <= 0) return PLDA_OK;
   if (!dU || !dV || !dout || ld < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
   if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix: n_uniform must be > 0 when n_enrol is NULL");
-  TrialOperands op;
-  PLDA_TRY(prepare_operands(h, dU, dn, n_uniform, M, dV, Nt, dzmean, dzstd, op));
-  h->last_M = M; h->last_Nt = Nt; h->last_k = op.mixed ? 2 * h->Dout : h->Dout;
-  if (dzmean && dzstd) return launch_gemm<0, true>(h, op, M, Nt, true, dout, ld, nullptr, nullptr, nullptr);
-  return launch_gemm<0, false>(h, op, M, Nt, false, dout, ld, nullptr, nullptr, nullptr);
+  // The 256 x 256 kernel addresses a packed operand with 32-bit byte offsets: a side whose packed form
+  // (KQ + 8 planes of 16 B per row) would reach 4 GiB is scored in row / column blocks, each side
+  // packed once per block of its own dimension.  (C3's 1 M x 512 test side is 2.2 GB: one block.)
+  const int D = h->Dout;
+  const int64_t kq8 = (int64_t)((dn ? 2 : 1) * round_up(D, 8)) / 4 + 8;
+  const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;      // rows of one block
+  const int64_t nrb = ceil_div(M, cap), ncb = ceil_div(Nt, cap);
+  const bool zn = dzmean && dzstd;
+  h->last_M = M; h->last_Nt = Nt; h->last_k = dn ? 2 * D : D;
+  for (int64_t rb = 0; rb < nrb; ++rb) {
+    const int64_t r0 = rb * cap, m = std::min(cap, M - r0);
+    for (int64_t cbk = 0; cbk < ncb; ++cbk) {
+      const int64_t c0 = cbk * cap, nt = std::min(cap, Nt - c0);
+      TrialOperands op;
+      PLDA_TRY(prepare_operands(h, dU + r0 * D, dn ? dn + r0 : nullptr, n_uniform, m, dV + c0 * D, nt,
+                                zn ? dzmean + r0 : nullptr, zn ? dzstd + r0 : nullptr, op,
+                                /*doA=*/cbk == 0, /*doB=*/ncb > 1 || rb == 0));
+      float *o = dout + r0 * ld + c0;
+      if (zn) PLDA_TRY(launch_gemm<0, true>(h, op, m, nt, true, o, ld, nullptr, nullptr, nullptr));
+      else PLDA_TRY(launch_gemm<0, false>(h, op, m, nt, false, o, ld, nullptr, nullptr, nullptr));
+    }
+  }
+  return PLDA_OK;
 }
 
 int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,

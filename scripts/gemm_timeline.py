@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PLDA_GEMM_VARIANT"] = "31"
+os.environ["PLDA_GEMM_VARIANT"] = os.environ.get("TL_VARIANT", "31")
 import torch
 from plda_amd import MPlda
 
