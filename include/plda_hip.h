@@ -153,7 +153,8 @@ int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double
 /* Diagnostic (PLDA_HIP tracing knob): with PLDA_GEMM_VARIANT=31 in the environment at
  * plda_create, the trials GEMM runs an instrumented instantiation whose workgroup 0 stamps the
  * shader clock per wave at every stage barrier (arrive, leave) and around every tile epilogue.
- * out[tile < 8][stage < 16][wave < 8][4] = {arrive, leave, epilogue start, epilogue end (stage 15)}. */
+ * out[tile < 8][stage < 16][wave < 8][8] = {barrier arrive, leave, start of steps 1..3 of the stage (0 if
+ * absent), -, epilogue start, epilogue end (the last two in stage slot 15)}. */
 int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words);
 /* algorithmic work of the last score_matrix call: flop of the trials GEMM and
  * its depth, for roofline accounting */

@@ -113,7 +113,7 @@ int hip_fail(plda_handle *h, hipError_t e, const char *what, const char *file, i
 
 #define PLDA_LAUNCH_CHECK(h) PLDA_HIP(h, hipGetLastError())
 
-constexpr size_t TIMELINE_WORDS = 8 * 16 * 8 * 4;   // [tile < 8][stage < 16][wave < 8][4] shader-clock stamps
+constexpr size_t TIMELINE_WORDS = 8 * 16 * 8 * 8;   // [tile < 8][stage < 16][wave < 8][8] shader-clock stamps
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }

@@ -459,32 +459,34 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
 #define BT2_LOAD(S, AP, BP)                                                                         \
   S##a[0] = (AP)[0]; S##a[1] = (AP)[32]; S##a[2] = (AP)[64]; S##a[3] = (AP)[96];                    \
   S##b[0] = (BP)[0]; S##b[1] = (BP)[32];
-// a step that is not the last of its stage: 32 MFMAs on the current fragments x, the next step's
-// fragments into y underneath, and x <- y component by component in the MFMA gaps (6 register moves
-// per gap; one code path for any number of steps, which the register allocator needs: separately
-// unrolled 1/2/3/4-step stage bodies with alternating sets spilled the accumulators)
-// component t of the six fragment registers is free once the t-th group of 8 MFMAs has issued
+// Steps run in pairs on two alternating fragment sets: the first step of a pair computes on x and
+// fetches the following step's fragments into y, the second computes on y and fetches into x.  Every
+// non-MFMA instruction in this stream costs the wave ~4 cycles of MFMA issue (measured: 68 instead of
+// 64 cycles per MFMA with 24 register copies + 12 other fillers per step), so nothing is copied
+// except once per stage with an odd number of steps: its first step runs alone (x, fetch into y,
+// y -> x).  One code path (separately unrolled stage bodies made the register allocator spill the
+// accumulators): the pair's second step carries the end-of-stage work -- early barrier, next stage's
+// first fragments, the DMA pieces of the stage after that -- under a uniform `last` flag.
 #define BT2_XYC(T)                                                                                  \
   xa[0][T] = ya[0][T]; xa[1][T] = ya[1][T]; xa[2][T] = ya[2][T]; xa[3][T] = ya[3][T];               \
   xb[0][T] = yb[0][T]; xb[1][T] = yb[1][T];
-#define BT2_STEP_MID(AP, BP)                                                                        \
+#define BT2_STEP_ODD(AP, BP)                                                                        \
   BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, AP, BP) BT2_SB;                                               \
   BT2_MFMA8(1, x) BT2_SB; BT2_XYC(0) BT2_SB; BT2_MFMA8(2, x) BT2_SB; BT2_XYC(1) BT2_SB;             \
-  BT2_MFMA2(3, x, 0) BT2_MFMA2(3, x, 1) BT2_SB; BT2_XYC(2) BT2_SB; BT2_MFMA2(3, x, 2) BT2_MFMA2(3, x, 3) BT2_SB; \
-  BT2_XYC(3) BT2_SB;
-// the last step of a stage: early barrier, then MFMAs with the next stage's first fragments and
-// the DMA pieces of the stage after that underneath
-#define BT2_STEP_LAST()                                                                             \
-  early_barrier(); BT2_SB;                                                                          \
-  BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, An, Bn) BT2_SB;                                               \
-  BT2_MFMA2(1, x, 0) BT2_SB; dma_piece(0); BT2_SB; BT2_MFMA2(1, x, 1) BT2_SB; dma_piece(1); BT2_SB; \
-  BT2_MFMA2(1, x, 2) BT2_SB; dma_piece(2); BT2_SB; BT2_MFMA2(1, x, 3) BT2_SB; dma_piece(3); BT2_SB; \
-  BT2_XYC(0) BT2_SB;                                                                                \
-  BT2_MFMA2(2, x, 0) BT2_SB; dma_piece(4); BT2_SB; BT2_MFMA2(2, x, 1) BT2_SB; dma_piece(5); BT2_SB; \
-  BT2_MFMA2(2, x, 2) BT2_SB; dma_piece(6); BT2_SB; BT2_MFMA2(2, x, 3) BT2_SB; dma_piece(7); BT2_SB; \
-  BT2_XYC(1) BT2_SB;                                                                                \
-  BT2_MFMA2(3, x, 0) BT2_MFMA2(3, x, 1) BT2_SB; dma_advance(); BT2_SB;                              \
-  BT2_MFMA2(3, x, 2) BT2_MFMA2(3, x, 3) BT2_SB; BT2_XYC(2) BT2_XYC(3) BT2_SB;
+  BT2_MFMA8(3, x) BT2_SB; BT2_XYC(2) BT2_XYC(3) BT2_SB;
+#define BT2_STEP_FIRST(AP, BP)                                                                      \
+  BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, AP, BP) BT2_SB;                                               \
+  BT2_MFMA8(1, x) BT2_MFMA8(2, x) BT2_MFMA8(3, x) BT2_SB;
+#define BT2_DMA(J) if (last) dma_piece(J);
+#define BT2_STEP_SECOND(AP, BP)                                                                     \
+  if (last) early_barrier();                                                                        \
+  BT2_SB; BT2_MFMA8(0, y) BT2_SB; BT2_LOAD(x, AP, BP) BT2_SB;                                       \
+  BT2_MFMA2(1, y, 0) BT2_SB; BT2_DMA(0) BT2_SB; BT2_MFMA2(1, y, 1) BT2_SB; BT2_DMA(1) BT2_SB;       \
+  BT2_MFMA2(1, y, 2) BT2_SB; BT2_DMA(2) BT2_SB; BT2_MFMA2(1, y, 3) BT2_SB; BT2_DMA(3) BT2_SB;       \
+  BT2_MFMA2(2, y, 0) BT2_SB; BT2_DMA(4) BT2_SB; BT2_MFMA2(2, y, 1) BT2_SB; BT2_DMA(5) BT2_SB;       \
+  BT2_MFMA2(2, y, 2) BT2_SB; BT2_DMA(6) BT2_SB; BT2_MFMA2(2, y, 3) BT2_SB; BT2_DMA(7) BT2_SB;       \
+  BT2_MFMA2(3, y, 0) BT2_MFMA2(3, y, 1) BT2_SB; if (last) dma_advance();                            \
+  BT2_SB; BT2_MFMA2(3, y, 2) BT2_MFMA2(3, y, 3) BT2_SB;
 
 template <bool ZN, int MODE>
 __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   const int i = lane & 31, hh = lane >> 5;
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
   const int lbm = lb / BPC, lbn = lb % BPC;                       // this workgroup's tile inside a patch
-  const int nsteps = KQ >> 1;                                     // 16-k steps per tile
+  const int nsteps = KQ >> 1;                                     // 16-k steps per tile (>= 2: the host pads K to 32)
   const int nst = (nsteps + 3) >> 2;                              // stages per tile
   const int sbase = nsteps / nst, srem = nsteps - sbase * nst;    // stage j has sbase + (j < srem) steps
   const int lane16 = lane * 16;
@@ -601,13 +603,19 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     if (TL) {
       t_lv = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && lane == 0 && tseq < 8 && st < 16) {
-        unsigned long long *p = dbg + (((size_t)tseq * 16 + st) * 8 + wave) * 4;
+        unsigned long long *p = dbg + (((size_t)tseq * 16 + st) * 8 + wave) * 8;
         p[0] = t_arr; p[1] = t_lv;
       }
     }
   };
 
   if (HALF_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  auto step_stamp = [&](int sn) {
+    if (TL) {
+      const unsigned long long ts = __builtin_amdgcn_s_memtime();
+      if (blockIdx.x == 0 && lane == 0 && tseq < 8 && st < 16) dbg[(((size_t)tseq * 16 + st) * 8 + wave) * 8 + 1 + sn] = ts;
+    }
+  };
   // ---- prologue: stage 0 of the first tile, barrier, then stage 1 in a burst ----
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
@@ -652,9 +660,20 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
       const int np = sbase + (st < srem ? 1 : 0);
       const f32x4 *Ac = Abase + cur * 4096, *Bc = Bbase + cur * 4096;
       const f32x4 *An = Abase + (cur ^ 1) * 4096, *Bn = Bbase + (cur ^ 1) * 4096;
+      int sn = 0;                // step whose fragments are in x
+      if (np & 1) {
+        step_stamp(1);
+        BT2_STEP_ODD(Ac + 512, Bc + 512)
+        sn = 1;
+      }
 #pragma unroll 1
-      for (int sn = 1; sn < np; ++sn) { BT2_STEP_MID(Ac + sn * 512, Bc + sn * 512) }
-      BT2_STEP_LAST()
+      for (; sn < np; sn += 2) {
+        const bool last = sn + 2 == np;
+        step_stamp(sn + 1);
+        BT2_STEP_FIRST(Ac + (sn + 1) * 512, Bc + (sn + 1) * 512)
+        const f32x4 *Ax = last ? An : Ac + (sn + 2) * 512, *Bx = last ? Bn : Bc + (sn + 2) * 512;
+        BT2_STEP_SECOND(Ax, Bx)
+      }
       cur ^= 1;
     }
 
@@ -735,8 +754,8 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     if (TL) {
       const unsigned long long t_e1 = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && lane == 0 && tseq < 8) {
-        unsigned long long *p = dbg + (((size_t)tseq * 16 + 15) * 8 + wave) * 4;
-        p[2] = t_e0; p[3] = t_e1;
+        unsigned long long *p = dbg + (((size_t)tseq * 16 + 15) * 8 + wave) * 8;
+        p[6] = t_e0; p[7] = t_e1;
       }
     }
     ++tseq;
@@ -747,8 +766,10 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // no DMA may land in LDS after the workgroup has gone
 }
-#undef BT2_STEP_LAST
-#undef BT2_STEP_MID
+#undef BT2_STEP_SECOND
+#undef BT2_DMA
+#undef BT2_STEP_FIRST
+#undef BT2_STEP_ODD
 #undef BT2_XYC
 #undef BT2_LOAD
 #undef BT2_MFMA8
@@ -863,7 +884,7 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   const int D = h->Dout;
   const int Dp = (int)round_up(D, 8);
   op.mixed = dn != nullptr;
-  op.Kg = op.mixed ? 2 * Dp : Dp;
+  op.Kg = std::max(op.mixed ? 2 * Dp : Dp, 32);   // >= two 16-k steps: the 256 x 256 kernel pairs them (zero planes cost nothing that matters at D <= 24)
   op.Kg_alg = op.mixed ? 2 * D : D;
   op.KQ = op.Kg / 4;
   op.Mpad = round_up(M, 256);   // 256: the big-tile kernel's block tile (the 128 kernel tolerates it)
@@ -1028,7 +1049,7 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
   // (KQ + 8 planes of 16 B per row) would reach 4 GiB is scored in row / column blocks, each side
   // packed once per block of its own dimension.  (C3's 1 M x 512 test side is 2.2 GB: one block.)
   const int D = h->Dout;
-  const int64_t kq8 = (int64_t)((dn ? 2 : 1) * round_up(D, 8)) / 4 + 8;
+  const int64_t kq8 = std::max<int64_t>((dn ? 2 : 1) * round_up(D, 8), 32) / 4 + 8;
   const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;      // rows of one block
   const int64_t nrb = ceil_div(M, cap), ncb = ceil_div(Nt, cap);
   const bool zn = dzmean && dzstd;

@@ -1,7 +1,6 @@
 """Per-wave timeline of workgroup 0 of the trials GEMM (PLDA_GEMM_VARIANT=31, plda_profile_timeline):
-shader-clock stamps at every stage barrier (arrive / leave) and around every tile epilogue.
-Diagnostic only; prints, for tiles 2..5 (steady state), per wave: cycles per stage, cycles
-waited at each barrier, epilogue cycles.  usage: gemm_timeline.py [N] [D]"""
+shader-clock stamps at every stage barrier (arrive / leave), at the start of the stage's steps and
+around every tile epilogue.  Diagnostic only.  usage: gemm_timeline.py [N] [D]"""
 import ctypes as C
 import os
 import sys
@@ -25,18 +24,28 @@ out = torch.empty((N, N), dtype=torch.float32, device=dev)
 for _ in range(2):
     eng.score_matrix_dev(U.data_ptr(), None, 1, N, U.data_ptr(), N, out.data_ptr(), N)
 torch.cuda.synchronize()
-tl = np.zeros((8, 16, 8, 4), np.uint64)
+tl = np.zeros((8, 16, 8, 8), np.uint64)
 eng._ck(eng._lib.plda_profile_timeline(eng._h, C.c_void_p(tl.ctypes.data), tl.size))
 tl = tl.astype(np.int64)
 nst = int((tl[2, :, 0, 0] != 0).sum())
 print("N=%d D=%d stages/tile=%d" % (N, D, nst))
-for t in range(2, 6):
+np.set_printoptions(linewidth=200)
+for t in range(3, 5):
     arr, lv = tl[t, :nst, :, 0], tl[t, :nst, :, 1]
-    e0, e1 = tl[t, 15, :, 2], tl[t, 15, :, 3]
+    e0, e1 = tl[t, 15, :, 6], tl[t, 15, :, 7]
     nxt = tl[t + 1, 0, :, 0]
-    print("tile %d" % t)
+    t0 = lv[0].max()
+    print("tile %d (times relative to the release of the tile's first barrier)" % t)
     print("  barrier wait (leave-arrive) per stage x wave:\n", (lv - arr))
     print("  stage length (arrive[s+1]-arrive[s]) per stage x wave:\n", np.diff(np.vstack([arr, nxt[None]]), axis=0))
-    print("  arrive spread across waves per stage:", arr.max(1) - arr.min(1))
-    print("  epilogue cycles per wave:", e1 - e0, " epilogue start spread:", e0.max() - e0.min())
+    for w in (0, 4):
+        ev = []
+        for s in range(nst):
+            ev.append(("s%d arrive" % s, arr[s, w])); ev.append(("s%d leave" % s, lv[s, w]))
+            for k in range(3):
+                if tl[t, s, w, 2 + k]: ev.append(("s%d step%d" % (s, k + 1), tl[t, s, w, 2 + k]))
+        ev.append(("epi start", e0[w])); ev.append(("epi end", e1[w]))
+        ev.sort(key=lambda x: x[1])
+        print("  wave %d:" % w, "  ".join("%s@%d" % (n, v - t0) for n, v in ev))
+    print("  epilogue cycles per wave:", e1 - e0)
     print("  tile length (wave 0):", tl[t + 1, 0, 0, 0] - tl[t, 0, 0, 0])
