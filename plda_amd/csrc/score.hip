@@ -24,7 +24,6 @@
 #include "common.hpp"
 
 #include <algorithm>
-#include <type_traits>
 
 namespace plda {
 
@@ -437,19 +436,20 @@ constexpr int BPR = 4, BPC = 8;   // patch of 256x256 tiles per XCD iteration (3
 //     the step's 32 MFMAs issue at once, the fragments of stage g+1's first step are fetched under
 //     them, and the DMA pieces of stage g+2 go out one per two MFMAs into the buffer just freed.
 //     No wave ever stands at a barrier with nothing queued behind it;
-//   * the pipeline is uniform across tile boundaries: the epilogue touches no LDS (4 x 4 transposes
-//     inside quads of lanes turn the accumulator layout into 16-byte row pieces), so the DMA stream
-//     and the fragment prefetch of the next tile run through it, and there is no barrier at a tile
-//     boundary at all;
+//   * the pipeline is uniform across tile boundaries: the epilogue owns a separate 16 KiB staging
+//     area (2 KiB per wave, 8 x 64 outputs per round trip, software-pipelined write / read-back /
+//     store), so the DMA stream and the fragment prefetch of the next tile run through it, and
+//     there is no barrier at a tile boundary at all;
 //   * the accumulators start from the bias terms r_i + q_j (staged per tile by DMA) instead of
 //     zero, which costs the same 128 register writes and leaves the epilogue without arithmetic;
 //   * K is cut into balanced stages of 2..4 steps (25 steps at D = 200 -> 4,4,4,4,3,3,3).
-// LDS: 2 x 64 KiB stage buffers + 3 x 3 KiB bias slots = 137 KiB.
+// LDS: 2 x 64 KiB stage buffers + 16 KiB staging + 3 x 3 KiB bias slots = 153 KiB.
 // Packed operands must be < 4 GiB each (32-bit soffset) and ld < 2^22 (32-bit store offsets inside a
 // tile); the host splits larger problems into column / row blocks.
 // ------------------------------------------------------------------------------------
-constexpr int BT2_BIAS = 2 * 65536;                // 3 bias slots x 768 floats behind the two stage buffers
-constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 140288 B
+constexpr int BT2_STG = 2 * 65536;                 // byte offset of the epilogue staging area
+constexpr int BT2_BIAS = BT2_STG + 16384;          // 3 slots x 768 floats
+constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
 
 #define BT2_SB __builtin_amdgcn_sched_barrier(0)
 #define BT2_MFMA2(T, S, TM)                                                                         \
@@ -682,77 +682,74 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     if (TL) t_e0 = __builtin_amdgcn_s_memtime();
     if (EPI_PRIO) __builtin_amdgcn_s_setprio(3);
     {
-      // An MFMA accumulator block (tm, tn, q) is 4 rows (registers e = 0..3: rows 8q + 4hh + e) x 32
-      // columns (lanes i).  A 4 x 4 transpose inside every quad of lanes -- two rounds of
-      // lane-exchange + select, 8 VALU operations, no LDS -- leaves lane i = 4j + l with ROW
-      // 8q + 4hh + l, COLUMNS 4j .. 4j+3: one 16-byte store per lane, 8 rows x 128 B per wave
-      // instruction.  (Round 1 took every block through LDS: 4 KiB of LDS writes, reads and waits
-      // per 16 stores, ~6 k cycles per wave and tile with both waves of a SIMD in it at once.)
-      const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
-      auto dpp = [](float v, auto ctrl) -> float {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
-                                                                     0xf, 0xf, true));
-      };
-      using QP0022 = std::integral_constant<int, 0xA0>;   // quad_perm [0,0,2,2]
-      using QP1133 = std::integral_constant<int, 0xF5>;   // [1,1,3,3]
-      using QP0101 = std::integral_constant<int, 0x44>;   // [0,1,0,1]
-      using QP2323 = std::integral_constant<int, 0xEE>;   // [2,3,2,3]
-      auto block_rows = [&](int tm, int tn, int q) -> f32x4 {
-        float m0 = acc[tm][tn][4 * q + 0], m1 = acc[tm][tn][4 * q + 1];
-        float m2 = acc[tm][tn][4 * q + 2], m3 = acc[tm][tn][4 * q + 3];
-        if (ZN) {
-          const f32x4 rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-          const f32x4 rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-          m0 = m0 * rs[0] + rb[0]; m1 = m1 * rs[1] + rb[1]; m2 = m2 * rs[2] + rb[2]; m3 = m3 * rs[3] + rb[3];
-        }
-        // (the lane exchanges are evaluated unconditionally and then selected: a convergent
-        //  operation inside a ?: arm becomes a divergent branch)
-        // round A: 2 x 2 blocks over (register bit 0, lane bit 0)
-        const float d1 = dpp(m1, QP0022{}), d0 = dpp(m0, QP1133{}), d3 = dpp(m3, QP0022{}), d2 = dpp(m2, QP1133{});
-        const float a0 = odd ? d1 : m0, a1 = odd ? m1 : d0, a2 = odd ? d3 : m2, a3 = odd ? m3 : d2;
-        // round B: (register bit 1, lane bit 1)
-        const float e2 = dpp(a2, QP0101{}), e3 = dpp(a3, QP0101{}), e0 = dpp(a0, QP2323{}), e1 = dpp(a1, QP2323{});
-        f32x4 t;
-        t[0] = hi ? e2 : a0;
-        t[1] = hi ? e3 : a1;
-        t[2] = hi ? a2 : e0;
-        t[3] = hi ? a3 : e1;
-        return t;   // lane i = 4j + l: row 8q + 4hh + l, columns 4j .. 4j+3 of the (tm, tn) block
-      };
-      const int lrow = 4 * hh + (i & 3), lcol = (i >> 2) * 4;
+      float *stg = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + BT2_STG) + wave * 512;
+      const int rrow = lane >> 4, rcol = (lane & 15) * 4;
       const bool interior = ((int64_t)r0 + 256 <= M) && ((int64_t)c0 + 256 <= Nt) && ((ld & 3) == 0) &&
                             ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-      if (interior) {
-        // a scalar tile base and a 32-bit lane offset that walks down the wave's 128 rows, 8 rows per
-        // step (the host guarantees 256 ld < 2^30 elements); the two column blocks share it
-        char *const tbase = reinterpret_cast<char *>(out + ((int64_t)r0 * ld + c0));
-        const unsigned ldb = (unsigned)ld * 4u;
-        unsigned voff = (unsigned)(wm * 128 + lrow) * ldb + (unsigned)(wn * 64 + lcol) * 4u;
-        asm volatile("" : "+v"(voff));   // opaque: keeps the 16 offsets from being hoisted out of the tile loop
+      // chunk c = 8 rows x 64 columns: W(c) 8 values per lane into the staging tile, R(c) two 16-byte
+      // row reads back, S(c) two 16-byte non-temporal stores (4 rows x 256 B per instruction)
+      auto chunk_w = [&](int c) {
+        const int tm = c >> 2, q = c & 3;
+        f32x4 rb, rs;
+        if (ZN) {
+          rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+          rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
+        }
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            __builtin_nontemporal_store(block_rows(tm, 0, q), reinterpret_cast<f32x4 *>(tbase + voff));
-            __builtin_nontemporal_store(block_rows(tm, 1, q), reinterpret_cast<f32x4 *>(tbase + voff + 128));
-            voff += 8u * ldb;
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[tm][tn][4 * q + e];
+            stg[(4 * hh + e) * 64 + tn * 32 + i] = ZN ? v * rs[e] + rb[e] : v;
           }
+      };
+      if (interior) {
+        // stores address the tile through a scalar base that walks down the wave's 128 rows, 4 rows per
+        // store, plus a constant 32-bit lane offset (the host guarantees ld < 2^22).
+        // Software pipeline W(c) R(c) S(c-1): a wave's LDS operations execute in order, so W(c) may be
+        // issued behind R(c-1) on the same 2 KiB, and the stores of chunk c-1 wait only for R(c-1).
+        // (the walk is done on the SCALAR base -- two SALU adds per store -- and the lane offset stays
+        //  constant: vector ALU work in the epilogue waits behind the partner wave's MFMAs)
+        const char *tbase = reinterpret_cast<const char *>(out + (((int64_t)r0 + wm * 128) * ld + c0 + wn * 64));
+        const int64_t ldb4 = 16 * ld;                           // bytes per 4 rows
+        unsigned voff = (unsigned)rrow * ((unsigned)ld * 4u) + (unsigned)rcol * 4u;
+        asm volatile("" : "+v"(voff));   // opaque: one live register, not 32 hoisted addresses
+        f32x4 pv[2][2];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          chunk_w(c);
+          __builtin_amdgcn_sched_barrier(0);
+          pv[c & 1][0] = *reinterpret_cast<const f32x4 *>(stg + lane * 4);
+          pv[c & 1][1] = *reinterpret_cast<const f32x4 *>(stg + 256 + lane * 4);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c > 0) {
+            __builtin_nontemporal_store(pv[(c - 1) & 1][0], reinterpret_cast<f32x4 *>(const_cast<char *>(tbase) + voff));
+            __builtin_nontemporal_store(pv[(c - 1) & 1][1], reinterpret_cast<f32x4 *>(const_cast<char *>(tbase + ldb4) + voff));
+            tbase += 2 * ldb4;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_nontemporal_store(pv[1][0], reinterpret_cast<f32x4 *>(const_cast<char *>(tbase) + voff));
+        __builtin_nontemporal_store(pv[1][1], reinterpret_cast<f32x4 *>(const_cast<char *>(tbase + ldb4) + voff));
       } else {
         const int64_t wrow0 = (int64_t)r0 + wm * 128, wcol0 = (int64_t)c0 + wn * 64;
+        float *dst = out + (wrow0 + rrow) * ld + wcol0 + rcol;
+        int64_t row = wrow0 + rrow;
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int c = 0; c < 16; ++c) {
+          chunk_w(c);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+          for (int k = 0; k < 2; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + k * 256 + lane * 4);
+            if (row < M) {
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-              const f32x4 v = block_rows(tm, tn, q);
-              const int64_t row = wrow0 + tm * 32 + 8 * q + lrow, col = wcol0 + tn * 32 + lcol;
-              if (row < M) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (col + e < Nt) __builtin_nontemporal_store(v[e], out + row * ld + col + e);
-              }
+              for (int e = 0; e < 4; ++e)
+                if (wcol0 + rcol + e < Nt) __builtin_nontemporal_store(v[e], dst + e);
             }
+            dst += 4 * ld;
+            row += 4;
+          }
+        }
       }
     }
     if (EPI_PRIO) { if (HALF_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
