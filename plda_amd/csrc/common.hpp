@@ -61,7 +61,7 @@ struct plda_handle {
   size_t one_cap = 0;
 
   // ---- scoring workspace ----
-  plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias;
+  plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias, s_rpair, s_cpair;
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 

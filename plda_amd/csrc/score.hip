@@ -120,6 +120,18 @@ __global__ void weighted_sq_bias_kernel(const double *__restrict__ X, const doub
   }
 }
 
+// The 256 x 256 kernel forms its starting value r'_i + s_i q_j with one rank-2 MFMA per accumulator
+// (k = 0: r'_i x 1, k = 1: s_i x q_j), so it wants the biases as k-pairs:
+//   rpair[row] = (r'_i, s_i)   cpair[col] = (1, q_j)
+// where r'_i = r_i, s_i = 1 without z-norm and r'_i = (r_i - zmean_i) / zstd_i, s_i = 1 / zstd_i with it.
+__global__ void bias_pairs_kernel(const float *__restrict__ rbias, const float *__restrict__ rscale, int64_t M,
+                                  const float *__restrict__ cbias, int64_t Nt, float2 *__restrict__ rpair,
+                                  float2 *__restrict__ cpair) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < M) rpair[t] = make_float2(rbias[t], rscale[t]);
+  if (t < Nt) cpair[t] = make_float2(1.f, cbias[t]);
+}
+
 // ------------------------------------------------------------------------------------
 // pack: fp64 [R, D] row-major  ->  fp32 k-quad packed P[kq][Rpad][4], through an LDS
 // transpose so that both the fp64 reads (256 B per half-wave) and the packed
@@ -202,8 +214,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
 //   grid   = 1-D, XCD-aware: block b -> XCD b % 8 (observed dispatch order), and each
 //            XCD walks its own sequence of PM x PN tile patches so that the panels
 //            its resident blocks share stay in that XCD's 4 MiB L2.
-//   EPI 0  : out[i][j] = acc (started from rbias_i + cbias_j), or rscale_i * acc + rbias_i (started from
-//            cbias_j) with the z-norm map; transposed through LDS, 16-byte non-temporal stores
+//   EPI 0  : out[i][j] = acc (started from the bias, z-norm map folded in); transposed through LDS,
+//            16-byte non-temporal stores
 //   EPI 1  : fused z-norm statistics -- per column j accumulate sum / sum of squares
 //            of (score - shift_j) over rows i < M into fp64 (no score matrix)
 // ------------------------------------------------------------------------------------
@@ -256,7 +268,7 @@ __device__ __forceinline__ void stage_tiles(const f32x4 *__restrict__ Apk,
   acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[T], B0[T], acc[1][0], 0, 0, 0);         \
   acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[T], B1[T], acc[1][1], 0, 0, 0);
 
-template <int NKQ, int EPI, bool ZN, int MINW, int ABL = 0>
+template <int NKQ, int EPI, int MINW, int ABL = 0>
 __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
     const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, int64_t Mpad, int64_t Npad,
     int KQ, const float *__restrict__ rbias, const float *__restrict__ rscale,
@@ -293,17 +305,22 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
       rb[tm][q] = *reinterpret_cast<const f32x4 *>(rbias + wrow0 + tm * 32 + 8 * q + 4 * hh);
   float cb[2];
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? cbias[wcol0 + tn * 32 + i] : 0.f;
+  for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias[wcol0 + tn * 32 + i];
 
-  // accumulators start from the bias r_i + q_j (q_j alone when the z-norm map follows): the same
-  // initial value and k order as the 256 x 256 kernel, hence the same bits
+  // accumulators start from the bias fma(s_i, q_j, r'_i) (s_i = 1, r'_i = r_i without z-norm; with it
+  // the map (x - zmean_i) / zstd_i is folded into r', s and the A operand): the same initial value
+  // and k order as the 256 x 256 kernel, hence the same bits
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 rs = *reinterpret_cast<const f32x4 *>(rscale + wrow0 + a * 32 + 8 * q + 4 * hh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = (ZN && EPI == 0) ? cb[c] : rb[a][r >> 2][r & 3] + cb[c];
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[a][c][4 * q + e] = __builtin_fmaf(rs[e], cb[c], rb[a][q][e]);
+    }
 
   const int nst = (KQ + NKQ - 1) / NKQ;
   __syncthreads();
@@ -350,14 +367,6 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[tm][tn][r]));
   } else if (EPI == 0) {
-    f32x4 rs[2][4];
-    if (ZN) {
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          rs[tm][q] = *reinterpret_cast<const f32x4 *>(rscale + wrow0 + tm * 32 + 8 * q + 4 * hh);
-    }
     // wave-private 32 x 64 fp32 staging tile (8 KiB); rows of 256 B, conflict-free both ways
     float *tw = reinterpret_cast<float *>(smem) + wave * 2048;
     const int rrow = lane >> 4, rcol = (lane & 15) * 4;     // transposed read: 4 rows x 256 B
@@ -369,9 +378,7 @@ __global__ __launch_bounds__(256, MINW) void trials_gemm_kernel(
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[tm][tn][r];
-          if (ZN) v = v * rs[tm][r >> 2][r & 3] + rb[tm][r >> 2][r & 3];
-          tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + tn * 32 + i] = v;
+          tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64 + tn * 32 + i] = acc[tm][tn][r];
         }
       // (same wave wrote and reads: LDS operations of one wave execute in order)
 #pragma unroll
@@ -440,16 +447,19 @@ constexpr int BPR = 4, BPC = 8;   // patch of 256x256 tiles per XCD iteration (3
 //     area (2 KiB per wave, 8 x 64 outputs per round trip, software-pipelined write / read-back /
 //     store), so the DMA stream and the fragment prefetch of the next tile run through it, and
 //     there is no barrier at a tile boundary at all;
-//   * the accumulators start from the bias terms r_i + q_j (staged per tile by DMA) instead of
-//     zero, which costs the same 128 register writes and leaves the epilogue without arithmetic;
+//   * no vector-ALU work at the tile boundary: while its partner on the SIMD is MFMA-dense, a wave's
+//     VALU instructions get one issue slot per partner MFMA (~64 cycles each).  The accumulators
+//     start from the bias r'_i + s_i q_j, formed by one rank-2 MFMA per accumulator on k-pairs
+//     (r'_i, s_i) x (1, q_j) staged per tile by DMA; the z-norm map is folded into r', s and the A
+//     operand; the epilogue only moves data (LDS transpose, scalar-addressed 16-byte stores);
 //   * K is cut into balanced stages of 2..4 steps (25 steps at D = 200 -> 4,4,4,4,3,3,3).
-// LDS: 2 x 64 KiB stage buffers + 16 KiB staging + 3 x 3 KiB bias slots = 153 KiB.
+// LDS: 2 x 64 KiB stage buffers + 16 KiB staging + 3 x 4 KiB bias slots = 156 KiB.
 // Packed operands must be < 4 GiB each (32-bit soffset) and ld < 2^22 (32-bit store offsets inside a
 // tile); the host splits larger problems into column / row blocks.
 // ------------------------------------------------------------------------------------
 constexpr int BT2_STG = 2 * 65536;                 // byte offset of the epilogue staging area
-constexpr int BT2_BIAS = BT2_STG + 16384;          // 3 slots x 768 floats
-constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
+constexpr int BT2_BIAS = BT2_STG + 16384;          // 3 slots x (256 row pairs + 256 column pairs)
+constexpr int BT2_LDS = BT2_BIAS + 3 * 4096;       // 159744 B
 
 #define BT2_SB __builtin_amdgcn_sched_barrier(0)
 #define BT2_MFMA2(T, S, TM)                                                                         \
@@ -488,16 +498,14 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 768 * 4;    // 156672 B
   BT2_MFMA2(3, y, 0) BT2_MFMA2(3, y, 1) BT2_SB; if (last) dma_advance();                            \
   BT2_SB; BT2_MFMA2(3, y, 2) BT2_MFMA2(3, y, 3) BT2_SB;
 
-template <bool ZN, int MODE>
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     const f32x4 *__restrict__ Apk, const f32x4 *__restrict__ Bpk, unsigned Mpad, unsigned Npad, int KQ,
-    const float *__restrict__ rbias, const float *__restrict__ rscale, const float *__restrict__ cbias,
-    float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt, int tilesM, int tilesN, int patchesN,
+    const float2 *__restrict__ rpair, const float2 *__restrict__ cpair, float *__restrict__ out, int64_t ld, int64_t M, int64_t Nt, int tilesM, int tilesN, int patchesN,
     int numPatches, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
   constexpr bool TL = (MODE & 1) != 0;                            // timeline instrumentation (diagnostic)
-  constexpr bool EPI_PRIO = (MODE & 2) != 0;                      // tuning arm: s_setprio 3 around the epilogue
-  constexpr bool HALF_PRIO = (MODE & 4) != 0;                     // tuning arm: static s_setprio 1 for waves 4..7
+  constexpr bool EPI_PRIO = (MODE & 2) != 0;                      // s_setprio 3 from the epilogue through the next tile's accumulator setup
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   int d_st = 0, d_slot = 0;
   int d_r0 = (t_pm * BPR + lbm) * 256, d_c0 = (t_pn * BPC + lbn) * 256;
   int q_r0[3] = {d_r0, 0, 0}, q_c0[3] = {d_c0, 0, 0};
-  bool q_ok[3] = {true, false, false};
+  int q_ok[3] = {1, 0, 0};   // (ints, not bools: the tile hand-over then stays on the scalar unit)
   unsigned d_offA = ((unsigned)kqw * Mpad + (unsigned)d_r0 + quarter * 64u) * 16u;
   unsigned d_offB = ((unsigned)kqw * Npad + (unsigned)d_c0 + quarter * 64u) * 16u;
   unsigned d_lds = 0;                                             // byte offset of the buffer the DMA cursor fills
@@ -561,18 +569,16 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   // tile the pieces re-fetch the last position; nothing consumes them.
   auto dma_advance = [&]() {
     if (d_st == 0 && d_ok) {
-      // buffer (MUBUF) DMA, not global_load_lds: a pending FLAT-encoded LDS load makes the compiler's
-      // waitcnt pass turn every LDS wait of the epilogue into lgkmcnt(0)
-      float *dst = bias_lds + d_slot * 768;
-      if (wave == 0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rbias), 0, -1, 0x00020000),
-                                                 (LDS_AS void *)dst, 16, lane16, d_r0 * 4, 0, 0);
-      else if (wave == 1 && cbias)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cbias), 0, -1, 0x00020000),
-                                                 (LDS_AS void *)(dst + 256), 16, lane16, d_c0 * 4, 0, 0);
-      else if (wave == 2 && ZN)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rscale), 0, -1, 0x00020000),
-                                                 (LDS_AS void *)(dst + 512), 16, lane16, d_r0 * 4, 0, 0);
+      // the tile's bias pairs, 2 KiB per side, one piece each from waves 0..3.  Buffer (MUBUF) DMA, not
+      // global_load_lds: a pending FLAT-encoded LDS load makes the compiler's waitcnt pass turn every
+      // LDS wait of the epilogue into lgkmcnt(0)
+      float *dst = bias_lds + d_slot * 1024 + wave * 256;
+      if (wave < 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(rpair), 0, -1, 0x00020000),
+                                                 (LDS_AS void *)dst, 16, lane16, d_r0 * 8 + wave * 1024, 0, 0);
+      else if (wave < 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(cpair), 0, -1, 0x00020000),
+                                                 (LDS_AS void *)dst, 16, lane16, d_c0 * 8 + (wave - 2) * 1024, 0, 0);
     }
     const unsigned npd = (unsigned)(sbase + (d_st < srem ? 1 : 0));
     d_offA += npd * strideA2;
@@ -583,9 +589,9 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
       d_slot = d_slot == 2 ? 0 : d_slot + 1;
       if (d_ok) d_ok = tile_next();
       if (d_ok) { d_r0 = (t_pm * BPR + lbm) * 256; d_c0 = (t_pn * BPC + lbn) * 256; }
-      if (d_slot == 0) { q_r0[0] = d_r0; q_c0[0] = d_c0; q_ok[0] = d_ok; }
-      else if (d_slot == 1) { q_r0[1] = d_r0; q_c0[1] = d_c0; q_ok[1] = d_ok; }
-      else { q_r0[2] = d_r0; q_c0[2] = d_c0; q_ok[2] = d_ok; }
+      if (d_slot == 0) { q_r0[0] = d_r0; q_c0[0] = d_c0; q_ok[0] = d_ok ? 1 : 0; }
+      else if (d_slot == 1) { q_r0[1] = d_r0; q_c0[1] = d_c0; q_ok[1] = d_ok ? 1 : 0; }
+      else { q_r0[2] = d_r0; q_c0[2] = d_c0; q_ok[2] = d_ok ? 1 : 0; }
       d_offA = ((unsigned)kqw * Mpad + (unsigned)d_r0 + quarter * 64u) * 16u;
       d_offB = ((unsigned)kqw * Npad + (unsigned)d_c0 + quarter * 64u) * 16u;
     }
@@ -609,7 +615,6 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     }
   };
 
-  if (HALF_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
   auto step_stamp = [&](int sn) {
     if (TL) {
       const unsigned long long ts = __builtin_amdgcn_s_memtime();
@@ -635,26 +640,28 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   BT2_LOAD(x, Abase, Bbase)
 
   while (have) {
-    // accumulators start from the bias: r_i + q_j, or q_j alone when the z-norm map follows
-    // (out = rscale_i (acc) + rbias_i).  The tile's bias slot landed with its first stage.
-    const float *const bl = bias_lds + c_slot * 768;
+    // accumulators start from the bias r'_i + s_i q_j, formed by ONE rank-2 MFMA per accumulator on the
+    // tile's bias pairs (srcC = 0): no vector-ALU work at the tile boundary.  (A wave's VALU
+    // instructions get one issue slot per MFMA of its partner while that one is MFMA-dense: the 128
+    // register writes of a conventional setup took the trailing wave ~6500 cycles per tile.)
+    const float *const bl = bias_lds + c_slot * 1024;
     f32x16 acc[4][2];
     {
-      float cb[2];
+      float ap[4], bp[2];
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) cb[tn] = cbias ? bl[256 + wn * 64 + tn * 32 + i] : 0.f;
+      for (int tm = 0; tm < 4; ++tm) ap[tm] = bl[(wm * 128 + tm * 32 + i) * 2 + hh];
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) bp[tn] = bl[512 + (wn * 64 + tn * 32 + i) * 2 + hh];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 rb = {0.f, 0.f, 0.f, 0.f};
-          if (!ZN) rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[tm][tn][4 * q + e] = ZN ? cb[tn] : rb[e] + cb[tn];
-        }
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[tm], bp[tn], zero16, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (EPI_PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
 
     for (st = 0; st < nst; ++st) {
       const int np = sbase + (st < srem ? 1 : 0);
@@ -690,18 +697,10 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
       // row reads back, S(c) two 16-byte non-temporal stores (4 rows x 256 B per instruction)
       auto chunk_w = [&](int c) {
         const int tm = c >> 2, q = c & 3;
-        f32x4 rb, rs;
-        if (ZN) {
-          rb = *reinterpret_cast<const f32x4 *>(bl + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-          rs = *reinterpret_cast<const f32x4 *>(bl + 512 + wm * 128 + tm * 32 + 8 * q + 4 * hh);
-        }
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = acc[tm][tn][4 * q + e];
-            stg[(4 * hh + e) * 64 + tn * 32 + i] = ZN ? v * rs[e] + rb[e] : v;
-          }
+          for (int e = 0; e < 4; ++e) stg[(4 * hh + e) * 64 + tn * 32 + i] = acc[tm][tn][4 * q + e];
       };
       if (interior) {
         // stores address the tile through a scalar base that walks down the wave's 128 rows, 4 rows per
@@ -752,7 +751,6 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
         }
       }
     }
-    if (EPI_PRIO) { if (HALF_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     if (TL) {
       const unsigned long long t_e1 = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && lane == 0 && tseq < 8) {
@@ -764,7 +762,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     c_slot = c_slot == 2 ? 0 : c_slot + 1;
     r0 = c_slot == 0 ? q_r0[0] : (c_slot == 1 ? q_r0[1] : q_r0[2]);
     c0 = c_slot == 0 ? q_c0[0] : (c_slot == 1 ? q_c0[1] : q_c0[2]);
-    have = c_slot == 0 ? q_ok[0] : (c_slot == 1 ? q_ok[1] : q_ok[2]);
+    have = (c_slot == 0 ? q_ok[0] : (c_slot == 1 ? q_ok[1] : q_ok[2])) != 0;
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // no DMA may land in LDS after the workgroup has gone
 }
@@ -897,39 +895,50 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   PLDA_HIP(h, h->s_rbias.reserve((size_t)op.Mpad * 4));
   PLDA_HIP(h, h->s_rscale.reserve((size_t)op.Mpad * 4));
   PLDA_HIP(h, h->s_cbias.reserve((size_t)op.Npad * 4));
+  PLDA_HIP(h, h->s_rpair.reserve((size_t)op.Mpad * 8));
+  PLDA_HIP(h, h->s_cpair.reserve((size_t)op.Npad * 8));
   const double *psi = h->d_psi.as<double>();
   const bool zn = dzmean && dzstd;
   const int wpb = 4;
+  // row side: r'_i and s_i (the z-norm map (x - zmean_i) / zstd_i folded in: s_i = 1 / zstd_i scales the
+  // packed A operand and the column bias, r'_i = (r_i - zmean_i) s_i; s_i = 1 without statistics);
+  // column side: q_j (0 when enrol counts differ: the second half of the contraction carries it)
   if (op.mixed) {
     if (doA)
       enrol_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
-          dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
-          zn ? h->s_rscale.as<float>() : nullptr);
+          dU, dn, n_uniform, psi, D, M, dzmean, dzstd, h->s_rbias.as<float>(), h->s_rscale.as<float>());
+    if (doB) PLDA_HIP(h, hipMemsetAsync(h->s_cbias.p, 0, (size_t)op.Npad * 4, h->stream));
   } else {
     PLDA_HIP(h, h->w[11].reserve((size_t)(2 * D + 1) * 8));
     double *coef = h->w[11].as<double>();
     uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
     if (doA)
       weighted_sq_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
-          dU, coef, 1.0, coef + 2 * D, D, M, dzmean, dzstd, h->s_rbias.as<float>(),
-          zn ? h->s_rscale.as<float>() : nullptr);
+          dU, coef, 1.0, coef + 2 * D, D, M, dzmean, dzstd, h->s_rbias.as<float>(), h->s_rscale.as<float>());
     if (doB)
       weighted_sq_bias_kernel<<<(unsigned)ceil_div(Nt, wpb), wpb * 64, 0, h->stream>>>(
           dV, coef + D, 0.0, coef + 2 * D, D, Nt, nullptr, nullptr, h->s_cbias.as<float>(), nullptr);
   }
+  {
+    const int64_t ma = doA ? M : 0, nb = doB ? Nt : 0;
+    bias_pairs_kernel<<<(unsigned)ceil_div(std::max(ma, nb), 256), 256, 0, h->stream>>>(
+        h->s_rbias.as<float>(), h->s_rscale.as<float>(), ma, h->s_cbias.as<float>(), nb,
+        h->s_rpair.as<float2>(), h->s_cpair.as<float2>());
+  }
   PLDA_LAUNCH_CHECK(h);
+  const float *rs = zn ? h->s_rscale.as<float>() : nullptr;      // folded into the packed A operand
   const dim3 ga((unsigned)(op.Mpad / 64), (unsigned)ceil_div(op.Kg, 32));
   const dim3 gb((unsigned)(op.Npad / 64), (unsigned)ceil_div(op.Kg, 32));
   if (op.mixed) {
     if (doA)
-      pack_kernel<1><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
+      pack_kernel<1><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, rs, D, Dp, M, op.Mpad,
                                                 op.KQ, h->s_Apk.as<float>());
     if (doB)
       pack_kernel<3><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
                                                 op.KQ, h->s_Bpk.as<float>());
   } else {
     if (doA)
-      pack_kernel<0><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, nullptr, D, Dp, M, op.Mpad,
+      pack_kernel<0><<<ga, 256, 0, h->stream>>>(dU, dn, n_uniform, psi, rs, D, Dp, M, op.Mpad,
                                                 op.KQ, h->s_Apk.as<float>());
     if (doB)
       pack_kernel<2><<<gb, 256, 0, h->stream>>>(dV, nullptr, 0, psi, nullptr, D, Dp, Nt, op.Npad,
@@ -939,9 +948,8 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   return PLDA_OK;
 }
 
-template <int EPI, bool ZN>
-static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64_t Nt, bool use_rscale,
-                       float *dout, int64_t ld, const float *shift, double *colsum, double *colsq) {
+template <int EPI>
+static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64_t Nt, float *dout, int64_t ld, const float *shift, double *colsum, double *colsq) {
   // M may be a row prefix of the packed operand (z-norm pilot): only its tiles are launched
   const int tilesM = (int)ceil_div(M, 128), tilesN = (int)(op.Npad / 128);
   const int patchesM = (int)ceil_div(tilesM, PATCH_M), patchesN = (int)ceil_div(tilesN, PATCH_N);
@@ -972,42 +980,26 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   if (use_bt2) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<true, 0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<false, 6>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
+      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>)};
+      for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
-#define BT2L(ZN_, MODE_, DBG_)                                                                            \
-  trials_gemm_bt2_kernel<ZN_, MODE_><<<256, 512, BT2_LDS, h->stream>>>(                                   \
+#define BT2L(MODE_, DBG_)                                                                                 \
+  trials_gemm_bt2_kernel<MODE_><<<256, 512, BT2_LDS, h->stream>>>(                                        \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
-      h->s_rbias.as<float>(), use_rscale ? h->s_rscale.as<float>() : nullptr,                             \
-      op.mixed ? nullptr : h->s_cbias.as<float>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
-    if ((h->gemm_variant == 31 || h->gemm_variant == 35) && !ZN) {
+      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
+    if (h->gemm_variant == 31 || h->gemm_variant == 35) {
       // diagnostic: per-wave timestamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
-      if (h->gemm_variant == 31) BT2L(false, 1, h->timeline.as<unsigned long long>());
-      else BT2L(false, 3, h->timeline.as<unsigned long long>());
+      if (h->gemm_variant == 31) BT2L(1, h->timeline.as<unsigned long long>());
+      else BT2L(3, h->timeline.as<unsigned long long>());
       h->timeline_valid = true;
-    } else if (h->gemm_variant == 32 && !ZN) {
-      BT2L(false, 2, nullptr);     // tuning arms (scripts/gemm_sweep.py)
-    } else if (h->gemm_variant == 33 && !ZN) {
-      BT2L(false, 4, nullptr);
-    } else if (h->gemm_variant == 34 && !ZN) {
-      BT2L(false, 6, nullptr);
+    } else if (h->gemm_variant == 32) {
+      BT2L(2, nullptr);     // tuning arm (scripts/gemm_sweep.py)
     } else {
-      BT2L(ZN, 0, nullptr);
+      BT2L(0, nullptr);
     }
 #undef BT2L
     PLDA_LAUNCH_CHECK(h);
@@ -1018,9 +1010,9 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   // tuning / ablation arms of scripts/gemm_sweep.py (PLDA_GEMM_VARIANT), kept because the
   // numbers in DESIGN.md section 3 come from them.
 #define TG(NKQ_, EPI_, MINW_, ABL_)                                                                     \
-  trials_gemm_kernel<NKQ_, EPI_, ZN, MINW_, ABL_><<<(unsigned)grid, 256, 0, h->stream>>>(               \
+  trials_gemm_kernel<NKQ_, EPI_, MINW_, ABL_><<<(unsigned)grid, 256, 0, h->stream>>>(                   \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),      \
-      use_rscale ? h->s_rscale.as<float>() : nullptr, op.mixed ? nullptr : h->s_cbias.as<float>(), dout, \
+      h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout,                                           \
       ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq)
   constexpr int EPI_NOSTORE = (EPI == 0) ? 2 : EPI;
   switch (h->gemm_variant) {
@@ -1065,8 +1057,7 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
                                 zn ? dzmean + r0 : nullptr, zn ? dzstd + r0 : nullptr, op,
                                 /*doA=*/cbk == 0, /*doB=*/ncb > 1 || rb == 0));
       float *o = dout + r0 * ld + c0;
-      if (zn) PLDA_TRY(launch_gemm<0, true>(h, op, m, nt, true, o, ld, nullptr, nullptr, nullptr));
-      else PLDA_TRY(launch_gemm<0, false>(h, op, m, nt, false, o, ld, nullptr, nullptr, nullptr));
+      PLDA_TRY(launch_gemm<0>(h, op, m, nt, o, ld, nullptr, nullptr, nullptr));
     }
   }
   return PLDA_OK;
@@ -1105,10 +1096,10 @@ int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_e
   // pilot: mean over the first rows -> shift (keeps the single-pass variance well conditioned)
   const int64_t Np = Nb < 128 ? Nb : 128;
   PLDA_HIP(h, hipMemsetAsync(colsum, 0, (size_t)op.Npad * 20, h->stream));
-  PLDA_TRY(launch_gemm<1, false>(h, op, Np, M, false, nullptr, 0, shift, colsum, colsq));
+  PLDA_TRY(launch_gemm<1>(h, op, Np, M, nullptr, 0, shift, colsum, colsq));
   pilot_shift_kernel<<<(unsigned)ceil_div(M, 256), 256, 0, h->stream>>>(colsum, M, 1.0 / (double)Np, shift);
   PLDA_HIP(h, hipMemsetAsync(colsum, 0, (size_t)op.Npad * 16, h->stream));
-  PLDA_TRY(launch_gemm<1, false>(h, op, Nb, M, false, nullptr, 0, shift, colsum, colsq));
+  PLDA_TRY(launch_gemm<1>(h, op, Nb, M, nullptr, 0, shift, colsum, colsq));
   znorm_finalize_kernel<<<(unsigned)ceil_div(M, 256), 256, 0, h->stream>>>(shift, colsum, colsq, M,
                                                                            1.0 / (double)Nb, dmean, dstd);
   PLDA_LAUNCH_CHECK(h);
