@@ -437,7 +437,7 @@ constexpr int BPR = 4, BPC = 8;   // patch of 256x256 tiles per XCD iteration (3
 // their first fragment reads, with the matrix pipe idle):
 //   * DMA addressing is two scalar adds per 1 KiB piece: per-wave byte offsets into a buffer
 //     descriptor (soffset) and into LDS (M0) live in SGPRs and advance per stage;
-//   * the stage barrier sits EARLY, in front of the LAST 16-k step of a stage, when that step's
+//   * the stage barrier sits EARLY, in front of the LAST 8-k step of a stage, when that step's
 //     fragments are already in registers.  Behind it every wave knows (a) stage g+1 has landed
 //     (each wave drained its own DMAs first) and (b) nobody reads stage g's buffer any more -- so
 //     the step's 32 MFMAs issue at once, the fragments of stage g+1's first step are fetched under
@@ -452,7 +452,7 @@ constexpr int BPR = 4, BPC = 8;   // patch of 256x256 tiles per XCD iteration (3
 //     start from the bias r'_i + s_i q_j, formed by one rank-2 MFMA per accumulator on k-pairs
 //     (r'_i, s_i) x (1, q_j) staged per tile by DMA; the z-norm map is folded into r', s and the A
 //     operand; the epilogue only moves data (LDS transpose, scalar-addressed 16-byte stores);
-//   * K is cut into balanced stages of 2..4 steps (25 steps at D = 200 -> 4,4,4,4,3,3,3).
+//   * K is cut into balanced stages of 2..4 steps of 8 k (25 steps at D = 200 -> 4,4,4,4,3,3,3).
 // LDS: 2 x 64 KiB stage buffers + 16 KiB staging + 3 x 4 KiB bias slots = 156 KiB.
 // Packed operands must be < 4 GiB each (32-bit soffset) and ld < 2^22 (32-bit store offsets inside a
 // tile); the host splits larger problems into column / row blocks.
@@ -505,14 +505,13 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     int numPatches, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
   constexpr bool TL = (MODE & 1) != 0;                            // timeline instrumentation (diagnostic)
-  constexpr bool EPI_PRIO = (MODE & 2) != 0;                      // s_setprio 3 from the epilogue through the next tile's accumulator setup
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
   const int i = lane & 31, hh = lane >> 5;
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
   const int lbm = lb / BPC, lbn = lb % BPC;                       // this workgroup's tile inside a patch
-  const int nsteps = KQ >> 1;                                     // 16-k steps per tile (>= 2: the host pads K to 32)
+  const int nsteps = KQ >> 1;                                     // 8-k steps per tile (>= 2: the host pads K to 16)
   const int nst = (nsteps + 3) >> 2;                              // stages per tile
   const int sbase = nsteps / nst, srem = nsteps - sbase * nst;    // stage j has sbase + (j < srem) steps
   const int lane16 = lane * 16;
@@ -659,9 +658,6 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
         for (int tn = 0; tn < 2; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[tm], bp[tn], zero16, 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (EPI_PRIO) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
 
     for (st = 0; st < nst; ++st) {
       const int np = sbase + (st < srem ? 1 : 0);
@@ -687,7 +683,6 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     // ---- epilogue: 16 round trips of 8 rows x 64 columns through this wave's 2 KiB of staging ----
     unsigned long long t_e0 = 0;
     if (TL) t_e0 = __builtin_amdgcn_s_memtime();
-    if (EPI_PRIO) __builtin_amdgcn_s_setprio(3);
     {
       float *stg = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + BT2_STG) + wave * 512;
       const int rrow = lane >> 4, rcol = (lane & 15) * 4;
@@ -884,7 +879,7 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   const int D = h->Dout;
   const int Dp = (int)round_up(D, 8);
   op.mixed = dn != nullptr;
-  op.Kg = std::max(op.mixed ? 2 * Dp : Dp, 32);   // >= two 16-k steps: the 256 x 256 kernel pairs them (zero planes cost nothing that matters at D <= 24)
+  op.Kg = std::max(op.mixed ? 2 * Dp : Dp, 16);   // >= two 8-k steps: the 256 x 256 kernel runs them in pairs
   op.Kg_alg = op.mixed ? 2 * D : D;
   op.KQ = op.Kg / 4;
   op.Mpad = round_up(M, 256);   // 256: the big-tile kernel's block tile (the 128 kernel tolerates it)
@@ -970,18 +965,17 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
   }
   // persistent 256 x 256 kernel: when there are enough tiles to keep 256 CUs busy (PLDA_GEMM_VARIANT=20
-  // forces the 128 x 128 kernel, 30 the 256 x 256 one; 31..35 are its diagnostic / tuning arms)
+  // forces the 128 x 128 kernel, 30 the 256 x 256 one, 31 its timeline-instrumented instantiation)
   const int btM = (int)ceil_div(M, 256), btN = (int)(op.Npad / 256);
   const bool big = EPI == 0 && (int64_t)btM * btN >= 1024;
   // it needs 32-bit byte offsets into each packed operand and into a tile's output rows
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
-                       ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || (h->gemm_variant == 0 && big));
+                       (h->gemm_variant == 30 || h->gemm_variant == 31 || (h->gemm_variant == 0 && big));
   if (use_bt2) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
-      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
-                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>)};
+      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>)};
       for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
@@ -989,15 +983,12 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   trials_gemm_bt2_kernel<MODE_><<<256, 512, BT2_LDS, h->stream>>>(                                        \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
       h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
-    if (h->gemm_variant == 31 || h->gemm_variant == 35) {
+    if (h->gemm_variant == 31) {
       // diagnostic: per-wave timestamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
-      if (h->gemm_variant == 31) BT2L(1, h->timeline.as<unsigned long long>());
-      else BT2L(3, h->timeline.as<unsigned long long>());
+      BT2L(1, h->timeline.as<unsigned long long>());
       h->timeline_valid = true;
-    } else if (h->gemm_variant == 32) {
-      BT2L(2, nullptr);     // tuning arm (scripts/gemm_sweep.py)
     } else {
       BT2L(0, nullptr);
     }
@@ -1043,7 +1034,7 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
   // (KQ + 8 planes of 16 B per row) would reach 4 GiB is scored in row / column blocks, each side
   // packed once per block of its own dimension.  (C3's 1 M x 512 test side is 2.2 GB: one block.)
   const int D = h->Dout;
-  const int64_t kq8 = std::max<int64_t>((dn ? 2 : 1) * round_up(D, 8), 32) / 4 + 8;
+  const int64_t kq8 = std::max<int64_t>((dn ? 2 : 1) * round_up(D, 8), 16) / 4 + 8;
   const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;      // rows of one block
   const int64_t nrb = ceil_div(M, cap), ncb = ceil_div(Nt, cap);
   const bool zn = dzmean && dzstd;
