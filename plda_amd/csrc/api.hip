@@ -9,7 +9,9 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
+#include <stdexcept>
 
 namespace plda {
 
@@ -96,193 +98,252 @@ using namespace plda;
 // one handle = one GPU + one stream: calls on the same handle from several threads are serialised
 #define PLDA_LOCK(h) std::lock_guard<std::recursive_mutex> plda_lock_guard_((h)->mu)
 
+// Nothing throws across the ABI: every entry point runs its body inside `guarded`, which turns a C++
+// exception (std::bad_alloc / std::length_error from a host-side container, std::system_error from the
+// mutex) into a status code + plda_last_error text.  (The reference lets Kaldi assertions abort the
+// interpreter: pldamodule.cpp has no try/catch.)
+namespace {
+int fail_quiet(plda_handle *h, int code, const char *fn, const char *what) noexcept {
+  try { return fail(h, code, "%s: %s", fn, what); } catch (...) { return code; }
+}
+template <typename F> int guarded(plda_handle *h, const char *fn, F &&body) noexcept {
+  try { return body(); }
+  catch (const std::bad_alloc &) { return fail_quiet(h, PLDA_E_HIP, fn, "out of host memory"); }
+  catch (const std::exception &e) { return fail_quiet(h, PLDA_E_HIP, fn, e.what()); }
+  catch (...) { return fail_quiet(h, PLDA_E_HIP, fn, "unknown C++ exception"); }
+}
+}  // namespace
+
 extern "C" {
 
 int plda_abi_version(void) { return 1; }
 
 int plda_create(int device, plda_handle **out) {
-  if (!out) return fail(nullptr, PLDA_E_INVAL, "plda_create: out is NULL");
-  *out = nullptr;
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0)
-    return fail(nullptr, PLDA_E_HIP, "plda_create: no HIP device available (%s); this engine has no CPU fallback",
-                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-  if (device < 0 || device >= count) return fail(nullptr, PLDA_E_INVAL, "plda_create: device %d out of range [0,%d)", device, count);
-  hipDeviceProp_t prop;
-  e = hipGetDeviceProperties(&prop, device);
-  if (e != hipSuccess) return fail(nullptr, PLDA_E_HIP, "plda_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(nullptr, PLDA_E_HIP, "plda_create: device %d is %s; libplda_hip is built for gfx950 only", device, prop.gcnArchName);
-  plda_handle *h = new (std::nothrow) plda_handle();
-  if (!h) return fail(nullptr, PLDA_E_HIP, "plda_create: out of host memory");
-  h->device = device;
-  e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
-  h->stream = h->own_stream;
-  if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
-  if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
-  if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
-  if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
-  *out = h;
-  return PLDA_OK;
+  return guarded(nullptr, "plda_create", [&]() -> int {
+    if (!out) return fail(nullptr, PLDA_E_INVAL, "plda_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+      return fail(nullptr, PLDA_E_HIP, "plda_create: no HIP device available (%s); this engine has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= count) return fail(nullptr, PLDA_E_INVAL, "plda_create: device %d out of range [0,%d)", device, count);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, PLDA_E_HIP, "plda_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(nullptr, PLDA_E_HIP, "plda_create: device %d is %s; libplda_hip is built for gfx950 only", device, prop.gcnArchName);
+    plda_handle *h = new (std::nothrow) plda_handle();
+    if (!h) return fail(nullptr, PLDA_E_HIP, "plda_create: out of host memory");
+    h->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
+    *out = h;
+    return PLDA_OK;
+  });
 }
 
 int plda_destroy(plda_handle *h) {
-  if (!h) return PLDA_OK;
-  (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
-  DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
-                    &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
-                    &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
-                    &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline};
-  for (DevBuf *b : bufs) b->release();
-  for (auto &b : h->w) b.release();
-  if (h->one_host) (void)hipHostFree(h->one_host);
-  if (h->jac_exec) (void)hipGraphExecDestroy(h->jac_exec);
-  for (auto &ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-  delete h;
-  return PLDA_OK;
+  return guarded(h, "plda_destroy", [&]() -> int {
+    if (!h) return PLDA_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
+                      &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
+                      &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
+                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &b : h->w) b.release();
+    if (h->one_host) (void)hipHostFree(h->one_host);
+    if (h->jac_exec) (void)hipGraphExecDestroy(h->jac_exec);
+    for (auto &ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return PLDA_OK;
+  });
 }
 
-const char *plda_last_error(const plda_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+const char *plda_last_error(const plda_handle *h) {
+  // a per-thread copy taken under the handle's lock: another thread failing at the same moment
+  // reassigns h->err, so the handle's own buffer must not be handed out
+  static thread_local std::string tl_err;
+  try {
+    if (!h) return g_create_err.c_str();
+    plda_handle *hm = const_cast<plda_handle *>(h);
+    std::lock_guard<std::recursive_mutex> g(hm->mu);
+    tl_err = h->err;
+    return tl_err.c_str();
+  } catch (...) { return "plda_last_error: out of host memory"; }
+}
 
 int plda_set_stream(plda_handle *h, void *hip_stream) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
-  return PLDA_OK;
+  return guarded(h, "plda_set_stream", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return PLDA_OK;
+  });
 }
 
 int plda_reset_stream(plda_handle *h) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  h->stream = h->own_stream;
-  return PLDA_OK;
+  return guarded(h, "plda_reset_stream", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    h->stream = h->own_stream;
+    return PLDA_OK;
+  });
 }
 
 int plda_synchronize(plda_handle *h) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_synchronize", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- fit
 int plda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
                  int32_t iters) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return fit_device(h, dX, N, D, dlabels, K, iters);
+  return guarded(h, "plda_fit_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return fit_device(h, dX, N, D, dlabels, K, iters);
+  });
 }
 
 int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels, int32_t iters) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
-  PLDA_TRY(set_device(h));
-  uint64_t mx = 0;
-  for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
-  if (mx >= (uint64_t)N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
-  const int64_t K = (int64_t)mx + 1;
-  Tmp dX, dL;
-  PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
-  PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
-  return fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), K, iters);
+  return guarded(h, "plda_fit", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
+    PLDA_TRY(set_device(h));
+    uint64_t mx = 0;
+    for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
+    if (mx >= (uint64_t)N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+    const int64_t K = (int64_t)mx + 1;
+    Tmp dX, dL;
+    PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
+    PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
+    return fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), K, iters);
+  });
 }
 
 int plda_fit_stats_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return fit_stats_device(h, dX, N, D, dlabels, K);
+  return guarded(h, "plda_fit_stats_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return fit_stats_device(h, dX, N, D, dlabels, K);
+  });
 }
 
 int plda_fit_get_stats_dev(plda_handle *h, double *dmeans, int64_t *dcounts, double *dscatter) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats_dev: no statistics pass has run on this handle");
-  PLDA_TRY(set_device(h));
-  const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
-  if (dmeans) PLDA_HIP(h, hipMemcpyAsync(dmeans, h->f_means.p, K * D * 8, hipMemcpyDeviceToDevice, h->stream));
-  if (dcounts) PLDA_HIP(h, hipMemcpyAsync(dcounts, h->f_counts.p, K * 8, hipMemcpyDeviceToDevice, h->stream));
-  if (dscatter) PLDA_HIP(h, hipMemcpyAsync(dscatter, h->f_scatter.p, D * D * 8, hipMemcpyDeviceToDevice, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_fit_get_stats_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats_dev: no statistics pass has run on this handle");
+    PLDA_TRY(set_device(h));
+    const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
+    if (dmeans) PLDA_HIP(h, hipMemcpyAsync(dmeans, h->f_means.p, K * D * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (dcounts) PLDA_HIP(h, hipMemcpyAsync(dcounts, h->f_counts.p, K * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (dscatter) PLDA_HIP(h, hipMemcpyAsync(dscatter, h->f_scatter.p, D * D * 8, hipMemcpyDeviceToDevice, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts, int64_t K, const double *dscatter,
                     int32_t D, int32_t iters) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!dmeans || !dcounts || !dscatter || K <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit_em: bad argument");
-  if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
-  PLDA_TRY(set_device(h));
-  PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
-  PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
-  PLDA_HIP(h, h->f_scatter.reserve((size_t)D * D * 8));
-  if (dmeans != h->f_means.p)
-    PLDA_HIP(h, hipMemcpyAsync(h->f_means.p, dmeans, (size_t)K * D * 8, hipMemcpyDeviceToDevice, h->stream));
-  if ((const void *)dcounts != h->f_counts.p)
-    PLDA_HIP(h, hipMemcpyAsync(h->f_counts.p, dcounts, (size_t)K * 8, hipMemcpyDeviceToDevice, h->stream));
-  if (dscatter != h->f_scatter.p)
-    PLDA_HIP(h, hipMemcpyAsync(h->f_scatter.p, dscatter, (size_t)D * D * 8, hipMemcpyDeviceToDevice, h->stream));
-  h->fit_ms[0] = 0.0;
-  return fit_em_device(h, K, D, iters);
+  return guarded(h, "plda_fit_em_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!dmeans || !dcounts || !dscatter || K <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit_em: bad argument");
+    if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
+    PLDA_TRY(set_device(h));
+    PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
+    PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
+    PLDA_HIP(h, h->f_scatter.reserve((size_t)D * D * 8));
+    if (dmeans != h->f_means.p)
+      PLDA_HIP(h, hipMemcpyAsync(h->f_means.p, dmeans, (size_t)K * D * 8, hipMemcpyDeviceToDevice, h->stream));
+    if ((const void *)dcounts != h->f_counts.p)
+      PLDA_HIP(h, hipMemcpyAsync(h->f_counts.p, dcounts, (size_t)K * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (dscatter != h->f_scatter.p)
+      PLDA_HIP(h, hipMemcpyAsync(h->f_scatter.p, dscatter, (size_t)D * D * 8, hipMemcpyDeviceToDevice, h->stream));
+    h->fit_ms[0] = 0.0;
+    return fit_em_device(h, K, D, iters);
+  });
 }
 
 int plda_fit_timings(plda_handle *h, double out_ms[4]) {
-  if (!h || !out_ms) return PLDA_E_INVAL;
-  for (int i = 0; i < 4; ++i) out_ms[i] = h->fit_ms[i];
-  return PLDA_OK;
+  return guarded(h, "plda_fit_timings", [&]() -> int {
+    if (!h || !out_ms) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    for (int i = 0; i < 4; ++i) out_ms[i] = h->fit_ms[i];
+    return PLDA_OK;
+  });
 }
 
 int plda_fit_num_classes(plda_handle *h, int64_t *K) {
-  if (!h || !K) return PLDA_E_INVAL;
-  *K = h->fit_K;
-  return PLDA_OK;
+  return guarded(h, "plda_fit_num_classes", [&]() -> int {
+    if (!h || !K) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    *K = h->fit_K;
+    return PLDA_OK;
+  });
 }
 
 int plda_fit_get_stats(plda_handle *h, double *means, int64_t *counts, double *scatter, double *sum,
                        double *W, double *B) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats: no fit has run on this handle");
-  PLDA_TRY(set_device(h));
-  const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
-  if (means) PLDA_HIP(h, hipMemcpyAsync(means, h->f_means.p, K * D * 8, hipMemcpyDeviceToHost, h->stream));
-  if (counts) PLDA_HIP(h, hipMemcpyAsync(counts, h->f_counts.p, K * 8, hipMemcpyDeviceToHost, h->stream));
-  if (scatter) PLDA_HIP(h, hipMemcpyAsync(scatter, h->f_scatter.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
-  if (sum) PLDA_HIP(h, hipMemcpyAsync(sum, h->f_sum.p, D * 8, hipMemcpyDeviceToHost, h->stream));
-  if (W) PLDA_HIP(h, hipMemcpyAsync(W, h->f_W.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
-  if (B) PLDA_HIP(h, hipMemcpyAsync(B, h->f_B.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_fit_get_stats", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (h->fit_K <= 0) return fail(h, PLDA_E_NOT_FITTED, "fit_get_stats: no fit has run on this handle");
+    PLDA_TRY(set_device(h));
+    const size_t K = (size_t)h->fit_K, D = (size_t)h->fit_D;
+    if (means) PLDA_HIP(h, hipMemcpyAsync(means, h->f_means.p, K * D * 8, hipMemcpyDeviceToHost, h->stream));
+    if (counts) PLDA_HIP(h, hipMemcpyAsync(counts, h->f_counts.p, K * 8, hipMemcpyDeviceToHost, h->stream));
+    if (scatter) PLDA_HIP(h, hipMemcpyAsync(scatter, h->f_scatter.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
+    if (sum) PLDA_HIP(h, hipMemcpyAsync(sum, h->f_sum.p, D * 8, hipMemcpyDeviceToHost, h->stream));
+    if (W) PLDA_HIP(h, hipMemcpyAsync(W, h->f_W.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
+    if (B) PLDA_HIP(h, hipMemcpyAsync(B, h->f_B.p, D * D * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- model
 int plda_get_dims(plda_handle *h, int32_t *Dout, int32_t *Din) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
-  if (Dout) *Dout = h->Dout;
-  if (Din) *Din = h->Din;
-  return PLDA_OK;
+  return guarded(h, "plda_get_dims", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+    if (Dout) *Dout = h->Dout;
+    if (Din) *Din = h->Din;
+    return PLDA_OK;
+  });
 }
 
 int plda_get_model(plda_handle *h, double *mean, double *transform, double *psi, double *offset) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
-  if (mean) std::memcpy(mean, h->h_mean.data(), h->h_mean.size() * 8);
-  if (transform) std::memcpy(transform, h->h_transform.data(), h->h_transform.size() * 8);
-  if (psi) std::memcpy(psi, h->h_psi.data(), h->h_psi.size() * 8);
-  if (offset) std::memcpy(offset, h->h_offset.data(), h->h_offset.size() * 8);
-  return PLDA_OK;
+  return guarded(h, "plda_get_model", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+    if (mean) std::memcpy(mean, h->h_mean.data(), h->h_mean.size() * 8);
+    if (transform) std::memcpy(transform, h->h_transform.data(), h->h_transform.size() * 8);
+    if (psi) std::memcpy(psi, h->h_psi.data(), h->h_psi.size() * 8);
+    if (offset) std::memcpy(offset, h->h_offset.data(), h->h_offset.size() * 8);
+    return PLDA_OK;
+  });
 }
 
 static int refresh_offset(plda_handle *h) {
@@ -296,535 +357,597 @@ static int refresh_offset(plda_handle *h) {
 
 int plda_set_model(plda_handle *h, int32_t Dout, int32_t Din, const double *mean, const double *transform,
                    const double *psi) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (Dout <= 0 || Din <= 0 || Dout > Din || !mean || !transform || !psi)
-    return fail(h, PLDA_E_INVAL, "set_model: bad argument");
-  PLDA_TRY(set_device(h));
-  h->Dout = Dout; h->Din = Din;
-  h->h_mean.assign(mean, mean + Din);
-  h->h_transform.assign(transform, transform + (size_t)Dout * Din);
-  h->h_psi.assign(psi, psi + Dout);
-  h->h_offset.assign(Dout, 0.0);
-  PLDA_TRY(model_to_device(h));
-  h->fitted = true;
-  return refresh_offset(h);
+  return guarded(h, "plda_set_model", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (Dout <= 0 || Din <= 0 || Dout > Din || !mean || !transform || !psi)
+      return fail(h, PLDA_E_INVAL, "set_model: bad argument");
+    PLDA_TRY(set_device(h));
+    h->Dout = Dout; h->Din = Din;
+    h->h_mean.assign(mean, mean + Din);
+    h->h_transform.assign(transform, transform + (size_t)Dout * Din);
+    h->h_psi.assign(psi, psi + Dout);
+    h->h_offset.assign(Dout, 0.0);
+    PLDA_TRY(model_to_device(h));
+    h->fitted = true;
+    return refresh_offset(h);
+  });
 }
 
 int plda_truncate(plda_handle *h, int32_t targetdim) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
-  if (targetdim <= 0 || targetdim > h->Dout) return fail(h, PLDA_E_INVAL, "truncate: targetdim %d not in [1,%d]", targetdim, h->Dout);
-  PLDA_TRY(set_device(h));
-  h->Dout = targetdim;
-  h->h_transform.resize((size_t)targetdim * h->Din);
-  h->h_psi.resize(targetdim);
-  h->h_offset.resize(targetdim);
-  return PLDA_OK;  // device arrays are row-major prefixes: nothing to move
+  return guarded(h, "plda_truncate", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+    if (targetdim <= 0 || targetdim > h->Dout) return fail(h, PLDA_E_INVAL, "truncate: targetdim %d not in [1,%d]", targetdim, h->Dout);
+    PLDA_TRY(set_device(h));
+    h->Dout = targetdim;
+    h->h_transform.resize((size_t)targetdim * h->Din);
+    h->h_psi.resize(targetdim);
+    h->h_offset.resize(targetdim);
+    return PLDA_OK;  // device arrays are row-major prefixes: nothing to move
+  });
 }
 
 int plda_smooth(plda_handle *h, double factor) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
-  if (!(factor >= 0.0 && factor <= 1.0)) return fail(h, PLDA_E_INVAL, "smooth: factor must be in [0,1]");
-  PLDA_TRY(set_device(h));
-  smooth_kernel<<<h->Dout, 256, 0, h->stream>>>(h->d_transform.as<double>(), h->d_psi.as<double>(), h->Dout, h->Din, factor);
-  PLDA_LAUNCH_CHECK(h);
-  PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, (size_t)h->Dout * h->Din * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
-  return refresh_offset(h);
+  return guarded(h, "plda_smooth", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "model not fitted");
+    if (!(factor >= 0.0 && factor <= 1.0)) return fail(h, PLDA_E_INVAL, "smooth: factor must be in [0,1]");
+    PLDA_TRY(set_device(h));
+    smooth_kernel<<<h->Dout, 256, 0, h->stream>>>(h->d_transform.as<double>(), h->d_psi.as<double>(), h->Dout, h->Din, factor);
+    PLDA_LAUNCH_CHECK(h);
+    PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, (size_t)h->Dout * h->Din * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+    return refresh_offset(h);
+  });
 }
 
 // ---------------------------------------------------------------- transform
 int plda_transform_rows_dev(plda_handle *h, const double *dXbar, int64_t R, int32_t Din, const int32_t *dn,
                             int32_t n_uniform, double *dout) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
-  PLDA_TRY(set_device(h));
-  return transform_rows_device(h, dXbar, R, Din, dn, n_uniform, dout);
+  return guarded(h, "plda_transform_rows_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
+    PLDA_TRY(set_device(h));
+    return transform_rows_device(h, dXbar, R, Din, dn, n_uniform, dout);
+  });
 }
 
 int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t Din, const int32_t *num_examples,
                         int32_t n_uniform, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
-  if (R <= 0) return PLDA_OK;
-  if (!Xbar || !out) return fail(h, PLDA_E_INVAL, "transform_rows: bad argument");
-  if (!num_examples && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
-  PLDA_TRY(set_device(h));
-  Tmp dX, dN, dO;
-  PLDA_TRY(upload(h, dX, Xbar, (size_t)R * Din * 8));
-  if (num_examples) PLDA_TRY(upload(h, dN, num_examples, (size_t)R * 4));
-  PLDA_HIP(h, dO.alloc((size_t)R * h->Dout * 8));
-  PLDA_TRY(transform_rows_device(h, dX.as<double>(), R, Din, num_examples ? dN.as<int32_t>() : nullptr, n_uniform, dO.as<double>()));
-  PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)R * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_transform_rows", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
+    if (R <= 0) return PLDA_OK;
+    if (!Xbar || !out) return fail(h, PLDA_E_INVAL, "transform_rows: bad argument");
+    if (!num_examples && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "transform_rows: need num_examples or n_uniform > 0");
+    PLDA_TRY(set_device(h));
+    Tmp dX, dN, dO;
+    PLDA_TRY(upload(h, dX, Xbar, (size_t)R * Din * 8));
+    if (num_examples) PLDA_TRY(upload(h, dN, num_examples, (size_t)R * 4));
+    PLDA_HIP(h, dO.alloc((size_t)R * h->Dout * 8));
+    PLDA_TRY(transform_rows_device(h, dX.as<double>(), R, Din, num_examples ? dN.as<int32_t>() : nullptr, n_uniform, dO.as<double>()));
+    PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)R * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Din, const uint64_t *labels,
                           uint64_t *out_labels, int64_t *out_counts, double *out_vecs, int64_t *Ku) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
-  if (!Ku) return fail(h, PLDA_E_INVAL, "transform_groups: Ku is NULL");
-  if (N <= 0) { *Ku = 0; return PLDA_OK; }
-  if (!X || !labels || !out_labels || !out_counts || !out_vecs) return fail(h, PLDA_E_INVAL, "transform_groups: bad argument");
-  if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
-  PLDA_TRY(set_device(h));
-  // label compaction (index bookkeeping; the reference does it with std::map, pldamodule.cpp:118,147-156)
-  std::vector<uint64_t> uniq(labels, labels + N);
-  std::sort(uniq.begin(), uniq.end());
-  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-  const int64_t G = (int64_t)uniq.size();
-  if (G > *Ku) { *Ku = G; return fail(h, PLDA_E_CAPACITY, "transform_groups: %lld groups > capacity", (long long)G); }
-  std::vector<uint64_t> dense((size_t)N);
-  for (int64_t r = 0; r < N; ++r)
-    dense[r] = (uint64_t)(std::lower_bound(uniq.begin(), uniq.end(), labels[r]) - uniq.begin());
-  Tmp dX, dL, dM, dC, dO;
-  PLDA_TRY(upload(h, dX, X, (size_t)N * Din * 8));
-  PLDA_TRY(upload(h, dL, dense.data(), (size_t)N * 8));
-  PLDA_HIP(h, dM.alloc((size_t)G * Din * 8));
-  PLDA_HIP(h, dC.alloc((size_t)G * 4));
-  PLDA_HIP(h, dO.alloc((size_t)G * h->Dout * 8));
-  PLDA_TRY(group_means_device(h, dX.as<double>(), N, Din, dL.as<uint64_t>(), G, dM.as<double>(), dC.as<int32_t>()));
-  PLDA_TRY(transform_rows_device(h, dM.as<double>(), G, Din, dC.as<int32_t>(), 0, dO.as<double>()));
-  std::vector<int32_t> c32((size_t)G);
-  PLDA_HIP(h, hipMemcpyAsync(c32.data(), dC.p, (size_t)G * 4, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(out_vecs, dO.p, (size_t)G * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  for (int64_t g = 0; g < G; ++g) { out_labels[g] = uniq[g]; out_counts[g] = c32[g]; }
-  *Ku = G;
-  return PLDA_OK;
+  return guarded(h, "plda_transform_groups", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
+    if (!Ku) return fail(h, PLDA_E_INVAL, "transform_groups: Ku is NULL");
+    if (N <= 0) { *Ku = 0; return PLDA_OK; }
+    if (!X || !labels || !out_labels || !out_counts || !out_vecs) return fail(h, PLDA_E_INVAL, "transform_groups: bad argument");
+    if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
+    PLDA_TRY(set_device(h));
+    // label compaction (index bookkeeping; the reference does it with std::map, pldamodule.cpp:118,147-156)
+    std::vector<uint64_t> uniq(labels, labels + N);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const int64_t G = (int64_t)uniq.size();
+    if (G > *Ku) { *Ku = G; return fail(h, PLDA_E_CAPACITY, "transform_groups: %lld groups > capacity", (long long)G); }
+    std::vector<uint64_t> dense((size_t)N);
+    for (int64_t r = 0; r < N; ++r)
+      dense[r] = (uint64_t)(std::lower_bound(uniq.begin(), uniq.end(), labels[r]) - uniq.begin());
+    Tmp dX, dL, dM, dC, dO;
+    PLDA_TRY(upload(h, dX, X, (size_t)N * Din * 8));
+    PLDA_TRY(upload(h, dL, dense.data(), (size_t)N * 8));
+    PLDA_HIP(h, dM.alloc((size_t)G * Din * 8));
+    PLDA_HIP(h, dC.alloc((size_t)G * 4));
+    PLDA_HIP(h, dO.alloc((size_t)G * h->Dout * 8));
+    PLDA_TRY(group_means_device(h, dX.as<double>(), N, Din, dL.as<uint64_t>(), G, dM.as<double>(), dC.as<int32_t>()));
+    PLDA_TRY(transform_rows_device(h, dM.as<double>(), G, Din, dC.as<int32_t>(), 0, dO.as<double>()));
+    std::vector<int32_t> c32((size_t)G);
+    PLDA_HIP(h, hipMemcpyAsync(c32.data(), dC.p, (size_t)G * 4, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(out_vecs, dO.p, (size_t)G * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t g = 0; g < G; ++g) { out_labels[g] = uniq[g]; out_counts[g] = c32[g]; }
+    *Ku = G;
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- score
 int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform, int64_t M,
                           const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
                           int64_t ld_out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return score_matrix_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out);
+  return guarded(h, "plda_score_matrix_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return score_matrix_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out);
+  });
 }
 
 int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, int32_t n_uniform, int64_t M,
                       const double *V, int64_t Nt, const double *zmean, const double *zstd, float *out,
                       int64_t ld_out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
-  if (M <= 0 || Nt <= 0) return PLDA_OK;
-  if (!U || !V || !out || ld_out < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
-  PLDA_TRY(set_device(h));
-  const int D = h->Dout;
-  Tmp dV, dU, dN, dZm, dZs, dO;
-  PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
-  // row slabs so that the device score block stays <= 1 GiB
-  int64_t slab = std::max<int64_t>(128, ((1ll << 30) / 4 / Nt) / 128 * 128);
-  slab = std::min(slab, round_up(M, 128));
-  PLDA_HIP(h, dU.alloc((size_t)slab * D * 8));
-  PLDA_HIP(h, dO.alloc((size_t)slab * Nt * 4));
-  if (n_enrol) PLDA_HIP(h, dN.alloc((size_t)slab * 4));
-  if (zmean && zstd) { PLDA_HIP(h, dZm.alloc((size_t)slab * 8)); PLDA_HIP(h, dZs.alloc((size_t)slab * 8)); }
-  for (int64_t r0 = 0; r0 < M; r0 += slab) {
-    const int64_t m = std::min(slab, M - r0);
-    PLDA_HIP(h, hipMemcpyAsync(dU.p, U + r0 * D, (size_t)m * D * 8, hipMemcpyHostToDevice, h->stream));
-    if (n_enrol) PLDA_HIP(h, hipMemcpyAsync(dN.p, n_enrol + r0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
-    if (zmean && zstd) {
-      PLDA_HIP(h, hipMemcpyAsync(dZm.p, zmean + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
-      PLDA_HIP(h, hipMemcpyAsync(dZs.p, zstd + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+  return guarded(h, "plda_score_matrix", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
+    if (M <= 0 || Nt <= 0) return PLDA_OK;
+    if (!U || !V || !out || ld_out < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
+    PLDA_TRY(set_device(h));
+    const int D = h->Dout;
+    Tmp dV, dU, dN, dZm, dZs, dO;
+    PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
+    // row slabs so that the device score block stays <= 1 GiB
+    int64_t slab = std::max<int64_t>(128, ((1ll << 30) / 4 / Nt) / 128 * 128);
+    slab = std::min(slab, round_up(M, 128));
+    PLDA_HIP(h, dU.alloc((size_t)slab * D * 8));
+    PLDA_HIP(h, dO.alloc((size_t)slab * Nt * 4));
+    if (n_enrol) PLDA_HIP(h, dN.alloc((size_t)slab * 4));
+    if (zmean && zstd) { PLDA_HIP(h, dZm.alloc((size_t)slab * 8)); PLDA_HIP(h, dZs.alloc((size_t)slab * 8)); }
+    for (int64_t r0 = 0; r0 < M; r0 += slab) {
+      const int64_t m = std::min(slab, M - r0);
+      PLDA_HIP(h, hipMemcpyAsync(dU.p, U + r0 * D, (size_t)m * D * 8, hipMemcpyHostToDevice, h->stream));
+      if (n_enrol) PLDA_HIP(h, hipMemcpyAsync(dN.p, n_enrol + r0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+      if (zmean && zstd) {
+        PLDA_HIP(h, hipMemcpyAsync(dZm.p, zmean + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+        PLDA_HIP(h, hipMemcpyAsync(dZs.p, zstd + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+      }
+      PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
+                                   dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
+                                   (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt));
+      PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
+                                   (size_t)m, hipMemcpyDeviceToHost, h->stream));
+      PLDA_HIP(h, hipStreamSynchronize(h->stream));
     }
-    PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
-                                 dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
-                                 (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt));
-    PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
-                                 (size_t)m, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  }
-  h->last_M = M;
-  return PLDA_OK;
+    h->last_M = M;
+    return PLDA_OK;
+  });
 }
 
 int plda_profile_enable(plda_handle *h, int32_t on) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  h->prof_on = on != 0;
-  return PLDA_OK;
+  return guarded(h, "plda_profile_enable", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    h->prof_on = on != 0;
+    return PLDA_OK;
+  });
 }
 
 int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double *gemm_flop, int32_t reset) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  double total = 0.0;
-  for (size_t i = 0; i < h->prof_used; ++i) {
-    float ms = 0.f;
-    PLDA_HIP(h, hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
-    total += ms;
-  }
-  if (gemm_ms) *gemm_ms = total;
-  if (launches) *launches = (int64_t)h->prof_used;
-  if (gemm_flop) *gemm_flop = h->prof_flop;
-  if (reset) { h->prof_used = 0; h->prof_flop = 0.0; }
-  return PLDA_OK;
+  return guarded(h, "plda_profile_read", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    for (size_t i = 0; i < h->prof_used; ++i) {
+      float ms = 0.f;
+      PLDA_HIP(h, hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+      total += ms;
+    }
+    if (gemm_ms) *gemm_ms = total;
+    if (launches) *launches = (int64_t)h->prof_used;
+    if (gemm_flop) *gemm_flop = h->prof_flop;
+    if (reset) { h->prof_used = 0; h->prof_flop = 0.0; }
+    return PLDA_OK;
+  });
 }
 
 int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!out || cap_words < (int64_t)TIMELINE_WORDS) return fail(h, PLDA_E_CAPACITY, "profile_timeline: need %zu words", TIMELINE_WORDS);
-  if (!h->timeline_valid) return fail(h, PLDA_E_INVAL, "profile_timeline: no PLDA_GEMM_VARIANT=31 launch has run on this handle");
-  PLDA_TRY(set_device(h));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  PLDA_HIP(h, hipMemcpy(out, h->timeline.p, TIMELINE_WORDS * 8, hipMemcpyDeviceToHost));
-  return PLDA_OK;
+  return guarded(h, "plda_profile_timeline", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!out || cap_words < (int64_t)TIMELINE_WORDS) return fail(h, PLDA_E_CAPACITY, "profile_timeline: need %zu words", TIMELINE_WORDS);
+    if (!h->timeline_valid) return fail(h, PLDA_E_INVAL, "profile_timeline: no PLDA_GEMM_VARIANT=31 launch has run on this handle");
+    PLDA_TRY(set_device(h));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    PLDA_HIP(h, hipMemcpy(out, h->timeline.p, TIMELINE_WORDS * 8, hipMemcpyDeviceToHost));
+    return PLDA_OK;
+  });
 }
 
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (M) *M = h->last_M;
-  if (Nt) *Nt = h->last_Nt;
-  if (gemm_k) *gemm_k = h->last_k;
-  return PLDA_OK;
+  return guarded(h, "plda_score_last_shape", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (M) *M = h->last_M;
+    if (Nt) *Nt = h->last_Nt;
+    if (gemm_k) *gemm_k = h->last_k;
+    return PLDA_OK;
+  });
 }
 
 int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, int64_t M, const double *V,
                      int64_t Nt, const int64_t *e_idx, const int64_t *t_idx, int64_t P, const double *zmean,
                      const double *zstd, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score: model not fitted");
-  if (P <= 0) return PLDA_OK;
-  if (!U || !n_enrol || !V || !e_idx || !t_idx || !out || M <= 0 || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: bad argument");
-  for (int64_t p = 0; p < P; ++p)
-    if (e_idx[p] < 0 || e_idx[p] >= M || t_idx[p] < 0 || t_idx[p] >= Nt)
-      return fail(h, PLDA_E_INVAL, "score_pairs: trial %lld indexes outside the enrol/test sets", (long long)p);
-  for (int64_t i = 0; i < M; ++i)
-    if (n_enrol[i] <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: num_examples must be > 0");
-  PLDA_TRY(set_device(h));
-  const int D = h->Dout;
-  if (P == 1 && M == 1 && Nt == 1) {
-    // One trial -- the reference's MPlda_score call (pldamodule.cpp:258-277).  No allocation and no copy
-    // engine: the operands go into a host buffer that is mapped into the GPU's address space, the kernel
-    // reads them and writes the score back through that mapping, and one stream synchronisation ends the call.
-    const size_t need = ((size_t)2 * D + 8) * 8;
-    if (h->one_cap < need) {
-      if (h->one_host) (void)hipHostFree(h->one_host);
-      h->one_host = nullptr; h->one_cap = 0;
-      PLDA_HIP(h, hipHostMalloc(&h->one_host, need, hipHostMallocMapped));
-      PLDA_HIP(h, hipHostGetDevicePointer(&h->one_dev, h->one_host, 0));
-      h->one_cap = need;
+  return guarded(h, "plda_score_pairs", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score: model not fitted");
+    if (P <= 0) return PLDA_OK;
+    if (!U || !n_enrol || !V || !e_idx || !t_idx || !out || M <= 0 || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: bad argument");
+    for (int64_t p = 0; p < P; ++p)
+      if (e_idx[p] < 0 || e_idx[p] >= M || t_idx[p] < 0 || t_idx[p] >= Nt)
+        return fail(h, PLDA_E_INVAL, "score_pairs: trial %lld indexes outside the enrol/test sets", (long long)p);
+    for (int64_t i = 0; i < M; ++i)
+      if (n_enrol[i] <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: num_examples must be > 0");
+    PLDA_TRY(set_device(h));
+    const int D = h->Dout;
+    if (P == 1 && M == 1 && Nt == 1) {
+      // One trial -- the reference's MPlda_score call (pldamodule.cpp:258-277).  No allocation and no copy
+      // engine: the operands go into a host buffer that is mapped into the GPU's address space, the kernel
+      // reads them and writes the score back through that mapping, and one stream synchronisation ends the call.
+      const size_t need = ((size_t)2 * D + 8) * 8;
+      if (h->one_cap < need) {
+        if (h->one_host) (void)hipHostFree(h->one_host);
+        h->one_host = nullptr; h->one_cap = 0;
+        PLDA_HIP(h, hipHostMalloc(&h->one_host, need, hipHostMallocMapped));
+        PLDA_HIP(h, hipHostGetDevicePointer(&h->one_dev, h->one_host, 0));
+        h->one_cap = need;
+      }
+      double *hb = static_cast<double *>(h->one_host);
+      double *db = static_cast<double *>(h->one_dev);
+      // layout: u[D] v[D] zmean zstd out | e_idx t_idx (int64) | n (int32)
+      std::memcpy(hb, U, (size_t)D * 8);
+      std::memcpy(hb + D, V, (size_t)D * 8);
+      const bool zn1 = zmean && zstd;
+      hb[2 * D] = zn1 ? zmean[0] : 0.0;
+      hb[2 * D + 1] = zn1 ? zstd[0] : 0.0;
+      int64_t *hi = reinterpret_cast<int64_t *>(hb + 2 * D + 3);
+      hi[0] = 0; hi[1] = 0;
+      *reinterpret_cast<int32_t *>(hb + 2 * D + 5) = n_enrol[0];
+      PLDA_TRY(score_pairs_device(h, db, reinterpret_cast<const int32_t *>(db + 2 * D + 5), db + D,
+                                  reinterpret_cast<const int64_t *>(db + 2 * D + 3),
+                                  reinterpret_cast<const int64_t *>(db + 2 * D + 4), 1, zn1 ? db + 2 * D : nullptr,
+                                  zn1 ? db + 2 * D + 1 : nullptr, db + 2 * D + 2));
+      PLDA_HIP(h, hipStreamSynchronize(h->stream));
+      out[0] = hb[2 * D + 2];
+      return PLDA_OK;
     }
-    double *hb = static_cast<double *>(h->one_host);
-    double *db = static_cast<double *>(h->one_dev);
-    // layout: u[D] v[D] zmean zstd out | e_idx t_idx (int64) | n (int32)
-    std::memcpy(hb, U, (size_t)D * 8);
-    std::memcpy(hb + D, V, (size_t)D * 8);
-    const bool zn1 = zmean && zstd;
-    hb[2 * D] = zn1 ? zmean[0] : 0.0;
-    hb[2 * D + 1] = zn1 ? zstd[0] : 0.0;
-    int64_t *hi = reinterpret_cast<int64_t *>(hb + 2 * D + 3);
-    hi[0] = 0; hi[1] = 0;
-    *reinterpret_cast<int32_t *>(hb + 2 * D + 5) = n_enrol[0];
-    PLDA_TRY(score_pairs_device(h, db, reinterpret_cast<const int32_t *>(db + 2 * D + 5), db + D,
-                                reinterpret_cast<const int64_t *>(db + 2 * D + 3),
-                                reinterpret_cast<const int64_t *>(db + 2 * D + 4), 1, zn1 ? db + 2 * D : nullptr,
-                                zn1 ? db + 2 * D + 1 : nullptr, db + 2 * D + 2));
+    Tmp dU, dN, dV, dE, dT, dZm, dZs, dO;
+    PLDA_TRY(upload(h, dU, U, (size_t)M * D * 8));
+    PLDA_TRY(upload(h, dN, n_enrol, (size_t)M * 4));
+    PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
+    PLDA_TRY(upload(h, dE, e_idx, (size_t)P * 8));
+    PLDA_TRY(upload(h, dT, t_idx, (size_t)P * 8));
+    const bool zn = zmean && zstd;
+    if (zn) { PLDA_TRY(upload(h, dZm, zmean, (size_t)M * 8)); PLDA_TRY(upload(h, dZs, zstd, (size_t)M * 8)); }
+    PLDA_HIP(h, dO.alloc((size_t)P * 8));
+    PLDA_TRY(score_pairs_device(h, dU.as<double>(), dN.as<int32_t>(), dV.as<double>(), dE.as<int64_t>(),
+                                dT.as<int64_t>(), P, zn ? dZm.as<double>() : nullptr,
+                                zn ? dZs.as<double>() : nullptr, dO.as<double>()));
+    PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    out[0] = hb[2 * D + 2];
     return PLDA_OK;
-  }
-  Tmp dU, dN, dV, dE, dT, dZm, dZs, dO;
-  PLDA_TRY(upload(h, dU, U, (size_t)M * D * 8));
-  PLDA_TRY(upload(h, dN, n_enrol, (size_t)M * 4));
-  PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
-  PLDA_TRY(upload(h, dE, e_idx, (size_t)P * 8));
-  PLDA_TRY(upload(h, dT, t_idx, (size_t)P * 8));
-  const bool zn = zmean && zstd;
-  if (zn) { PLDA_TRY(upload(h, dZm, zmean, (size_t)M * 8)); PLDA_TRY(upload(h, dZs, zstd, (size_t)M * 8)); }
-  PLDA_HIP(h, dO.alloc((size_t)P * 8));
-  PLDA_TRY(score_pairs_device(h, dU.as<double>(), dN.as<int32_t>(), dV.as<double>(), dE.as<int64_t>(),
-                              dT.as<int64_t>(), P, zn ? dZm.as<double>() : nullptr,
-                              zn ? dZs.as<double>() : nullptr, dO.as<double>()));
-  PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- z-norm
 int plda_znorm_stats_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples, int32_t Din,
                          const double *dmodels, int64_t M, double *dout_mean, double *dout_std) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return znorm_stats_device(h, dbkg, Nb, num_examples, Din, dmodels, M, dout_mean, dout_std);
+  return guarded(h, "plda_znorm_stats_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return znorm_stats_device(h, dbkg, Nb, num_examples, Din, dmodels, M, dout_mean, dout_std);
+  });
 }
 
 int plda_znorm_stats(plda_handle *h, const double *bkg, int64_t Nb, int32_t num_examples, int32_t Din,
                      const double *models, int64_t M, double *out_mean, double *out_std) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
-  if (!bkg || !models || !out_mean || !out_std || Nb <= 0 || M <= 0) return fail(h, PLDA_E_INVAL, "norm: bad argument");
-  if (Din != h->Din) return fail(h, PLDA_E_INVAL, "norm: feature dim %d != model dim %d", Din, h->Din);
-  PLDA_TRY(set_device(h));
-  Tmp dB, dM, dMean, dStd;
-  PLDA_TRY(upload(h, dB, bkg, (size_t)Nb * Din * 8));
-  PLDA_TRY(upload(h, dM, models, (size_t)M * h->Dout * 8));
-  PLDA_HIP(h, dMean.alloc((size_t)M * 8));
-  PLDA_HIP(h, dStd.alloc((size_t)M * 8));
-  PLDA_TRY(znorm_stats_device(h, dB.as<double>(), Nb, num_examples, Din, dM.as<double>(), M, dMean.as<double>(),
-                              dStd.as<double>()));
-  PLDA_HIP(h, hipMemcpyAsync(out_mean, dMean.p, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(out_std, dStd.p, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_znorm_stats", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
+    if (!bkg || !models || !out_mean || !out_std || Nb <= 0 || M <= 0) return fail(h, PLDA_E_INVAL, "norm: bad argument");
+    if (Din != h->Din) return fail(h, PLDA_E_INVAL, "norm: feature dim %d != model dim %d", Din, h->Din);
+    PLDA_TRY(set_device(h));
+    Tmp dB, dM, dMean, dStd;
+    PLDA_TRY(upload(h, dB, bkg, (size_t)Nb * Din * 8));
+    PLDA_TRY(upload(h, dM, models, (size_t)M * h->Dout * 8));
+    PLDA_HIP(h, dMean.alloc((size_t)M * 8));
+    PLDA_HIP(h, dStd.alloc((size_t)M * 8));
+    PLDA_TRY(znorm_stats_device(h, dB.as<double>(), Nb, num_examples, Din, dM.as<double>(), M, dMean.as<double>(),
+                                dStd.as<double>()));
+    PLDA_HIP(h, hipMemcpyAsync(out_mean, dMean.p, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(out_std, dStd.p, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- d-vector front-end
 int plda_dvector_pool_dev(plda_handle *h, const void *dframes, int32_t dtype, int64_t T, int32_t D,
                           const int64_t *doffsets, int64_t U, int32_t method, int32_t l2norm, double *dout) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return dvector_pool_device(h, dframes, dtype, T, D, doffsets, U, method, l2norm, dout);
+  return guarded(h, "plda_dvector_pool_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return dvector_pool_device(h, dframes, dtype, T, D, doffsets, U, method, l2norm, dout);
+  });
 }
 
 int plda_dvector_pool(plda_handle *h, const void *frames, int32_t dtype, int64_t T, int32_t D, const int64_t *offsets,
                       int64_t U, int32_t method, int32_t l2norm, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (U <= 0) return PLDA_OK;
-  if (!frames || !offsets || !out || T < 0 || D <= 0 || (dtype != 0 && dtype != 1))
-    return fail(h, PLDA_E_INVAL, "dvector_pool: bad argument");
-  for (int64_t u = 0; u < U; ++u)
-    if (offsets[u] < 0 || offsets[u + 1] < offsets[u] || offsets[u + 1] > T)
-      return fail(h, PLDA_E_INVAL, "dvector_pool: offsets must be non-decreasing within [0, T]");
-  PLDA_TRY(set_device(h));
-  Tmp dF, dO, dOut;
-  PLDA_TRY(upload(h, dF, frames, (size_t)T * D * (dtype == 0 ? 4 : 8)));
-  PLDA_TRY(upload(h, dO, offsets, (size_t)(U + 1) * 8));
-  PLDA_HIP(h, dOut.alloc((size_t)U * D * 8));
-  PLDA_TRY(dvector_pool_device(h, dF.p, dtype, T, D, dO.as<int64_t>(), U, method, l2norm, dOut.as<double>()));
-  PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, (size_t)U * D * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_dvector_pool", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (U <= 0) return PLDA_OK;
+    if (!frames || !offsets || !out || T < 0 || D <= 0 || (dtype != 0 && dtype != 1))
+      return fail(h, PLDA_E_INVAL, "dvector_pool: bad argument");
+    for (int64_t u = 0; u < U; ++u)
+      if (offsets[u] < 0 || offsets[u + 1] < offsets[u] || offsets[u + 1] > T)
+        return fail(h, PLDA_E_INVAL, "dvector_pool: offsets must be non-decreasing within [0, T]");
+    PLDA_TRY(set_device(h));
+    Tmp dF, dO, dOut;
+    PLDA_TRY(upload(h, dF, frames, (size_t)T * D * (dtype == 0 ? 4 : 8)));
+    PLDA_TRY(upload(h, dO, offsets, (size_t)(U + 1) * 8));
+    PLDA_HIP(h, dOut.alloc((size_t)U * D * 8));
+    PLDA_TRY(dvector_pool_device(h, dF.p, dtype, T, D, dO.as<int64_t>(), U, method, l2norm, dOut.as<double>()));
+    PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, (size_t)U * D * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- LDA (python/liblda/lda.py)
 int plda_lda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
                      int32_t solver, const double *priors) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return lda_fit_device(h, dX, N, D, dlabels, K, solver, priors);
+  return guarded(h, "plda_lda_fit_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return lda_fit_device(h, dX, N, D, dlabels, K, solver, priors);
+  });
 }
 
 int plda_lda_fit(plda_handle *h, const double *X, int64_t N, int32_t D, const uint64_t *labels, int32_t solver,
                  const double *priors) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "lda_fit: bad argument");
-  uint64_t mx = 0;
-  for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
-  if (mx >= (uint64_t)N) return fail(h, PLDA_E_LABELS, "lda_fit: labels must be dense 0..K-1");
-  PLDA_TRY(set_device(h));
-  Tmp dX, dL;
-  PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
-  PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
-  return lda_fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), (int64_t)mx + 1, solver, priors);
+  return guarded(h, "plda_lda_fit", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!X || !labels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "lda_fit: bad argument");
+    uint64_t mx = 0;
+    for (int64_t r = 0; r < N; ++r) mx = std::max(mx, labels[r]);
+    if (mx >= (uint64_t)N) return fail(h, PLDA_E_LABELS, "lda_fit: labels must be dense 0..K-1");
+    PLDA_TRY(set_device(h));
+    Tmp dX, dL;
+    PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
+    PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
+    return lda_fit_device(h, dX.as<double>(), N, D, dL.as<uint64_t>(), (int64_t)mx + 1, solver, priors);
+  });
 }
 
 int plda_lda_dims(plda_handle *h, int64_t *K, int32_t *D, int32_t *rank, int32_t *solver) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
-  if (K) *K = h->lda_K;
-  if (D) *D = h->lda_D;
-  if (rank) *rank = h->lda_rank;
-  if (solver) *solver = h->lda_solver;
-  return PLDA_OK;
+  return guarded(h, "plda_lda_dims", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+    if (K) *K = h->lda_K;
+    if (D) *D = h->lda_D;
+    if (rank) *rank = h->lda_rank;
+    if (solver) *solver = h->lda_solver;
+    return PLDA_OK;
+  });
 }
 
 int plda_lda_get_model(plda_handle *h, double *priors, double *means, double *xbar, double *scalings, double *coef,
                        double *intercept, double *evr) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
-  PLDA_TRY(set_device(h));
-  const size_t K = (size_t)h->lda_K, D = (size_t)h->lda_D, R = (size_t)h->lda_rank;
-  auto get = [&](double *dst, const DevBuf &src, size_t n) -> hipError_t {
-    return (dst && n) ? hipMemcpyAsync(dst, src.p, n * 8, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
-  };
-  PLDA_HIP(h, get(priors, h->l_priors, K));
-  PLDA_HIP(h, get(means, h->l_means, K * D));
-  PLDA_HIP(h, get(coef, h->l_coef, K * D));
-  PLDA_HIP(h, get(intercept, h->l_intercept, K));
-  if (h->lda_solver == 0) PLDA_HIP(h, get(xbar, h->l_xbar, D));
-  if (h->lda_solver != 2) PLDA_HIP(h, get(scalings, h->l_scalings, D * R));
-  if (h->lda_solver == 1) PLDA_HIP(h, get(evr, h->l_evr, D));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_lda_get_model", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+    PLDA_TRY(set_device(h));
+    const size_t K = (size_t)h->lda_K, D = (size_t)h->lda_D, R = (size_t)h->lda_rank;
+    auto get = [&](double *dst, const DevBuf &src, size_t n) -> hipError_t {
+      return (dst && n) ? hipMemcpyAsync(dst, src.p, n * 8, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+    };
+    PLDA_HIP(h, get(priors, h->l_priors, K));
+    PLDA_HIP(h, get(means, h->l_means, K * D));
+    PLDA_HIP(h, get(coef, h->l_coef, K * D));
+    PLDA_HIP(h, get(intercept, h->l_intercept, K));
+    if (h->lda_solver == 0) PLDA_HIP(h, get(xbar, h->l_xbar, D));
+    if (h->lda_solver != 2) PLDA_HIP(h, get(scalings, h->l_scalings, D * R));
+    if (h->lda_solver == 1) PLDA_HIP(h, get(evr, h->l_evr, D));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 int plda_lda_set_model(plda_handle *h, int32_t solver, int64_t K, int32_t D, int32_t rank, const double *priors,
                        const double *means, const double *xbar, const double *scalings, const double *coef,
                        const double *intercept) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (solver < 0 || solver > 2 || K <= 0 || D <= 0 || rank < 0 || rank > D || !coef || !intercept)
-    return fail(h, PLDA_E_INVAL, "lda_set_model: bad argument");
-  if (solver != 2 && (!scalings || rank == 0)) return fail(h, PLDA_E_INVAL, "lda_set_model: scalings required");
-  if (solver == 0 && !xbar) return fail(h, PLDA_E_INVAL, "lda_set_model: xbar required for the svd solver");
-  PLDA_TRY(set_device(h));
-  auto put = [&](DevBuf &dst, const double *src, size_t n) -> hipError_t {
-    hipError_t e = dst.reserve((n ? n : 1) * 8);
-    if (e != hipSuccess || !src || !n) return e;
-    return hipMemcpyAsync(dst.p, src, n * 8, hipMemcpyHostToDevice, h->stream);
-  };
-  const size_t k = (size_t)K, d = (size_t)D;
-  PLDA_HIP(h, put(h->l_priors, priors, k));
-  PLDA_HIP(h, put(h->l_means, means, k * d));
-  PLDA_HIP(h, put(h->l_xbar, xbar, d));
-  PLDA_HIP(h, put(h->l_scalings, scalings, d * (size_t)rank));
-  PLDA_HIP(h, put(h->l_coef, coef, k * d));
-  PLDA_HIP(h, put(h->l_intercept, intercept, k));
-  PLDA_HIP(h, h->l_evr.reserve(d * 8));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  h->lda_fitted = true; h->lda_solver = solver; h->lda_K = K; h->lda_D = D; h->lda_rank = rank;
-  return PLDA_OK;
+  return guarded(h, "plda_lda_set_model", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (solver < 0 || solver > 2 || K <= 0 || D <= 0 || rank < 0 || rank > D || !coef || !intercept)
+      return fail(h, PLDA_E_INVAL, "lda_set_model: bad argument");
+    if (solver != 2 && (!scalings || rank == 0)) return fail(h, PLDA_E_INVAL, "lda_set_model: scalings required");
+    if (solver == 0 && !xbar) return fail(h, PLDA_E_INVAL, "lda_set_model: xbar required for the svd solver");
+    PLDA_TRY(set_device(h));
+    auto put = [&](DevBuf &dst, const double *src, size_t n) -> hipError_t {
+      hipError_t e = dst.reserve((n ? n : 1) * 8);
+      if (e != hipSuccess || !src || !n) return e;
+      return hipMemcpyAsync(dst.p, src, n * 8, hipMemcpyHostToDevice, h->stream);
+    };
+    const size_t k = (size_t)K, d = (size_t)D;
+    PLDA_HIP(h, put(h->l_priors, priors, k));
+    PLDA_HIP(h, put(h->l_means, means, k * d));
+    PLDA_HIP(h, put(h->l_xbar, xbar, d));
+    PLDA_HIP(h, put(h->l_scalings, scalings, d * (size_t)rank));
+    PLDA_HIP(h, put(h->l_coef, coef, k * d));
+    PLDA_HIP(h, put(h->l_intercept, intercept, k));
+    PLDA_HIP(h, h->l_evr.reserve(d * 8));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    h->lda_fitted = true; h->lda_solver = solver; h->lda_K = K; h->lda_D = D; h->lda_rank = rank;
+    return PLDA_OK;
+  });
 }
 
 int plda_lda_predict_dev(plda_handle *h, const double *dX, int64_t N, int32_t mode, double *dout) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return lda_predict_device(h, dX, N, mode, dout);
+  return guarded(h, "plda_lda_predict_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return lda_predict_device(h, dX, N, mode, dout);
+  });
 }
 
 int plda_lda_predict(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t mode, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
-  if (D != h->lda_D)
-    return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);   // lda.py:264-266
-  if (N <= 0) return PLDA_OK;
-  if (!X || !out) return fail(h, PLDA_E_INVAL, "lda_predict: bad argument");
-  PLDA_TRY(set_device(h));
-  // row slabs bound the device footprint of the [N, K] result
-  const int64_t slab = std::max<int64_t>(1, std::min<int64_t>(N, ((int64_t)1 << 28) / std::max<int64_t>(h->lda_K, D)));
-  Tmp dX, dO;
-  PLDA_HIP(h, dX.alloc((size_t)slab * D * 8));
-  PLDA_HIP(h, dO.alloc((size_t)slab * h->lda_K * 8));
-  for (int64_t r0 = 0; r0 < N; r0 += slab) {
-    const int64_t r = std::min(slab, N - r0);
-    PLDA_HIP(h, hipMemcpyAsync(dX.p, X + r0 * D, (size_t)r * D * 8, hipMemcpyHostToDevice, h->stream));
-    PLDA_TRY(lda_predict_device(h, dX.as<double>(), r, mode, dO.as<double>()));
-    PLDA_HIP(h, hipMemcpyAsync(out + r0 * h->lda_K, dO.p, (size_t)r * h->lda_K * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  }
-  return PLDA_OK;
+  return guarded(h, "plda_lda_predict", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+    if (D != h->lda_D)
+      return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);   // lda.py:264-266
+    if (N <= 0) return PLDA_OK;
+    if (!X || !out) return fail(h, PLDA_E_INVAL, "lda_predict: bad argument");
+    PLDA_TRY(set_device(h));
+    // row slabs bound the device footprint of the [N, K] result
+    const int64_t slab = std::max<int64_t>(1, std::min<int64_t>(N, ((int64_t)1 << 28) / std::max<int64_t>(h->lda_K, D)));
+    Tmp dX, dO;
+    PLDA_HIP(h, dX.alloc((size_t)slab * D * 8));
+    PLDA_HIP(h, dO.alloc((size_t)slab * h->lda_K * 8));
+    for (int64_t r0 = 0; r0 < N; r0 += slab) {
+      const int64_t r = std::min(slab, N - r0);
+      PLDA_HIP(h, hipMemcpyAsync(dX.p, X + r0 * D, (size_t)r * D * 8, hipMemcpyHostToDevice, h->stream));
+      PLDA_TRY(lda_predict_device(h, dX.as<double>(), r, mode, dO.as<double>()));
+      PLDA_HIP(h, hipMemcpyAsync(out + r0 * h->lda_K, dO.p, (size_t)r * h->lda_K * 8, hipMemcpyDeviceToHost, h->stream));
+      PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return PLDA_OK;
+  });
 }
 
 int plda_lda_transform_dev(plda_handle *h, const double *dX, int64_t N, int32_t ncomp, double *dout) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return lda_transform_device(h, dX, N, ncomp, dout);
+  return guarded(h, "plda_lda_transform_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return lda_transform_device(h, dX, N, ncomp, dout);
+  });
 }
 
 int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, int32_t ncomp, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
-  if (D != h->lda_D) return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);
-  if (N <= 0 || ncomp <= 0) return PLDA_OK;
-  if (!X || !out) return fail(h, PLDA_E_INVAL, "lda_transform: bad argument");
-  PLDA_TRY(set_device(h));
-  Tmp dX, dO;
-  PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
-  PLDA_HIP(h, dO.alloc((size_t)N * ncomp * 8));
-  PLDA_TRY(lda_transform_device(h, dX.as<double>(), N, ncomp, dO.as<double>()));
-  PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)N * ncomp * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_lda_transform", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->lda_fitted) return fail(h, PLDA_E_NOT_FITTED, "This LDA instance is not fitted yet");
+    if (D != h->lda_D) return fail(h, PLDA_E_INVAL, "X has %d features per sample; expecting %d", D, h->lda_D);
+    if (N <= 0 || ncomp <= 0) return PLDA_OK;
+    if (!X || !out) return fail(h, PLDA_E_INVAL, "lda_transform: bad argument");
+    PLDA_TRY(set_device(h));
+    Tmp dX, dO;
+    PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
+    PLDA_HIP(h, dO.alloc((size_t)N * ncomp * 8));
+    PLDA_TRY(lda_transform_device(h, dX.as<double>(), N, ncomp, dO.as<double>()));
+    PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)N * ncomp * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- HTK feature files
 int plda_htk_frames_dev(plda_handle *h, const void *dblob, const int64_t *dfile_off, const int64_t *dframe_off,
                         int64_t U, int64_t T, int32_t samplesize, int32_t frm_ext, float *dout) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return htk_frames_device(h, dblob, dfile_off, dframe_off, U, T, samplesize, frm_ext, dout);
+  return guarded(h, "plda_htk_frames_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return htk_frames_device(h, dblob, dfile_off, dframe_off, U, T, samplesize, frm_ext, dout);
+  });
 }
 
 int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const int64_t *file_off,
                     const int64_t *frame_off, int64_t U, int32_t samplesize, int32_t frm_ext, float *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (U <= 0) return PLDA_OK;
-  if (!blob || !file_off || !frame_off || !out || blob_bytes < 0 || samplesize <= 0 || frm_ext < 0)
-    return fail(h, PLDA_E_INVAL, "htk_frames: bad argument");
-  if (samplesize % 4) return fail(h, PLDA_E_INVAL, "htk_frames: samplesize %d is not a multiple of 4", samplesize);
-  const int64_t W = samplesize / 4;
-  for (int64_t u = 0; u < U; ++u) {
-    const int64_t n = frame_off[u + 1] - frame_off[u];
-    if (n < 0 || file_off[u] < 0 || (file_off[u] + n * W) * 4 > blob_bytes)
-      return fail(h, PLDA_E_INVAL, "htk_frames: file %lld does not fit the blob (pad short files with zeros)", (long long)u);
-  }
-  const int64_t T = frame_off[U] - frame_off[0];
-  if (frame_off[0] != 0) return fail(h, PLDA_E_INVAL, "htk_frames: frame_off[0] must be 0");
-  if (T <= 0) return PLDA_OK;
-  PLDA_TRY(set_device(h));
-  Tmp dB, dF, dO, dOut;
-  PLDA_TRY(upload(h, dB, blob, (size_t)blob_bytes));
-  PLDA_TRY(upload(h, dF, file_off, (size_t)U * 8));
-  PLDA_TRY(upload(h, dO, frame_off, (size_t)(U + 1) * 8));
-  const size_t obytes = (size_t)T * (2 * frm_ext + 1) * samplesize;
-  PLDA_HIP(h, dOut.alloc(obytes));
-  PLDA_TRY(htk_frames_device(h, dB.p, dF.as<int64_t>(), dO.as<int64_t>(), U, T, samplesize, frm_ext, dOut.as<float>()));
-  PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, obytes, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  return PLDA_OK;
+  return guarded(h, "plda_htk_frames", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (U <= 0) return PLDA_OK;
+    if (!blob || !file_off || !frame_off || !out || blob_bytes < 0 || samplesize <= 0 || frm_ext < 0)
+      return fail(h, PLDA_E_INVAL, "htk_frames: bad argument");
+    if (samplesize % 4) return fail(h, PLDA_E_INVAL, "htk_frames: samplesize %d is not a multiple of 4", samplesize);
+    const int64_t W = samplesize / 4;
+    for (int64_t u = 0; u < U; ++u) {
+      const int64_t n = frame_off[u + 1] - frame_off[u];
+      if (n < 0 || file_off[u] < 0 || (file_off[u] + n * W) * 4 > blob_bytes)
+        return fail(h, PLDA_E_INVAL, "htk_frames: file %lld does not fit the blob (pad short files with zeros)", (long long)u);
+    }
+    const int64_t T = frame_off[U] - frame_off[0];
+    if (frame_off[0] != 0) return fail(h, PLDA_E_INVAL, "htk_frames: frame_off[0] must be 0");
+    if (T <= 0) return PLDA_OK;
+    PLDA_TRY(set_device(h));
+    Tmp dB, dF, dO, dOut;
+    PLDA_TRY(upload(h, dB, blob, (size_t)blob_bytes));
+    PLDA_TRY(upload(h, dF, file_off, (size_t)U * 8));
+    PLDA_TRY(upload(h, dO, frame_off, (size_t)(U + 1) * 8));
+    const size_t obytes = (size_t)T * (2 * frm_ext + 1) * samplesize;
+    PLDA_HIP(h, dOut.alloc(obytes));
+    PLDA_TRY(htk_frames_device(h, dB.p, dF.as<int64_t>(), dO.as<int64_t>(), U, T, samplesize, frm_ext, dOut.as<float>()));
+    PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, obytes, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
 }
 
 // ---------------------------------------------------------------- EER
 int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
                         const int64_t *denrol_spk, const int64_t *dtest_spk, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  PLDA_TRY(set_device(h));
-  return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
+  return guarded(h, "plda_eer_matrix_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
+  });
 }
 
 int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
                                 const int64_t *denrol_spk, const int64_t *dtest_spk, plda_eer_reduce_fn reduce, void *ctx,
                                 double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!reduce) return fail(h, PLDA_E_INVAL, "eer_matrix_sharded: a reduction callback is required");
-  PLDA_TRY(set_device(h));
-  return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out, reduce, ctx);
+  return guarded(h, "plda_eer_matrix_sharded_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!reduce) return fail(h, PLDA_E_INVAL, "eer_matrix_sharded: a reduction callback is required");
+    PLDA_TRY(set_device(h));
+    return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out, reduce, ctx);
+  });
 }
 
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn, double *out) {
-  if (!h) return PLDA_E_INVAL;
-  PLDA_LOCK(h);
-  if (!pos || !neg || !out || np <= 0 || nn <= 0)
-    return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor score");
-  PLDA_TRY(set_device(h));
-  Tmp dP, dN;
-  PLDA_TRY(upload(h, dP, pos, (size_t)np * 4));
-  PLDA_TRY(upload(h, dN, neg, (size_t)nn * 4));
-  return eer_lists_device(h, dP.as<float>(), np, dN.as<float>(), nn, out);
+  return guarded(h, "plda_eer_lists", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!pos || !neg || !out || np <= 0 || nn <= 0)
+      return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor score");
+    PLDA_TRY(set_device(h));
+    Tmp dP, dN;
+    PLDA_TRY(upload(h, dP, pos, (size_t)np * 4));
+    PLDA_TRY(upload(h, dN, neg, (size_t)nn * 4));
+    return eer_lists_device(h, dP.as<float>(), np, dN.as<float>(), nn, out);
+  });
 }
 
 }  // extern "C"

@@ -120,6 +120,7 @@ struct EerSource {
   void *ctx = nullptr;
 };
 
+// One histogram pass over the local data -> hh (host).  No reduction here: see eer_device.
 static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, unsigned prefix, int has_prefix,
                     unsigned long long *dhist, unsigned *dbelow, unsigned *dabove, std::vector<unsigned long long> &hh) {
   PLDA_HIP(h, hipMemsetAsync(dhist, 0, 2 * EER_BINS * 8, h->stream));
@@ -141,14 +142,18 @@ static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, 
   hh.resize(2 * EER_BINS);
   PLDA_HIP(h, hipMemcpyAsync(hh.data(), dhist, 2 * EER_BINS * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  if (src.reduce && src.reduce(src.ctx, hh.data(), nullptr, nullptr) != 0)
-    return fail(h, PLDA_E_INVAL, "eer: the caller's reduction failed");
   return PLDA_OK;
 }
 
 // out: [0] threshold, [1] FAR, [2] FRR, [3] EER = (FAR + FRR) / 2, [4] #targets, [5] #impostors
+//
+// Sharded calls (src.reduce): every rank makes the SAME four reduction calls whatever happens locally.
+// A rank that fails (HIP error, inconsistent counts) keeps taking part with a poisoned histogram --
+// 2^48 added to counter 0, far above any real count -- so that all ranks see the failure after the
+// next sum and return an error together instead of leaving their peers blocked in a collective.
 int eer_device(plda_handle *h, const EerSource &src, double *out) {
   typedef unsigned __int128 u128;
+  constexpr unsigned long long POISON = 1ull << 48;
   PLDA_HIP(h, h->w[10].reserve(2 * EER_BINS * 8 + 64));
   unsigned long long *dhist = h->w[10].as<unsigned long long>();
   unsigned *dbelow = reinterpret_cast<unsigned *>(dhist + 2 * EER_BINS), *dabove = dbelow + 1;
@@ -159,16 +164,25 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
   const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
   unsigned long long cP = 0, cN = 0;   // counts at k1
   std::vector<unsigned long long> last;
+  static const unsigned init[2] = {0u, 0xffffffffu};   // (static: the async copy below may read it after this frame)
+  int rc = PLDA_OK;                                    // first failure seen by this rank
   for (int pass = 0; pass < 3; ++pass) {
-    if (pass == 2) {
-      const unsigned init[2] = {0u, 0xffffffffu};
-      PLDA_HIP(h, hipMemcpyAsync(dbelow, init, 8, hipMemcpyHostToDevice, h->stream));
+    if (rc == PLDA_OK && pass == 2) {
+      const hipError_t e = hipMemcpyAsync(dbelow, init, 8, hipMemcpyHostToDevice, h->stream);
+      if (e != hipSuccess) rc = hip_fail(h, e, "hipMemcpyAsync(dbelow)", __FILE__, __LINE__);
     }
-    PLDA_TRY(eer_pass(h, src, shifts[pass], bits[pass], prefix, pass > 0, dhist, dbelow, dabove, H));
+    if (rc == PLDA_OK) rc = eer_pass(h, src, shifts[pass], bits[pass], prefix, pass > 0, dhist, dbelow, dabove, H);
+    if (src.reduce) {
+      if (rc != PLDA_OK) { H.assign(2 * EER_BINS, 0ull); H[0] = POISON; }
+      if (src.reduce(src.ctx, H.data(), nullptr, nullptr) != 0 && rc == PLDA_OK)
+        rc = fail(h, PLDA_E_INVAL, "eer: the caller's reduction failed");
+      if (rc == PLDA_OK && H[0] >= POISON) rc = fail(h, PLDA_E_NUMERIC, "eer: another rank of the sharded call failed");
+    }
+    if (rc != PLDA_OK) continue;
     const int nb = 1 << bits[pass];
     if (pass == 0) {
       for (int b = 0; b < nb; ++b) { Nn += H[b]; Np += H[EER_BINS + b]; }
-      if (Np == 0 || Nn == 0) return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor trial");
+      if (Np == 0 || Nn == 0) { rc = fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor trial"); continue; }
     }
     int sel = -1;
     unsigned long long P = Pb, N = Nb;
@@ -177,17 +191,21 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
       if ((H[b] | H[EER_BINS + b]) && (u128)p2 * Nn >= (u128)(Nn - n2) * Np) { sel = b; cP = H[EER_BINS + b]; cN = H[b]; break; }
       P = p2; N = n2;
     }
-    if (sel < 0) return fail(h, PLDA_E_NUMERIC, "eer: crossing not found (inconsistent counts)");
+    if (sel < 0) { rc = fail(h, PLDA_E_NUMERIC, "eer: crossing not found (inconsistent counts)"); continue; }
     Pb = P; Nb = N;
     prefix = (prefix << bits[pass]) | (unsigned)sel;
     if (pass == 2) last = H;
   }
+  unsigned hb[2] = {0u, 0xffffffffu};
+  if (rc == PLDA_OK) {
+    hipError_t e = hipMemcpyAsync(hb, dbelow, 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = hip_fail(h, e, "copy of the neighbour keys", __FILE__, __LINE__);
+  }
+  if (src.reduce && src.reduce(src.ctx, nullptr, &hb[0], &hb[1]) != 0 && rc == PLDA_OK)
+    rc = fail(h, PLDA_E_INVAL, "eer: the caller's reduction failed");
+  if (rc != PLDA_OK) return rc;
   const unsigned k1 = prefix;                       // smallest key with g >= 0; Pb/Nb = counts below k1
-  unsigned hb[2];
-  PLDA_HIP(h, hipMemcpyAsync(hb, dbelow, 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  if (src.reduce && src.reduce(src.ctx, nullptr, &hb[0], &hb[1]) != 0)
-    return fail(h, PLDA_E_INVAL, "eer: the caller's reduction failed");
   // neighbours of k1 among the data keys
   const int b2 = (int)(k1 & 1023u);
   long long k0 = -1, k2 = -1;

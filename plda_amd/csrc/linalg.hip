@@ -1112,6 +1112,14 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   // T1 = chol(W)^-1.  (Any T1 with T1 W T1^T = I gives the same final transform up to row signs; this is
   // the Cholesky one, as in the reference's GetOutput.)
   PLDA_TRY(whiten_blocked(h, W, D, D, T1, D, scr, dflag));
+  {
+    // checked HERE: with a W that is not positive definite T1 is full of NaNs, and the eigensolver would
+    // run its 40 sweeps on garbage and report "did not converge" instead of the actual cause
+    int hflag = 0;
+    PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
+  }
   // tmp = T1 B ; G = tmp T1^T
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, T1, D, 1, B, D, 1, nullptr, 0.0, tmp, D));
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
@@ -1120,10 +1128,6 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   PLDA_TRY(sym_eig_f64(h, G, D, psi, warm ? tmp : Vr, nullptr, warm ? Vr : nullptr));
   if (warm) PLDA_HIP(h, hipMemcpyAsync(Vr, tmp, DD * 8, hipMemcpyDeviceToDevice, h->stream));
   h->simdiag_has_vr = true;
-  int hflag = 0;
-  PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
   // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = T^-1 = W T^T (from T W T^T = I)
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));
   if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, W, D, 1, T, 1, D, nullptr, 0.0, Tinv, D));

@@ -143,10 +143,12 @@ class LDA(object):
         for name in ("_xbar", "_scalings", "explained_variance_ratio_"):
             if hasattr(self, name):
                 rec[name.strip("_")] = getattr(self, name)
-        np.savez(path, **rec)
+        from .libplda import _npz_path
+        np.savez(_npz_path(path), **rec)
 
     def load(self, path):
-        z = np.load(path, allow_pickle=False)
+        from .libplda import _npz_path
+        z = np.load(_npz_path(path), allow_pickle=False)
         self.solver = str(z["solver"])
         self._classes = z["classes"]
         coef = np.ascontiguousarray(z["coef"], np.float64)

@@ -50,6 +50,18 @@ def _labels(y, n, allow_strings_msg=False):
     return np.ascontiguousarray(y)
 
 
+def _npz_path(path):
+    """np.savez appends '.npz' to a path without that suffix and np.load does not: normalise both ways,
+    so that save('model') / load('model') round-trip.  File objects pass through."""
+    if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__"):
+        import os
+        p = os.fspath(path)
+        if isinstance(p, bytes):
+            p = p.decode()
+        return p if p.endswith(".npz") else p + ".npz"
+    return path
+
+
 class MPlda(object):
     """GPU-resident PLDA model + z-norm statistics (MPlda struct, pldamodule.cpp:27-34)."""
 
@@ -140,12 +152,12 @@ class MPlda(object):
         """Model + z-norm statistics to .npz (the reference has no persistence)."""
         m = self.get_model()
         ids = np.array(sorted(self._meanz), dtype=np.int64)
-        np.savez(path, mean=m["mean"], transform=m["transform"], psi=m["psi"], zn_ids=ids,
+        np.savez(_npz_path(path), mean=m["mean"], transform=m["transform"], psi=m["psi"], zn_ids=ids,
                  zn_mean=np.array([self._meanz[i] for i in ids], dtype=np.float64),
                  zn_std=np.array([self._stdvz[i] for i in ids], dtype=np.float64))
 
     def load(self, path):
-        z = np.load(path)
+        z = np.load(_npz_path(path))
         self.set_model(z["mean"], z["transform"], z["psi"])
         self._meanz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_mean"])}
         self._stdvz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_std"])}
@@ -154,6 +166,10 @@ class MPlda(object):
         """Write the model as a Kaldi `Plda` file (plda_amd/kaldi_io.py: format restated, not pinned)."""
         from . import kaldi_io
         m = self.get_model()
+        if m["transform"].shape[0] != m["transform"].shape[1]:
+            # Kaldi's Plda::Read / TransformIvector assume a square transform (Dim() = mean.Dim() = psi.Dim())
+            raise ValueError("save_kaldi: a model truncated with targetdim (transform %d x %d) has no Kaldi Plda "
+                             "representation; use save()" % m["transform"].shape)
         kaldi_io.write_plda(path, m["mean"], m["transform"], m["psi"], binary)
 
     def load_kaldi(self, path):
@@ -239,7 +255,10 @@ class MPlda(object):
         for k in ids:
             if not isinstance(k, (int, np.integer)) or not isinstance(transformedvecs[k], tuple):
                 return None  # the reference bails out with NULL (:229-230)
-        models = np.ascontiguousarray(np.stack([np.asarray(transformedvecs[k][1], np.float64) for k in ids]))
+        models = self._check_dim(np.ascontiguousarray(np.stack([np.asarray(transformedvecs[k][1], np.float64) for k in ids])),
+                                 "norm: model vectors")
+        if d != self.dims()[1]:
+            raise ValueError("norm: cohort vectors have %d features, the model expects %d" % (d, self.dims()[1]))
         mean, std = np.zeros(len(ids)), np.zeros(len(ids))
         self._ck(self._lib.plda_znorm_stats(self._h, _ptr(rows), rows.shape[0], nb, d, _ptr(models), len(ids),
                                             _ptr(mean), _ptr(std)))
@@ -296,11 +315,20 @@ class MPlda(object):
             ids = np.array(list(side.keys()), dtype=np.int64)
             counts = np.array([int(side[k][0]) for k in side], np.int32)
             vecs = np.ascontiguousarray(np.stack([np.asarray(side[k][1], np.float64) for k in side]))
-            return ids, counts, vecs
+            return ids, counts, self._check_dim(vecs)
         counts, vecs = side[0], np.ascontiguousarray(side[1], np.float64)
         counts = np.ascontiguousarray(np.broadcast_to(np.asarray(counts), (vecs.shape[0],)), np.int32)
         ids = np.asarray(side[2], np.int64) if len(side) > 2 else None
-        return ids, counts, vecs
+        return ids, counts, self._check_dim(vecs)
+
+    def _check_dim(self, vecs, what="vectors"):
+        """The C side reads rows of exactly the model's current dimension: vectors transformed before a
+        later truncate() / transform(targetdim=...) / load() / refit would be re-strided silently."""
+        dout = self._dout_cached()
+        if vecs.ndim != 2 or vecs.shape[1] != dout:
+            raise ValueError("%s must be [rows, %d] (the model's current dimension), got %s"
+                             % (what, dout, tuple(vecs.shape)))
+        return vecs
 
     def _zn_arrays(self, ids, znorm):
         if not znorm or ids is None or not self._meanz:
