@@ -114,6 +114,11 @@ int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Di
                           const uint64_t *labels, uint64_t *out_labels,
                           int64_t *out_counts, double *out_vecs /*[Ku*Dout]*/,
                           int64_t *Ku);
+/* the same on HBM-resident rows and labels; outputs (device): out_labels[Ku] u64, out_counts[Ku] int32,
+ * out_vecs[Ku, Dout].  Grouping is a device radix sort over as many 8-bit digits as the largest label has. */
+int plda_transform_groups_dev(plda_handle *h, const double *dX, int64_t N, int32_t Din,
+                              const uint64_t *dlabels, uint64_t *dout_labels, int32_t *dout_counts,
+                              double *dout_vecs, int64_t *Ku);
 /* batched Plda::TransformIvector on R already-averaged rows; num_examples[R]
  * (int32) or, if NULL, `n_uniform` for every row. */
 int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t Din,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "plda_truncate": (C.c_int, [_vp, _i32]),
     "plda_smooth": (C.c_int, [_vp, _f64]),
     "plda_transform_groups": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "plda_transform_groups_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "plda_transform_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "plda_transform_rows_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "plda_score_pairs": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -48,7 +48,7 @@ int model_to_device(plda_handle *h) {
 // implemented in score.hip / fit.hip
 int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
                         const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
-                        float *dout, int64_t ld);
+                        float *dout, int64_t ld, bool reuse_packed_B = false);
 int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,
                        const int64_t *de, const int64_t *dt, int64_t P, const double *dzmean,
                        const double *dzstd, double *dout);
@@ -57,6 +57,10 @@ int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_e
 int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
                        int64_t Ku, double *dmeans, int32_t *dcounts32);
 int compute_offset_device(plda_handle *h);
+int group_by_label_device(plda_handle *h, const uint64_t *dlabels, int64_t N, uint32_t **perm_out, int **offsets_out,
+                          uint64_t **uniq_out, int64_t *G_out);
+int group_centroids_device(plda_handle *h, const double *dX, int64_t N, int D, const uint32_t *perm, const int *offsets,
+                           int64_t G, double *dmeans, int32_t *dcounts32);
 int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
                       const int64_t *dtspk, double *out,
                       int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *) = nullptr, void *ctx = nullptr);
@@ -437,6 +441,44 @@ int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t D
   });
 }
 
+// grouping, per-label means and TransformIvector on device-resident rows; results stay on the device
+// (out arrays sized by the caller's capacity *Ku; PLDA_E_CAPACITY reports the needed size in *Ku)
+static int transform_groups_device(plda_handle *h, const double *dX, int64_t N, int32_t Din, const uint64_t *dlabels,
+                                   uint64_t *dout_labels, int32_t *dcounts32, double *dout_vecs, int64_t *Ku,
+                                   Tmp &dM) {
+  uint32_t *perm = nullptr;
+  int *offsets = nullptr;
+  uint64_t *uniq = nullptr;
+  int64_t G = 0;
+  // label compaction on the device (the reference does it with std::map, pldamodule.cpp:118,147-156)
+  PLDA_TRY(group_by_label_device(h, dlabels, N, &perm, &offsets, &uniq, &G));
+  if (G > *Ku) { *Ku = G; return fail(h, PLDA_E_CAPACITY, "transform_groups: %lld groups > capacity", (long long)G); }
+  PLDA_HIP(h, dM.alloc((size_t)G * Din * 8));
+  PLDA_TRY(group_centroids_device(h, dX, N, Din, perm, offsets, G, dM.as<double>(), dcounts32));
+  PLDA_TRY(transform_rows_device(h, dM.as<double>(), G, Din, dcounts32, 0, dout_vecs));
+  PLDA_HIP(h, hipMemcpyAsync(dout_labels, uniq, (size_t)G * 8, hipMemcpyDeviceToDevice, h->stream));
+  *Ku = G;
+  return PLDA_OK;
+}
+
+int plda_transform_groups_dev(plda_handle *h, const double *dX, int64_t N, int32_t Din, const uint64_t *dlabels,
+                              uint64_t *dout_labels, int32_t *dout_counts, double *dout_vecs, int64_t *Ku) {
+  return guarded(h, "plda_transform_groups_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
+    if (!Ku) return fail(h, PLDA_E_INVAL, "transform_groups: Ku is NULL");
+    if (N <= 0) { *Ku = 0; return PLDA_OK; }
+    if (!dX || !dlabels || !dout_labels || !dout_counts || !dout_vecs) return fail(h, PLDA_E_INVAL, "transform_groups: bad argument");
+    if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
+    PLDA_TRY(set_device(h));
+    Tmp dM;
+    PLDA_TRY(transform_groups_device(h, dX, N, Din, dlabels, dout_labels, dout_counts, dout_vecs, Ku, dM));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));   // dM is released on return
+    return PLDA_OK;
+  });
+}
+
 int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Din, const uint64_t *labels,
                           uint64_t *out_labels, int64_t *out_counts, double *out_vecs, int64_t *Ku) {
   return guarded(h, "plda_transform_groups", [&]() -> int {
@@ -448,28 +490,25 @@ int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Di
     if (!X || !labels || !out_labels || !out_counts || !out_vecs) return fail(h, PLDA_E_INVAL, "transform_groups: bad argument");
     if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
     PLDA_TRY(set_device(h));
-    // label compaction (index bookkeeping; the reference does it with std::map, pldamodule.cpp:118,147-156)
-    std::vector<uint64_t> uniq(labels, labels + N);
-    std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    const int64_t G = (int64_t)uniq.size();
-    if (G > *Ku) { *Ku = G; return fail(h, PLDA_E_CAPACITY, "transform_groups: %lld groups > capacity", (long long)G); }
-    std::vector<uint64_t> dense((size_t)N);
-    for (int64_t r = 0; r < N; ++r)
-      dense[r] = (uint64_t)(std::lower_bound(uniq.begin(), uniq.end(), labels[r]) - uniq.begin());
-    Tmp dX, dL, dM, dC, dO;
+    const int64_t cap = *Ku;
+    if (cap <= 0) return fail(h, PLDA_E_CAPACITY, "transform_groups: capacity must be > 0");
+    Tmp dX, dL, dM, dC, dO, dU;
     PLDA_TRY(upload(h, dX, X, (size_t)N * Din * 8));
-    PLDA_TRY(upload(h, dL, dense.data(), (size_t)N * 8));
-    PLDA_HIP(h, dM.alloc((size_t)G * Din * 8));
-    PLDA_HIP(h, dC.alloc((size_t)G * 4));
-    PLDA_HIP(h, dO.alloc((size_t)G * h->Dout * 8));
-    PLDA_TRY(group_means_device(h, dX.as<double>(), N, Din, dL.as<uint64_t>(), G, dM.as<double>(), dC.as<int32_t>()));
-    PLDA_TRY(transform_rows_device(h, dM.as<double>(), G, Din, dC.as<int32_t>(), 0, dO.as<double>()));
+    PLDA_TRY(upload(h, dL, labels, (size_t)N * 8));
+    const int64_t gmax = std::min(cap, N);
+    PLDA_HIP(h, dC.alloc((size_t)gmax * 4));
+    PLDA_HIP(h, dO.alloc((size_t)gmax * h->Dout * 8));
+    PLDA_HIP(h, dU.alloc((size_t)gmax * 8));
+    int64_t G = gmax;
+    const int rc = transform_groups_device(h, dX.as<double>(), N, Din, dL.as<uint64_t>(), dU.as<uint64_t>(),
+                                           dC.as<int32_t>(), dO.as<double>(), &G, dM);
+    if (rc != PLDA_OK) { if (rc == PLDA_E_CAPACITY) *Ku = G; return rc; }
     std::vector<int32_t> c32((size_t)G);
     PLDA_HIP(h, hipMemcpyAsync(c32.data(), dC.p, (size_t)G * 4, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(out_labels, dU.p, (size_t)G * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipMemcpyAsync(out_vecs, dO.p, (size_t)G * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    for (int64_t g = 0; g < G; ++g) { out_labels[g] = uniq[g]; out_counts[g] = c32[g]; }
+    for (int64_t g = 0; g < G; ++g) out_counts[g] = c32[g];
     *Ku = G;
     return PLDA_OK;
   });
@@ -517,7 +556,8 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
       }
       PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
                                    dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
-                                   (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt));
+                                   (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt,
+                                   /*reuse_packed_B=*/r0 > 0));   // the test side is packed once, not per slab
       PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
                                    (size_t)m, hipMemcpyDeviceToHost, h->stream));
       PLDA_HIP(h, hipStreamSynchronize(h->stream));

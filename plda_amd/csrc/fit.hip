@@ -632,6 +632,108 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
 // Mplda_transform grouping (pldamodule.cpp:139-168): labels are arbitrary u64 here, so
 // the host compacts them (sorted unique) and the device reuses K1a/K1.
 // ------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------
+// Grouping by ARBITRARY uint64 labels (Mplda_transform, pldamodule.cpp:139-156: a std::map keyed by
+// label value): the same LSD radix sort over as many 8-bit digits as the largest label has, then
+// boundaries by adjacent difference.  Leaves, on the device: perm (row ids grouped by label,
+// ascending row within a label -- the order the reference accumulates in), offsets[G+1], the
+// distinct labels in ascending order (std::map iteration order, :164) and returns G.
+// ------------------------------------------------------------------------------------
+__global__ void labels_split_kernel(const uint64_t *__restrict__ labels, int64_t N, uint32_t *__restrict__ keys,
+                                    uint32_t *__restrict__ vals, unsigned long long *__restrict__ maxlab) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long l = 0;
+  if (r < N) { l = labels[r]; keys[r] = (uint32_t)l; vals[r] = (uint32_t)r; }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(l, o); l = y > l ? y : l; }
+  if ((threadIdx.x & 63) == 0 && l) atomicMax(maxlab, l);
+}
+
+__global__ void labels_hi_kernel(const uint64_t *__restrict__ labels, const uint32_t *__restrict__ vals, int64_t N,
+                                 uint32_t *__restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) keys[i] = (uint32_t)(labels[vals[i]] >> 32);
+}
+
+__global__ void group_flag_kernel(const uint64_t *__restrict__ labels, const uint32_t *__restrict__ perm, int64_t N,
+                                  int *__restrict__ flag /*[N+1]*/) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) flag[i] = (i == 0 || labels[perm[i]] != labels[perm[i - 1]]) ? 1 : 0;
+  if (i == N) flag[N] = 0;
+}
+
+// pos = exclusive scan of the boundary flags: group id of sorted position i = pos[i + 1] - 1
+__global__ void group_emit_kernel(const uint64_t *__restrict__ labels, const uint32_t *__restrict__ perm,
+                                  const int *__restrict__ pos, int64_t N, uint64_t *__restrict__ uniq,
+                                  int *__restrict__ offsets) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N && pos[i + 1] != pos[i]) { uniq[pos[i]] = labels[perm[i]]; offsets[pos[i]] = (int)i; }
+  if (i == N) offsets[pos[N]] = (int)N;
+}
+
+int group_by_label_device(plda_handle *h, const uint64_t *dlabels, int64_t N, uint32_t **perm_out, int **offsets_out,
+                          uint64_t **uniq_out, int64_t *G_out) {
+  if (N >= (1ll << 31)) return fail(h, PLDA_E_INVAL, "transform: N too large");
+  const int nblocks = (int)ceil_div(N, RS_CHUNK);
+  PLDA_HIP(h, h->w[0].reserve((size_t)N * 4 * 4));                  // keys a/b, vals a/b
+  PLDA_HIP(h, h->w[2].reserve((size_t)256 * nblocks * 4 + 16));     // digit histograms (+ max label)
+  PLDA_HIP(h, h->w[4].reserve((size_t)(N + 2) * 4));                // boundary flags -> positions
+  uint32_t *ka = h->w[0].as<uint32_t>(), *va = ka + N, *kb = va + N, *vb = kb + N;
+  int *hist = h->w[2].as<int>();
+  unsigned long long *dmax = reinterpret_cast<unsigned long long *>(hist + (size_t)256 * nblocks + (((size_t)256 * nblocks) & 1));
+  int *pos = h->w[4].as<int>();
+  PLDA_HIP(h, hipMemsetAsync(dmax, 0, 8, h->stream));
+  labels_split_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, h->stream>>>(dlabels, N, ka, va, dmax);
+  PLDA_LAUNCH_CHECK(h);
+  unsigned long long hmax = 0;
+  PLDA_HIP(h, hipMemcpyAsync(&hmax, dmax, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  int bits = 1;
+  while (bits < 64 && (hmax >> bits)) bits++;
+  auto passes = [&](int nbits) -> int {
+    for (int shift = 0; shift < nbits; shift += 8) {
+      rs_hist_kernel<<<nblocks, RS_THREADS, 0, h->stream>>>(ka, N, shift, nblocks, hist);
+      scan_kernel<<<1, 1024, 0, h->stream>>>(hist, (int64_t)256 * nblocks);
+      rs_scatter_kernel<<<nblocks, RS_THREADS, 0, h->stream>>>(ka, va, kb, vb, N, shift, nblocks, hist);
+      PLDA_LAUNCH_CHECK(h);
+      std::swap(ka, kb);
+      std::swap(va, vb);
+    }
+    return PLDA_OK;
+  };
+  PLDA_TRY(passes(std::min(bits, 32)));
+  if (bits > 32) {
+    labels_hi_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, h->stream>>>(dlabels, va, N, ka);
+    PLDA_LAUNCH_CHECK(h);
+    PLDA_TRY(passes(bits - 32));
+  }
+  group_flag_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, h->stream>>>(dlabels, va, N, pos);
+  scan_kernel<<<1, 1024, 0, h->stream>>>(pos, N + 1);
+  PLDA_LAUNCH_CHECK(h);
+  int hG = 0;
+  PLDA_HIP(h, hipMemcpyAsync(&hG, pos + N, 4, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const int64_t G = hG;
+  PLDA_HIP(h, h->w[1].reserve((size_t)(G + 2) * 4 + 64));
+  PLDA_HIP(h, h->w[5].reserve((size_t)G * 8));
+  int *offsets = h->w[1].as<int>();
+  uint64_t *uniq = h->w[5].as<uint64_t>();
+  group_emit_kernel<<<(unsigned)ceil_div(N + 1, 256), 256, 0, h->stream>>>(dlabels, va, pos, N, uniq, offsets);
+  PLDA_LAUNCH_CHECK(h);
+  *perm_out = va; *offsets_out = offsets; *uniq_out = uniq; *G_out = G;
+  return PLDA_OK;
+}
+
+// per-label means of already grouped rows (pldamodule.cpp:147-168)
+int group_centroids_device(plda_handle *h, const double *dX, int64_t N, int D, const uint32_t *perm, const int *offsets,
+                           int64_t G, double *dmeans, int32_t *dcounts32) {
+  PLDA_HIP(h, h->w[3].reserve((size_t)N * 8));
+  centroid_kernel<<<(unsigned)G, 256, 0, h->stream>>>(dX, D, perm, offsets, dmeans, h->w[3].as<double>());
+  PLDA_LAUNCH_CHECK(h);
+  counts_to_i32_kernel<<<(unsigned)ceil_div(G, 256), 256, 0, h->stream>>>(offsets, G, dcounts32);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
                        int64_t Ku, double *dmeans, int32_t *dcounts32) {
   uint32_t *perm = nullptr;

@@ -1023,9 +1023,11 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   return PLDA_OK;
 }
 
+// reuse_packed_B: the test side (dV, Nt, enrol-count kind) is the one the previous call on this handle
+// packed -- the host entry point scores one test set against successive row slabs
 int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
                         const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
-                        float *dout, int64_t ld) {
+                        float *dout, int64_t ld, bool reuse_packed_B) {
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
   if (M <= 0 || Nt <= 0) return PLDA_OK;
   if (!dU || !dV || !dout || ld < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
@@ -1046,7 +1048,7 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
       TrialOperands op;
       PLDA_TRY(prepare_operands(h, dU + r0 * D, dn ? dn + r0 : nullptr, n_uniform, m, dV + c0 * D, nt,
                                 zn ? dzmean + r0 : nullptr, zn ? dzstd + r0 : nullptr, op,
-                                /*doA=*/cbk == 0, /*doB=*/ncb > 1 || rb == 0));
+                                /*doA=*/cbk == 0, /*doB=*/ncb > 1 || (rb == 0 && !reuse_packed_B)));
       float *o = dout + r0 * ld + c0;
       PLDA_TRY(launch_gemm<0>(h, op, m, nt, o, ld, nullptr, nullptr, nullptr));
     }
