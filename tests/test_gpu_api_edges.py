@@ -200,3 +200,51 @@ def test_one_handle_from_several_threads():
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_absurd_size_returns_an_error_code():
+    """Nothing aborts and nothing throws across the ABI: a request no machine can hold comes back as a status
+    code with a message (the reference would die in a Kaldi assertion or std::bad_alloc, pldamodule.cpp has no
+    try/catch).  Every entry point body runs inside api.hip's `guarded`."""
+    import ctypes as C
+    from plda_amd import MPlda, _native as N
+    eng = MPlda(0)
+    d = 8
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    eng.set_model(rng.random(d), q, np.sort(rng.random(d))[::-1].copy())
+    lib = N.load()
+    x = np.zeros((4, d)); y = np.zeros(4, np.uint64)
+    cap = C.c_int64(4)
+    ol, oc, ov = np.zeros(4, np.uint64), np.zeros(4, np.int64), np.zeros((4, d))
+    huge = 1 << 44
+    rc = lib.plda_transform_groups(eng._h, x.ctypes.data, huge, d, y.ctypes.data, ol.ctypes.data, oc.ctypes.data,
+                                   ov.ctypes.data, C.byref(cap))
+    assert rc != N.PLDA_OK and N.last_error(eng._h)
+    out = np.zeros(4, np.float32)
+    rc = lib.plda_score_matrix(eng._h, x.ctypes.data, None, 1, huge, x.ctypes.data, huge, None, None, out.ctypes.data, huge)
+    assert rc != N.PLDA_OK
+    # the handle is still usable
+    got = eng.transform(rng.random((6, d)), np.array([5, 5, 2**40 + 3, 7, 2**40 + 3, 5], np.uint64))
+    assert list(got.keys()) == [5, 7, 2**40 + 3] and [got[k][0] for k in got] == [3, 1, 2]
+
+
+def test_host_score_matrix_row_slabs_pack_the_test_side_once(oracle):
+    """plda_score_matrix stages > 1 GiB of scores in row slabs; the test side is packed for the first slab
+    only (reuse_packed_B) -- every slab must still see it."""
+    from plda_amd import MPlda
+    from oracle import plda_oracle_np as onp
+    eng = MPlda(0)
+    d = 24
+    rng = np.random.default_rng(1)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    psi = np.sort(rng.random(d) * 3 + 0.1)[::-1].copy()
+    eng.set_model(rng.random(d), q, psi)
+    m, nt = 3000, 150000                     # 1.8 GB of fp32 scores -> slabs of 1664 rows
+    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
+    S = eng.score_matrix((2, U), (1, V))
+    rows = np.array([0, 1, 1663, 1664, 1665, 2999]); cols = rng.integers(0, nt, 3000)
+    ref = onp.llr_matrix(psi, U[rows], 2, V[cols])
+    got = S[np.ix_(rows, cols)].astype(np.float64)
+    tol = 1e-4 * np.maximum(np.abs(ref), np.abs(ref).mean())
+    assert (np.abs(got - ref) <= tol).all()

@@ -129,10 +129,10 @@ def test_pldatest_shapes(oracle):
     Z_ref = oracle.score_block(ref["psi"], rv, rc, rtv, zm, zs)
     Z = p.score_matrix(transformed, transformedtest)
     assert np.isfinite(Z).all()
-    # z-scores divide by a std of ~2e-4: compare with the tolerance scaled accordingly
-    assert (np.abs(Z - Z_ref) <= 2e-3 * np.maximum(np.abs(Z_ref), np.abs(Z_ref).mean())).all(), np.abs(Z - Z_ref).max()
+    # z-scores divide by a cohort std of ~2e-4; north_star's 1e-4 relative holds all the same
+    assert (np.abs(Z - Z_ref) <= score_tol(Z_ref)).all(), (np.abs(Z - Z_ref) / score_tol(Z_ref)).max()
     z00 = p.score(0, transformed[0], transformedtest[0])
-    assert abs(z00 - Z_ref[0, 0]) <= 2e-3 * max(abs(Z_ref[0, 0]), np.abs(Z_ref).mean())
+    assert abs(z00 - Z_ref[0, 0]) <= 1e-4 * max(abs(Z_ref[0, 0]), np.abs(Z_ref).mean())
 
 
 def test_pldatest_large_and_odd_shapes(oracle):
