@@ -28,6 +28,7 @@ int fail(plda_handle *h, int code, const char *fmt, ...) {
 }
 
 int hip_fail(plda_handle *h, hipError_t e, const char *what, const char *file, int line) {
+  (void)hipGetLastError();   // a failed call leaves its code behind: the next launch check would report it again
   return fail(h, PLDA_E_HIP, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
 }
 
