@@ -234,6 +234,47 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
                                 const int64_t *denrol_spk, const int64_t *dtest_spk,
                                 plda_eer_reduce_fn reduce, void *ctx, double *out);
 
+/* ---- several GPUs of one node: one process per GPU, one handle per process, RCCL over
+ * xGMI inside the library.  The reference has no counterpart (one process, one thread; its native object
+ * libplda.MPlda, pldamodule.cpp:280-295, is the only thing callers bind, so the sharded path lives behind the same
+ * object).  Rank 0 calls plda_comm_unique_id and distributes the 128 bytes by any means (MPI, a file,
+ * torch.distributed's store); every rank then calls plda_comm_init (collective).
+ *
+ *   plda_score_matrix_sharded_dev   every rank passes the SAME replicated inputs (all M enrol rows, all Nt tests,
+ *       a replicated model).  Enrol rows are dealt out block-cyclically -- block b of `block_rows` rows (a multiple
+ *       of 256; <= 0: 2048) belongs to rank b mod R -- and each rank writes its blocks straight into their
+ *       final rows of the full matrix dout[M, ld_out].  gather == 0: that is all (scores stay sharded: what
+ *       thresholding, counting, EER want; no collective).  gather != 0: every R consecutive blocks are
+ *       assembled on every rank by one IN-PLACE all-gather on a side stream while the next blocks are being
+ *       scored (no staging copy; ragged tail: a group of broadcasts); the handle's stream is ordered
+ *       behind the last one.
+ *   plda_znorm_stats_sharded_dev    MPlda_norm (pldamodule.cpp:196-256) with the M models split contiguously
+ *       over the ranks (every rank scans the whole cohort); full mean / std arrays on every rank.
+ *   plda_fit_sharded_dev            MPlda_fit with the statistics pass (pldamodule.cpp:76-100) over THIS rank's
+ *       speakers (local dense labels 0..K-1; a speaker's rows must all be on one rank); the D x D offset
+ *       scatter is all-reduced, centroids and counts are all-gathered in rank order, and EM + GetOutput
+ *       (:102-106) run as replicas on every rank from identical inputs.
+ *   plda_eer_matrix_comm_dev        plda_eer_matrix_sharded_dev with the library's own reduction.
+ * Without plda_comm_init all of them run as a single rank. ---- */
+int plda_comm_unique_id(void *out, int64_t cap_bytes /* >= 128 */);
+int plda_comm_init(plda_handle *h, int32_t nranks, int32_t rank, const void *unique_id);
+int plda_comm_destroy(plda_handle *h);
+int plda_comm_info(plda_handle *h, int32_t *nranks, int32_t *rank);
+/* test hook: act as rank `rank` of `nranks` WITHOUT a communicator (no collective runs, gather is ignored):
+ * lets one GPU play every rank in turn and check that the shards tile the whole problem */
+int plda_comm_emulate(plda_handle *h, int32_t nranks, int32_t rank);
+int plda_score_matrix_sharded_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform,
+                                  int64_t M, const double *dV, int64_t Nt, const double *dzmean,
+                                  const double *dzstd, float *dout, int64_t ld_out, int64_t block_rows,
+                                  int32_t gather);
+int plda_znorm_stats_sharded_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples,
+                                 int32_t Din, const double *dmodels, int64_t M, double *dout_mean,
+                                 double *dout_std);
+int plda_fit_sharded_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels,
+                         int64_t K, int32_t iters);
+int plda_eer_matrix_comm_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                             const int64_t *denrol_spk, const int64_t *dtest_spk, double *out);
+
 /* ---- LDA: replaces the reference's second model, the pure-Python
  * class LDA of python/liblda/lda.py (used by scoring/scoreLDA.py:175,224,241), on the same
  * handle.  All fp64.  solver: 0 = 'svd' (lda.py:171-209), 1 = 'eigen' (:134-169),

@@ -71,6 +71,15 @@ SIGNATURES = {
     "plda_eer_matrix_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "plda_eer_lists": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "plda_eer_matrix_sharded_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "plda_comm_unique_id": (C.c_int, [_vp, _i64]),
+    "plda_comm_init": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "plda_comm_destroy": (C.c_int, [_vp]),
+    "plda_comm_emulate": (C.c_int, [_vp, _i32, _i32]),
+    "plda_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "plda_score_matrix_sharded_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32]),
+    "plda_znorm_stats_sharded_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "plda_fit_sharded_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32]),
+    "plda_eer_matrix_comm_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "plda_znorm_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "plda_znorm_stats_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
 }

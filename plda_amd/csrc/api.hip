@@ -66,14 +66,17 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
                       const int64_t *dtspk, double *out,
                       int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *) = nullptr, void *ctx = nullptr);
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out);
-
-// simple RAII device temp for host-pointer entry points
-struct Tmp {
-  void *p = nullptr;
-  ~Tmp() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-  template <typename T> T *as() { return reinterpret_cast<T *>(p); }
-};
+// comm.hip
+int comm_init(plda_handle *h, int nranks, int rank, const void *uid);
+int comm_destroy(plda_handle *h);
+int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
+                                const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
+                                int64_t ld, int64_t block_rows, int gather);
+int znorm_stats_sharded_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
+                               const double *dmodels, int64_t M, double *dmean, double *dstd);
+int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K, int iters);
+int eer_matrix_comm_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
+                           const int64_t *dtspk, double *out);
 
 static int upload(plda_handle *h, Tmp &t, const void *src, size_t bytes) {
   PLDA_HIP(h, t.alloc(bytes));
@@ -159,6 +162,7 @@ int plda_destroy(plda_handle *h) {
     if (!h) return PLDA_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)comm_destroy(h);
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
@@ -951,6 +955,90 @@ int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const 
     PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, obytes, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
     return PLDA_OK;
+  });
+}
+
+// ---------------------------------------------------------------- multi-GPU (comm.hip)
+int plda_comm_init(plda_handle *h, int32_t nranks, int32_t rank, const void *unique_id) {
+  return guarded(h, "plda_comm_init", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return comm_init(h, nranks, rank, unique_id);
+  });
+}
+
+int plda_comm_destroy(plda_handle *h) {
+  return guarded(h, "plda_comm_destroy", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return comm_destroy(h);
+  });
+}
+
+int plda_comm_emulate(plda_handle *h, int32_t nranks, int32_t rank) {
+  return guarded(h, "plda_comm_emulate", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (h->comm) return fail(h, PLDA_E_INVAL, "comm_emulate: this handle has a real communicator");
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(h, PLDA_E_INVAL, "comm_emulate: bad argument");
+    h->comm_nranks = nranks; h->comm_rank = rank;
+    return PLDA_OK;
+  });
+}
+
+int plda_comm_info(plda_handle *h, int32_t *nranks, int32_t *rank) {
+  return guarded(h, "plda_comm_info", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (nranks) *nranks = h->comm_nranks;
+    if (rank) *rank = h->comm_rank;
+    return PLDA_OK;
+  });
+}
+
+int plda_score_matrix_sharded_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform, int64_t M,
+                                  const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
+                                  int64_t ld_out, int64_t block_rows, int32_t gather) {
+  return guarded(h, "plda_score_matrix_sharded_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!dn_enrol && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: n_uniform must be > 0 when n_enrol is NULL");
+    PLDA_TRY(set_device(h));
+    return score_matrix_sharded_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out, block_rows, gather);
+  });
+}
+
+int plda_znorm_stats_sharded_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples, int32_t Din,
+                                 const double *dmodels, int64_t M, double *dout_mean, double *dout_std) {
+  return guarded(h, "plda_znorm_stats_sharded_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
+    if (!dbkg || !dmodels || !dout_mean || !dout_std || Nb <= 0 || M <= 0) return fail(h, PLDA_E_INVAL, "norm: bad argument");
+    PLDA_TRY(set_device(h));
+    return znorm_stats_sharded_device(h, dbkg, Nb, num_examples, Din, dmodels, M, dout_mean, dout_std);
+  });
+}
+
+int plda_fit_sharded_dev(plda_handle *h, const double *dX, int64_t N, int32_t D, const uint64_t *dlabels, int64_t K,
+                         int32_t iters) {
+  return guarded(h, "plda_fit_sharded_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return fit_sharded_device(h, dX, N, D, dlabels, K, iters);
+  });
+}
+
+int plda_eer_matrix_comm_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                             const int64_t *denrol_spk, const int64_t *dtest_spk, double *out) {
+  return guarded(h, "plda_eer_matrix_comm_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return eer_matrix_comm_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
   });
 }
 

@@ -29,6 +29,14 @@ struct DevBuf {
   template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// RAII device temporary of the host-pointer entry points
+struct Tmp {
+  void *p = nullptr;
+  ~Tmp() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
 }  // namespace plda
 
 struct plda_handle {
@@ -89,6 +97,12 @@ struct plda_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
   double prof_flop = 0.0;
+
+  // ---- multi-GPU (comm.hip): RCCL communicator, side stream for the gather, ordering events ----
+  void *comm = nullptr;          // ncclComm_t
+  int comm_nranks = 1, comm_rank = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];

@@ -423,6 +423,56 @@ class MPlda(object):
             C.c_void_p(int(dV)), int(nt), C.c_void_p(int(dzmean)) if dzmean else None,
             C.c_void_p(int(dzstd)) if dzstd else None, C.c_void_p(int(dout)), int(ld)))
 
+    # ------------------------------------------------- several GPUs (csrc/comm.hip)
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes for rank 0 to hand to every rank's comm_init (ncclGetUniqueId)."""
+        buf = C.create_string_buffer(128)
+        rc = N.load().plda_comm_unique_id(buf, 128)
+        if rc != N.PLDA_OK:
+            raise N.PldaError(rc, "plda_comm_unique_id failed")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        """Collective: RCCL communicator of this handle (one process per GPU)."""
+        uid = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self._lib.plda_comm_init(self._h, int(nranks), int(rank), uid))
+
+    def comm_destroy(self):
+        self._ck(self._lib.plda_comm_destroy(self._h))
+
+    def comm_emulate(self, nranks, rank):
+        self._ck(self._lib.plda_comm_emulate(self._h, int(nranks), int(rank)))
+
+    def comm_info(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self._lib.plda_comm_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def score_matrix_sharded_dev(self, dU, dn, n_uniform, m, dV, nt, dout, ld, block_rows=2048, gather=False,
+                                 dzmean=None, dzstd=None):
+        """Row-sharded trials matrix on replicated HBM-resident inputs: this rank's blocks (block b -> rank
+        b mod R) written in place into the full [M, ld] matrix; gather=True assembles it on every rank."""
+        self._ck(self._lib.plda_score_matrix_sharded_dev(
+            self._h, C.c_void_p(int(dU)), C.c_void_p(int(dn)) if dn else None, int(n_uniform), int(m),
+            C.c_void_p(int(dV)), int(nt), C.c_void_p(int(dzmean)) if dzmean else None,
+            C.c_void_p(int(dzstd)) if dzstd else None, C.c_void_p(int(dout)), int(ld), int(block_rows),
+            1 if gather else 0))
+
+    def znorm_stats_sharded_dev(self, dbkg, nb, num_examples, d, dmodels, m, dmean, dstd):
+        self._ck(self._lib.plda_znorm_stats_sharded_dev(self._h, C.c_void_p(int(dbkg)), int(nb), int(num_examples), int(d),
+                                                        C.c_void_p(int(dmodels)), int(m), C.c_void_p(int(dmean)),
+                                                        C.c_void_p(int(dstd))))
+
+    def fit_sharded_dev(self, dX, n, d, dlabels, k, iters=10):
+        """Fit with the statistics pass over THIS rank's speakers (local dense labels 0..k-1)."""
+        self._dout = None
+        rc = self._lib.plda_fit_sharded_dev(self._h, C.c_void_p(int(dX)), int(n), int(d), C.c_void_p(int(dlabels)),
+                                            int(k), int(iters))
+        if rc == N.PLDA_E_ONE_SPEAKER:
+            raise ValueError(_ERR_ONE_SPK)
+        self._ck(rc)
+
     def znorm_stats_dev(self, dbkg, nb, num_examples, d, dmodels, m, dmean, dstd):
         self._ck(self._lib.plda_znorm_stats_dev(self._h, C.c_void_p(int(dbkg)), int(nb), int(num_examples), int(d),
                                                 C.c_void_p(int(dmodels)), int(m), C.c_void_p(int(dmean)),

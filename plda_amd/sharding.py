@@ -18,6 +18,39 @@ import torch
 import torch.distributed as dist
 
 
+def init_comm(engine, group=None, device=None):
+    """Give `engine` (an MPlda) its RCCL communicator: rank 0 draws the unique id, torch.distributed
+    (any backend -- it only carries 128 bytes) hands it round, every rank calls plda_comm_init.  After
+    this the library's own sharded entry points (score_matrix_sharded_dev, fit_sharded_dev,
+    znorm_stats_sharded_dev, plda_eer_matrix_comm_dev) run over RCCL without torch in the data path."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 1, 0
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    uid = [engine.comm_unique_id() if rank == 0 else None]
+    if dist.get_backend(group) == "nccl":
+        t = torch.tensor(list(uid[0]) if rank == 0 else [0] * 128, dtype=torch.uint8,
+                         device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+    else:
+        dist.broadcast_object_list(uid, src=0, group=group)
+        raw = uid[0]
+    engine.comm_init(world, rank, raw)
+    return world, rank
+
+
+def block_cyclic_rows(m, world, rank, block_rows=2048):
+    """Row ranges [(start, stop), ...] of `rank` under plda_score_matrix_sharded_dev's partition: block b of
+    `block_rows` rows (rounded up to 256) belongs to rank b mod world."""
+    block = -(-int(block_rows) // 256) * 256
+    out = []
+    b = rank
+    while b * block < m:
+        out.append((b * block, min(m, (b + 1) * block)))
+        b += world
+    return out
+
+
 def shard_rows(m, world, rank):
     """Contiguous balanced partition of m rows: (start, stop) for `rank`."""
     base, extra = divmod(int(m), int(world))
