@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--speakers", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--targetdim", type=int, default=0, help="build extension: keep the top-psi dims (0 = all)")
-    ap.add_argument("--block-rows", type=int, default=2048, help="N>1: rows per block of the block-cyclic row partition")
+    ap.add_argument("--block-rows", type=int, default=4096, help="N>1: rows per block of the block-cyclic row partition")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the targetdim-150 extra measurement (profiling runs: every launch of the trials kernel "

@@ -242,7 +242,8 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
  *
  *   plda_score_matrix_sharded_dev   every rank passes the SAME replicated inputs (all M enrol rows, all Nt tests,
  *       a replicated model).  Enrol rows are dealt out block-cyclically -- block b of `block_rows` rows (a multiple
- *       of 256; <= 0: 2048) belongs to rank b mod R -- and each rank writes its blocks straight into their
+ *       of 256; <= 0: 4096) belongs to rank b mod R; the rows left over after the last full round of R blocks
+ *       are dealt out once more in R equal smaller blocks -- and each rank writes its blocks straight into their
  *       final rows of the full matrix dout[M, ld_out].  gather == 0: that is all (scores stay sharded: what
  *       thresholding, counting, EER want; no collective).  gather != 0: every R consecutive blocks are
  *       assembled on every rank by one IN-PLACE all-gather on a side stream while the next blocks are being

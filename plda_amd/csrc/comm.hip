@@ -101,18 +101,22 @@ int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t 
   if (M <= 0 || Nt <= 0) return PLDA_OK;
   if (!dU || !dV || !dout || ld < Nt) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: bad argument");
   const int R = h->comm_nranks, me = h->comm_rank;   // (without a communicator: 1 / 0, or plda_comm_emulate's)
-  if (block_rows <= 0) block_rows = 2048;
+  if (block_rows <= 0) block_rows = 4096;
   block_rows = round_up(block_rows, 256);
   const int D = h->Dout;
   const bool zn = dzmean && dzstd;
   const int64_t super = block_rows * R;                       // rows of one super-block
-  const int64_t nsuper = ceil_div(M, super);
+  const int64_t nfull = M / super;                            // full super-blocks; the remainder is dealt out
+  const int64_t rem = M - nfull * super;                      // again in (smaller) equal blocks, so that the
+  const int64_t tail_block = rem ? round_up(ceil_div(rem, R), 256) : 0;   // last rows do not all land on rank 0
+  const int64_t nsuper = nfull + (rem ? 1 : 0);
   const bool do_gather = gather && R > 1 && h->comm;
   bool packedB = false;
   for (int64_t s = 0; s < nsuper; ++s) {
     const int64_t s0 = s * super;
-    const int64_t r0 = s0 + (int64_t)me * block_rows;
-    const int64_t cnt = std::max<int64_t>(0, std::min(block_rows, M - r0));
+    const int64_t blk = s < nfull ? block_rows : tail_block;
+    const int64_t r0 = s0 + (int64_t)me * blk;
+    const int64_t cnt = std::max<int64_t>(0, std::min(blk, M - r0));
     if (cnt > 0) {
       PLDA_TRY(score_matrix_device(h, dU + r0 * D, dn ? dn + r0 : nullptr, n_uniform, cnt, dV, Nt, zn ? dzmean + r0 : nullptr,
                                    zn ? dzstd + r0 : nullptr, dout + r0 * ld, ld, packedB));
@@ -122,16 +126,16 @@ int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t 
     hipEvent_t ev = h->comm_ev[s & 3];
     PLDA_HIP(h, hipEventRecord(ev, h->stream));
     PLDA_HIP(h, hipStreamWaitEvent(h->comm_stream, ev, 0));
-    if (s0 + super <= M) {
+    if (s < nfull) {
       // full super-block: equal pieces, contiguous -> in-place all-gather
       PLDA_NCCL(h, ncclAllGather(dout + r0 * ld, dout + s0 * ld, (size_t)(block_rows * ld), ncclFloat, comm_of(h),
                                  h->comm_stream));
     } else {
       std::vector<int64_t> offs(R), counts(R);
       for (int q = 0; q < R; ++q) {
-        const int64_t q0 = s0 + (int64_t)q * block_rows;
+        const int64_t q0 = s0 + (int64_t)q * blk;
         offs[q] = q0 * ld;
-        counts[q] = std::max<int64_t>(0, std::min(block_rows, M - q0)) * ld;
+        counts[q] = std::max<int64_t>(0, std::min(blk, M - q0)) * ld;
       }
       PLDA_TRY(allgatherv_inplace(h, dout, offs, counts, 4, h->comm_stream));
     }

@@ -449,7 +449,7 @@ class MPlda(object):
         self._ck(self._lib.plda_comm_info(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def score_matrix_sharded_dev(self, dU, dn, n_uniform, m, dV, nt, dout, ld, block_rows=2048, gather=False,
+    def score_matrix_sharded_dev(self, dU, dn, n_uniform, m, dV, nt, dout, ld, block_rows=4096, gather=False,
                                  dzmean=None, dzstd=None):
         """Row-sharded trials matrix on replicated HBM-resident inputs: this rank's blocks (block b -> rank
         b mod R) written in place into the full [M, ld] matrix; gather=True assembles it on every rank."""

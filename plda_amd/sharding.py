@@ -39,15 +39,20 @@ def init_comm(engine, group=None, device=None):
     return world, rank
 
 
-def block_cyclic_rows(m, world, rank, block_rows=2048):
+def block_cyclic_rows(m, world, rank, block_rows=4096):
     """Row ranges [(start, stop), ...] of `rank` under plda_score_matrix_sharded_dev's partition: block b of
-    `block_rows` rows (rounded up to 256) belongs to rank b mod world."""
-    block = -(-int(block_rows) // 256) * 256
-    out = []
-    b = rank
-    while b * block < m:
-        out.append((b * block, min(m, (b + 1) * block)))
-        b += world
+    `block_rows` rows (rounded up to 256) belongs to rank b mod world; the rows left after the last full
+    round of `world` blocks are dealt out once more in `world` equal smaller blocks."""
+    block = -(-int(block_rows if block_rows > 0 else 4096) // 256) * 256
+    sup = block * world
+    nfull = m // sup
+    out = [(s * sup + rank * block, s * sup + (rank + 1) * block) for s in range(nfull)]
+    rem = m - nfull * sup
+    if rem:
+        tb = -(-(-(-rem // world)) // 256) * 256
+        a = nfull * sup + rank * tb
+        if a < m:
+            out.append((a, min(m, a + tb)))
     return out
 
 
