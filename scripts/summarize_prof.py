@@ -9,6 +9,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else "rXX"            # round tag of the written files
+shape = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [100000, 100000, 200]
 
 
 def find(pattern):
@@ -30,6 +32,27 @@ for f in find("*kernel_stats.csv"):
         print("  %-70s calls=%6s total_ms=%10.3f avg_us=%10.2f pct=%5s" % (
             short(r.get("Name", "")), r.get("Calls"), float(r.get("TotalDurationNs", 0)) / 1e6,
             float(r.get("AverageNs", 0)) / 1e3, r.get("Percentage")))
+
+# steady-state duration of the dominant kernel from the kernel trace: the first launch of a process pays
+# code load and clock ramp (34.0 vs 31.2 ms in round 1) and is left out of the average
+import json
+steady = {}
+for f in find("*kernel_trace.csv"):
+    if "pmc" in f:
+        continue
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+    print("== steady-state kernel durations (first launch of each kernel excluded):", os.path.relpath(f, out))
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(d for _, d in kv[1]))[:12]:
+        v.sort()
+        ds = [d for _, d in v]
+        ss = ds[1:] if len(ds) > 1 else ds
+        print("  %-70s launches=%5d first_ms=%9.4f steady_avg_ms=%9.4f min_ms=%9.4f" % (k, len(ds), ds[0], sum(ss) / len(ss), min(ds)))
+        if "trials_gemm" in k:
+            steady[k] = {"launches": len(ds), "first_ms": ds[0], "steady_avg_ms": sum(ss) / len(ss), "min_ms": min(ds)}
+if steady:
+    json.dump(steady, open(os.path.join(out, "%s_trials_gemm_durations.json" % tag), "w"), indent=1)
 
 for label, pat in (("FETCH_SIZE", "*fetch*counter_collection.csv"), ("WRITE_SIZE", "*write*counter_collection.csv")):
     for f in find(pat):
@@ -54,17 +77,17 @@ for label, pat in (("fetch", "*fetch*counter_collection.csv"), ("write", "*write
         hdr = rows[0]
         ki = hdr.index("Kernel_Name")
         keep = [hdr] + [r for r in rows[1:] if "trials_gemm" in r[ki]]
-        csv.writer(open(os.path.join(out, "pmc_%s_trials_gemm.csv" % label), "w")).writerows(keep)
+        csv.writer(open(os.path.join(out, "%s_pmc_%s_trials_gemm.csv" % (tag, label)), "w")).writerows(keep)
 
 
 # machine-readable HBM traffic of the dominant kernel, per launch (consumed by bench.py)
-import json
-traffic = {}
+traffic = {"shape": shape, "kernel": "trials_gemm_bt2_kernel", "round": tag}
 for label, pat in (("FETCH_SIZE", "*fetch*counter_collection.csv"), ("WRITE_SIZE", "*write*counter_collection.csv")):
     for f in find(pat):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
                 if r.get("Counter_Name") == label and "trials_gemm" in r.get("Kernel_Name", "")]
         if vals:
+            vals = vals[1:] if len(vals) > 1 else vals          # steady state
             traffic[label + "_raw_KiB_avg"] = sum(vals) / len(vals)
             traffic[label + "_launches"] = len(vals)
 if "FETCH_SIZE_raw_KiB_avg" in traffic and "WRITE_SIZE_raw_KiB_avg" in traffic:
@@ -73,4 +96,4 @@ if "FETCH_SIZE_raw_KiB_avg" in traffic and "WRITE_SIZE_raw_KiB_avg" in traffic:
     traffic["hbm_bytes_per_launch"] = traffic["fetch_bytes_corrected_x2"] + traffic["write_bytes"]
     traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
                        "(gfx950 reports 1/2 of a wide coalesced stream, MI355X_MICROARCH.md section HBM)")
-    json.dump(traffic, open(os.path.join(out, "traffic_trials_gemm.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(out, "%s_traffic_trials_gemm.json" % tag), "w"), indent=1)
