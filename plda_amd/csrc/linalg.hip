@@ -698,6 +698,7 @@ __global__ __launch_bounds__(256) void jacobi_block_kernel(double *__restrict__ 
   // bye (the partner block does not exist): the rows of bq are treated as missing and the workgroup still
   // runs the INTRA-block pairs of bp -- with a single block (D <= 4) that is the only place they are rotated
   if (bp * JB >= D) return;
+  if (rotations[2]) return;   // converged in an earlier sweep of this batch (jacobi_end_kernel)
   double *lA = rows, *lV = rows + 2 * JB * D;
   // global row of local row r (r < JB: block bp, else block bq); rows >= D do not exist
   auto grow = [&](int r) { return (r < JB ? bp * JB + r : bq * JB + (r - JB)); };
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(256) void jacobi_gram_kernel(double *__restrict__ A
   // bye (the partner block does not exist): the rows of bq are treated as missing and the workgroup still
   // runs the INTRA-block pairs of bp -- with a single block (D <= 4) that is the only place they are rotated
   if (bp * JB >= D) return;
+  if (rotations[2]) return;   // converged in an earlier sweep of this batch (jacobi_end_kernel)
   constexpr int NP = 2 * JB;  // 8 rows
   double *lA = rows, *lV = rows + NP * D;
   auto grow = [&](int r) { return (r < JB ? bp * JB + r : bq * JB + (r - JB)); };
@@ -933,6 +935,24 @@ __global__ __launch_bounds__(256) void jacobi_gram_kernel(double *__restrict__ A
   }
 }
 
+// Convergence is decided on the device: rot[0] rotations of the running sweep, rot[1] its largest rotated
+// gamma^2 / (alpha beta) (float bits), rot[2] != 0 once converged (= sweeps it took), rot[3] sweeps run.
+// A sweep (one graph replay) is begin -> rounds -> end; after convergence all of them return at once, so the
+// host enqueues sweeps in batches and looks at rot[2] once per batch instead of synchronising every sweep.
+__global__ void jacobi_begin_kernel(int *rot) {
+  if (rot[2]) return;
+  rot[0] = 0; rot[1] = 0;
+}
+__global__ void jacobi_end_kernel(int *rot, int use_relmax) {
+  if (rot[2]) return;
+  rot[3] += 1;
+  // Quadratic convergence: a sweep whose largest rotated off-diagonal was gamma^2/(alpha beta) <= 1e-18
+  // (|cos| <= 1e-9) leaves every pair far below the threshold tol ~ 1e-14, so the confirming sweep that
+  // would find nothing to rotate is skipped.  (Only the Gram kernel reports the maximum.)
+  const float relmax = __uint_as_float((unsigned)rot[1]);
+  if (rot[0] == 0 || (use_relmax && relmax > 0.f && relmax <= 1e-18f)) rot[2] = rot[3];
+}
+
 __global__ void set_identity_kernel(double *V, int D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < D * D) V[idx] = (idx / D == idx % D) ? 1.0 : 0.0;
@@ -987,7 +1007,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
                                     : E <= 8 ? reinterpret_cast<const void *>(&jacobi_block_kernel<8>)
                                              : reinterpret_cast<const void *>(&jacobi_block_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PLDA_HIP(h, hipMemsetAsync(drot, 0, 2 * sizeof(int), h->stream));
+    jacobi_begin_kernel<<<1, 1, 0, h->stream>>>(drot);
     if (gram) PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_gram_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int round = 0; round < nb_even - 1; ++round) {
@@ -1000,6 +1020,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
       else JR(16);
 #undef JR
     }
+    jacobi_end_kernel<<<1, 1, 0, h->stream>>>(drot, gram ? 1 : 0);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
   }
@@ -1016,7 +1037,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipGraph_t graph = nullptr;
     PLDA_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-    (void)hipMemsetAsync(drot, 0, 2 * sizeof(int), h->stream);
+    jacobi_begin_kernel<<<1, 1, 0, h->stream>>>(drot);
     for (int round = 0; round < nb_even - 1; ++round) {
 #define JR(EE) jacobi_block_kernel<EE><<<wgs, 256, lds, h->stream>>>(G, V, D, nb_even, round, tol, drot)
       if (gram) jacobi_gram_kernel<<<wgs, 256, lds, h->stream>>>(G, V, D, nb_even, round, tol, drot);
@@ -1027,6 +1048,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
       else JR(16);
 #undef JR
     }
+    jacobi_end_kernel<<<1, 1, 0, h->stream>>>(drot, gram ? 1 : 0);
     hipError_t ec = hipStreamEndCapture(h->stream, &graph);
     if (ec != hipSuccess) return hip_fail(h, ec, "hipStreamEndCapture(jacobi sweep)", __FILE__, __LINE__);
     ec = hipGraphInstantiate(&h->jac_exec, graph, nullptr, nullptr, 0);
@@ -1049,7 +1071,7 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
   double *V = h->w[14].as<double>();
   double *A = V + DD;
   double *lam = A + DD;
-  int *drot = reinterpret_cast<int *>(lam + D);
+  int *drot = reinterpret_cast<int *>(lam + D);   // 4 ints (jacobi_begin_kernel)
   if (warm) {
     PLDA_HIP(h, hipMemcpyAsync(V, warm, DD * 8, hipMemcpyDeviceToDevice, h->stream));
     PLDA_TRY(gemm_f64(h, D, D, D, 1.0, warm, D, 1, G, D, 1, nullptr, 0.0, A, D));
@@ -1059,24 +1081,22 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
   }
   PLDA_LAUNCH_CHECK(h);
   const double tol = 2.220446049250313e-16 * 4.0 * sqrt((double)D);
-  int sweeps = 0;
+  // sweeps are enqueued in batches and the device-side convergence flag is read once per batch (a cold
+  // start needs ~11 sweeps at D = 200, ~13 at D = 512; sweeps past convergence return at once)
   const int max_sweeps = 40;
-  for (; sweeps < max_sweeps && D > 1; ++sweeps) {
-    PLDA_TRY(jacobi_sweep_graph(h, A, V, D, tol, drot));
-    int hrot[2] = {0, 0};
-    PLDA_HIP(h, hipMemcpyAsync(hrot, drot, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  int sweeps = 0, hrot[4] = {0, 0, 0, 0};
+  PLDA_HIP(h, hipMemsetAsync(drot, 0, 4 * sizeof(int), h->stream));
+  for (int enq = 0; D > 1 && enq < max_sweeps && !hrot[2];) {
+    const int batch = std::min(max_sweeps - enq, enq == 0 ? (warm ? 3 : 9) : 2);
+    for (int b = 0; b < batch; ++b) PLDA_TRY(jacobi_sweep_graph(h, A, V, D, tol, drot));
+    enq += batch;
+    PLDA_HIP(h, hipMemcpyAsync(hrot, drot, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    if (hrot[0] == 0) break;
-    // Quadratic convergence: a sweep whose largest rotated off-diagonal was gamma^2/(alpha beta) <= 1e-18
-    // (|cos| <= 1e-9) leaves every pair far below the threshold tol ~ 1e-14, so the confirming sweep
-    // that would find nothing to rotate is skipped.  (Only the Gram kernel reports the maximum.)
-    float relmax;
-    std::memcpy(&relmax, &hrot[1], 4);
-    if (h->jacobi_variant != 1 && relmax > 0.f && relmax <= 1e-18f) break;
   }
-  if (sweeps >= max_sweeps) return fail(h, PLDA_E_NUMERIC, "sym_eig: Jacobi did not converge in %d sweeps", max_sweeps);
-  if (sweeps_out) *sweeps_out = sweeps + 1;
-  h->jac_total_sweeps += sweeps + 1;
+  if (D > 1 && !hrot[2]) return fail(h, PLDA_E_NUMERIC, "sym_eig: Jacobi did not converge in %d sweeps", max_sweeps);
+  sweeps = D > 1 ? hrot[2] : 0;
+  if (sweeps_out) *sweeps_out = sweeps;
+  h->jac_total_sweeps += sweeps;
   eig_values_kernel<<<(unsigned)ceil_div(D, 4), 256, 0, h->stream>>>(A, V, D, lam);
   eig_sort_kernel<<<D, 64, 0, h->stream>>>(lam, V, D, s, Vrows, !h->eig_keep_sign);
   PLDA_LAUNCH_CHECK(h);
