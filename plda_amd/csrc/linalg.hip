@@ -175,6 +175,196 @@ __global__ void splitk_reduce_kernel(const double *__restrict__ part, int splits
   *c = alpha * s + (beta != 0.0 ? beta * *c : 0.0);
 }
 
+// ------------------------------------------------------------------------------------
+// K2: symmetric rank-K update  S = alpha X^T diag(w) X (+ beta S)  -- the AddSamples scatter
+// (PldaStats::AddSamples reached at pldamodule.cpp:94-98; Kaldi's AddMat2 / ATLAS dsyrk) and the
+// scatter matrices of LDA.  X is [K, D] row-major: both GEMM operands are the SAME rows.
+//
+// The general kernel above treats it as a D x D x K product: at D = 200 it computes a 256 x 256 output
+// (1.64 x the algorithmic flops: 128-tiles), twice (no symmetry), reads X once per operand, and its
+// 250-way split-K writes 250 full-size partial slabs -- 0.35 of the fp64 MFMA peak at C2.  Here:
+//   * only the LOWER-triangular 128 x 128 super-tiles (I >= J) are launched;
+//   * inside a super-tile the 16 x 16 MFMA tiles that lie in the padding (>= D) or, on a diagonal
+//     super-tile, strictly above the diagonal are skipped, with a wave -> tile mapping that keeps the
+//     four waves balanced: diagonal super-tile: wave w owns tile rows {w, nvr-1-w} (r+1 tiles in row r);
+//     off-diagonal: wave w owns tile columns {2w, 2w+1} over all valid tile rows.  At D = 200 a row chunk
+//     costs 9 + 10 + 6 MFMA tile-steps per wave against 64 before; at D = 512 132 against 256;
+//   * a diagonal super-tile fetches its rows from memory once for both MFMA operands;
+//   * split-K writes only the valid tiles of a partial (2 KiB each), a second kernel sums the
+//     splits in fixed order and mirrors the triangle -- deterministic.
+// ------------------------------------------------------------------------------------
+template <bool DIAG>   // (two instantiations rather than one kernel with both tile mappings: that one spilled)
+__global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, int64_t kchunk,
+                                                            const double *__restrict__ X, int64_t ldx,
+                                                            const double *__restrict__ kw,
+                                                            double *__restrict__ part, int nP) {
+  constexpr int TB = 128, LD = TB + 16;
+  __shared__ double As[2][GK * LD];
+  __shared__ double Bs[2][GK * LD];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // blockIdx.x enumerates the diagonal super-tiles (DIAG) or the strictly-lower pairs (I > J) row by row;
+  // `slot` is the pair's index in the partial slabs: I (I + 1) / 2 + J
+  int I, J;
+  if (DIAG) { I = J = (int)blockIdx.x; }
+  else { I = 1; J = (int)blockIdx.x; while (J >= I) { J -= I; ++I; } }
+  const int slot = I * (I + 1) / 2 + J;
+  constexpr bool diag = DIAG;
+  const int64_t m0 = (int64_t)I * TB, n0 = (int64_t)J * TB;
+  const int nvr = min(8, (int)((D - m0 + 15) / 16)), nvc = min(8, (int)((D - n0 + 15) / 16));
+  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kend = min(K, kbeg + kchunk);
+  // this wave's two "lines" (tile rows on a diagonal super-tile, tile columns otherwise) and, per line,
+  // how many tiles of it are computed
+  int line[2], cnt[2];
+  if (diag) {
+    line[0] = wave; line[1] = nvr - 1 - wave;
+    cnt[0] = line[0] < nvr && line[0] <= line[1] ? line[0] + 1 : 0;
+    cnt[1] = line[1] > line[0] ? line[1] + 1 : 0;      // (== when nvr is odd: the middle row is line[0]'s)
+  } else {
+    line[0] = 2 * wave; line[1] = 2 * wave + 1;
+    cnt[0] = line[0] < nvc ? nvr : 0;
+    cnt[1] = line[1] < nvc ? nvr : 0;
+  }
+  f64x4 acc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  const int fi = lane & 15, fk = lane >> 4;
+  // a 16 (k) x 128 (columns) tile of X: thread t holds column t & 127 of rows (t >> 7) + 2 pass; loads are
+  // unconditional on clamped indices, out-of-range elements are zeroed on the way into LDS.  A diagonal
+  // super-tile fetches its rows ONCE and stores them twice: weighted (row operand) and plain (column
+  // operand) -- the weight enters each product once, as in the general kernel.
+  double ra[8], rb[8], wa[8];
+  const int tc = t & 127, tk = t >> 7;
+  auto fetch = [&](double (&r)[8], int64_t c0, int64_t k0, bool weights) {
+    const int64_t gm = min(c0 + tc, (int64_t)D - 1);
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int64_t gk = min(k0 + tk + pass * 2, kend - 1);
+      r[pass] = X[gk * ldx + gm];
+      if (weights) wa[pass] = kw ? kw[gk] : 1.0;
+    }
+  };
+  auto store = [&](double *lds, const double (&r)[8], int64_t c0, int64_t k0, bool weighted) {
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const bool ok = (c0 + tc < D) && (k0 + tk + pass * 2 < kend);
+      lds[(tk + pass * 2) * LD + tc] = ok ? (weighted ? r[pass] * wa[pass] : r[pass]) : 0.0;
+    }
+  };
+  if (kbeg < kend) {
+    fetch(ra, m0, kbeg, true);
+    if (!diag) fetch(rb, n0, kbeg, false);
+    store(As[0], ra, m0, kbeg, true);
+    if (diag) store(Bs[0], ra, m0, kbeg, false); else store(Bs[0], rb, n0, kbeg, false);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
+    const bool more = k0 + GK < kend;
+    if (more) {
+      fetch(ra, m0, k0 + GK, true);
+      if (!diag) fetch(rb, n0, k0 + GK, false);
+    }
+    const double *Ar = As[cur], *Bc = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      const int kb = (kk * 4 + fk) * LD + fi;
+      if (diag) {
+        double a[2], b[8];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) a[l] = cnt[l] ? Ar[kb + line[l] * 16] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = c < nvc ? Bc[kb + c * 16] : 0.0;
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (c < cnt[l]) acc[l][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[l], b[c], acc[l][c], 0, 0, 0);
+      } else {
+        double a[8], b[2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = r < nvr ? Ar[kb + r * 16] : 0.0;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) b[l] = cnt[l] ? Bc[kb + line[l] * 16] : 0.0;
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (r < cnt[l]) acc[l][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[l], acc[l][r], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store(As[cur ^ 1], ra, m0, k0 + GK, true);
+      if (diag) store(Bs[cur ^ 1], ra, m0, k0 + GK, false); else store(Bs[cur ^ 1], rb, n0, k0 + GK, false);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // partial slab of this (split, pair): 64 tile slots of 256 doubles; only computed tiles are written
+  double *slab = part + ((int64_t)blockIdx.y * nP + slot) * (64 * 256);
+#pragma unroll
+  for (int l = 0; l < 2; ++l)
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      if (x < cnt[l]) {
+        const int tr = diag ? line[l] : x, tc = diag ? x : line[l];
+        double *d = slab + (tr * 8 + tc) * 256 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r * 64] = acc[l][x][r];
+      }
+}
+
+// sum of the split partials (fixed order), alpha / beta, and the mirror image
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const double *__restrict__ part, int splits_diag,
+                                                          int splits_off, int nP, int D,
+                                                          double alpha, double beta, double *__restrict__ C,
+                                                          int64_t ldc) {
+  int I = 0, J = (int)blockIdx.x / 64;
+  while (J > I) { J -= I + 1; ++I; }
+  const int tile = (int)blockIdx.x % 64, tr = tile >> 3, tc = tile & 7;
+  const int lane = threadIdx.x & 63, reg = threadIdx.x >> 6;
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int gr = I * 128 + tr * 16 + (lane >> 4) + 4 * reg, gc = J * 128 + tc * 16 + (lane & 15);
+  if (gr >= D || gc >= D || gc > gr) return;            // padding, or above the diagonal (skipped or mirrored)
+  const double *p = part + (int64_t)(blockIdx.x / 64) * (64 * 256) + tile * 256 + reg * 64 + lane;
+  const int splits = I == J ? splits_diag : splits_off;
+  double s = 0.0;
+  for (int z = 0; z < splits; ++z) s += p[(int64_t)z * nP * (64 * 256)];
+  double *c1 = C + (int64_t)gr * ldc + gc, *c2 = C + (int64_t)gc * ldc + gr;
+  const double v1 = alpha * s + (beta != 0.0 ? beta * *c1 : 0.0);
+  const double v2 = alpha * s + (beta != 0.0 ? beta * *c2 : 0.0);
+  *c1 = v1;
+  if (gr != gc) *c2 = v2;
+}
+
+int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, int64_t ldx, const double *kw,
+             double beta, double *C, int64_t ldc) {
+  const int nT = (int)ceil_div(D, 128), nP = nT * (nT + 1) / 2, nO = nP - nT;
+  // diagonal and strictly-lower super-tiles are two launches (two tile mappings); each gets its own split of
+  // the rows: ~320 workgroups, chunks of at least 256 rows (a partial costs 2 KiB per computed tile)
+  auto plan = [&](int pairs, int &splits, int64_t &kchunk) {
+    splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(320, pairs), ceil_div(K, 256)));
+    kchunk = round_up(ceil_div(K, splits), GK);
+    splits = (int)ceil_div(K, kchunk);
+  };
+  int sd = 1, so = 1;
+  int64_t kd = K, ko = K;
+  plan(nT, sd, kd);
+  if (nO) plan(nO, so, ko);
+  PLDA_HIP(h, h->w[15].reserve((size_t)std::max(sd, so) * nP * 64 * 256 * 8));
+  double *part = h->w[15].as<double>();
+  syrk_lower_kernel<true><<<dim3((unsigned)nT, (unsigned)sd), 256, 0, h->stream>>>(D, K, kd, X, ldx, kw, part, nP);
+  if (nO) syrk_lower_kernel<false><<<dim3((unsigned)nO, (unsigned)so), 256, 0, h->stream>>>(D, K, ko, X, ldx, kw, part, nP);
+  PLDA_LAUNCH_CHECK(h);
+  syrk_reduce_kernel<<<(unsigned)(nP * 64), 256, 0, h->stream>>>(part, sd, so, nP, D, alpha, beta, C, ldc);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 // Small products (the D x D x D GEMMs of the EM, K <= 256): the 64 x 64 kernel above would put 16
 // workgroups on the chip and walk K in 13 dependent load -> LDS -> MFMA rounds.  Here a workgroup owns a
 // 32 x 32 tile, pulls the WHOLE K extent of both operand panels into LDS with every load in flight at
@@ -248,6 +438,11 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
   const bool akc = (sak == 1), bkc = (sbk == 1);
   if ((!akc && sam != 1) || (!bkc && sbn != 1))
     return fail(h, PLDA_E_INVAL, "gemm_f64: operands need one unit stride");
+  // X^T diag(w) X with both operands the same rows: the symmetric kernel (PLDA_GEMM64_VARIANT=2 keeps the
+  // general one, for A/B measurements)
+  if (batch == 1 && A == B && M == N && !akc && !bkc && sak == sbk && sam == 1 && sbn == 1 && K >= 512 && M >= 32 &&
+      M <= 1024 && h->gemm64_variant != 2)
+    return syrk_f64(h, (int)M, K, alpha, A, sak, kw, beta, C, ldc);
   const int64_t tiles = ceil_div(M, GB) * ceil_div(N, GB);
   if (K <= 256 && M <= 1024 && N <= 1024 && !kw) {
     const size_t lds = (size_t)2 * 32 * (((K + 3) & ~3) + 1) * 8;
