@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 namespace plda {
 
@@ -218,9 +219,9 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, in
   // how many tiles of it are computed
   int line[2], cnt[2];
   if (diag) {
-    line[0] = wave; line[1] = nvr - 1 - wave;
-    cnt[0] = line[0] < nvr && line[0] <= line[1] ? line[0] + 1 : 0;
-    cnt[1] = line[1] > line[0] ? line[1] + 1 : 0;      // (== when nvr is odd: the middle row is line[0]'s)
+    line[0] = wave; line[1] = max(nvr - 1 - wave, 0);
+    cnt[0] = line[0] < nvr && line[0] <= nvr - 1 - wave ? line[0] + 1 : 0;
+    cnt[1] = nvr - 1 - wave > line[0] ? line[1] + 1 : 0;      // (== when nvr is odd: the middle row is line[0]'s)
   } else {
     line[0] = 2 * wave; line[1] = 2 * wave + 1;
     cnt[0] = line[0] < nvc ? nvr : 0;
@@ -270,33 +271,39 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, in
       if (!diag) fetch(rb, n0, k0 + GK, false);
     }
     const double *Ar = As[cur], *Bc = Bs[cur];
+    // the tile counts of the two lines are wave-uniform: one scalar branch per MFMA slot (specialised
+    // branch-free bodies per count pattern made the register allocator spill the accumulators)
+    auto body = [&](auto c0_, auto c1_) {
+      constexpr int C0 = decltype(c0_)::value, C1 = decltype(c1_)::value;   // -1: run-time counts
 #pragma unroll
-    for (int kk = 0; kk < GK / 4; ++kk) {
-      const int kb = (kk * 4 + fk) * LD + fi;
-      if (diag) {
-        double a[2], b[8];
+      for (int kk = 0; kk < GK / 4; ++kk) {
+        const int kb = (kk * 4 + fk) * LD + fi;
+        if (diag) {
+          double a[2], b[8];
 #pragma unroll
-        for (int l = 0; l < 2; ++l) a[l] = cnt[l] ? Ar[kb + line[l] * 16] : 0.0;
+          for (int l = 0; l < 2; ++l) a[l] = Ar[kb + line[l] * 16];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = c < nvc ? Bc[kb + c * 16] : 0.0;
+          for (int c = 0; c < 8; ++c) b[c] = Bc[kb + c * 16];
 #pragma unroll
-        for (int l = 0; l < 2; ++l)
+          for (int c = 0; c < 8; ++c) {
+            if (C0 < 0 ? c < cnt[0] : c < C0) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[c], acc[0][c], 0, 0, 0);
+            if (C1 < 0 ? c < cnt[1] : c < C1) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[c], acc[1][c], 0, 0, 0);
+          }
+        } else {
+          double a[8], b[2];
 #pragma unroll
-          for (int c = 0; c < 8; ++c)
-            if (c < cnt[l]) acc[l][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[l], b[c], acc[l][c], 0, 0, 0);
-      } else {
-        double a[8], b[2];
+          for (int r = 0; r < 8; ++r) a[r] = Ar[kb + r * 16];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = r < nvr ? Ar[kb + r * 16] : 0.0;
+          for (int l = 0; l < 2; ++l) b[l] = Bc[kb + line[l] * 16];
 #pragma unroll
-        for (int l = 0; l < 2; ++l) b[l] = cnt[l] ? Bc[kb + line[l] * 16] : 0.0;
-#pragma unroll
-        for (int l = 0; l < 2; ++l)
-#pragma unroll
-          for (int r = 0; r < 8; ++r)
-            if (r < cnt[l]) acc[l][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[l], acc[l][r], 0, 0, 0);
+          for (int r = 0; r < 8; ++r) {
+            if (C0 < 0 ? r < cnt[0] : r < C0) acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[0], acc[0][r], 0, 0, 0);
+            if (C1 < 0 ? r < cnt[1] : r < C1) acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[1], acc[1][r], 0, 0, 0);
+          }
+        }
       }
-    }
+    };
+    body(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
     if (more) {
       store(As[cur ^ 1], ra, m0, k0 + GK, true);
       if (diag) store(Bs[cur ^ 1], ra, m0, k0 + GK, false); else store(Bs[cur ^ 1], rb, n0, k0 + GK, false);
@@ -345,9 +352,10 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
              double beta, double *C, int64_t ldc) {
   const int nT = (int)ceil_div(D, 128), nP = nT * (nT + 1) / 2, nO = nP - nT;
   // diagonal and strictly-lower super-tiles are two launches (two tile mappings); each gets its own split of
-  // the rows: ~320 workgroups, chunks of at least 256 rows (a partial costs 2 KiB per computed tile)
+  // the rows: 512 workgroups (two per CU, all resident at once), chunks of at least 128 rows (a partial costs
+  // 2 KiB per computed tile)
   auto plan = [&](int pairs, int &splits, int64_t &kchunk) {
-    splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(320, pairs), ceil_div(K, 256)));
+    splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(512, pairs), ceil_div(K, 128)));
     kchunk = round_up(ceil_div(K, splits), GK);
     splits = (int)ceil_div(K, kchunk);
   };
