@@ -474,9 +474,10 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 4096;       // 159744 B
 // non-MFMA instruction in this stream costs the wave ~4 cycles of MFMA issue (measured: 68 instead of
 // 64 cycles per MFMA with 24 register copies + 12 other fillers per step), so nothing is copied
 // except once per stage with an odd number of steps: its first step runs alone (x, fetch into y,
-// y -> x).  One code path (separately unrolled stage bodies made the register allocator spill the
-// accumulators): the pair's second step carries the end-of-stage work -- early barrier, next stage's
-// first fragments, the DMA pieces of the stage after that -- under a uniform `last` flag.
+// y -> x).  Few bodies with fixed register roles (separately unrolled 1/2/3/4-step stage bodies with
+// swapping roles made the register allocator spill the accumulators): a loop over inner pairs, then the
+// stage's last pair, whose second step carries the end-of-stage work -- early barrier, next stage's
+// first fragments, the DMA pieces of the stage after that.
 #define BT2_XYC(T)                                                                                  \
   xa[0][T] = ya[0][T]; xa[1][T] = ya[1][T]; xa[2][T] = ya[2][T]; xa[3][T] = ya[3][T];               \
   xb[0][T] = yb[0][T]; xb[1][T] = yb[1][T];
@@ -487,15 +488,20 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 4096;       // 159744 B
 #define BT2_STEP_FIRST(AP, BP)                                                                      \
   BT2_MFMA8(0, x) BT2_SB; BT2_LOAD(y, AP, BP) BT2_SB;                                               \
   BT2_MFMA8(1, x) BT2_MFMA8(2, x) BT2_MFMA8(3, x) BT2_SB;
-#define BT2_DMA(J) if (last) dma_piece(J);
+// second step of a pair inside a stage, and the stage's last step (early barrier, next stage's first
+// fragments, DMA pieces of the stage after that): two bodies -- eight skipped DMA slots cost 16 scalar
+// instructions per pair, i.e. ~1 cycle per MFMA
 #define BT2_STEP_SECOND(AP, BP)                                                                     \
-  if (last) early_barrier();                                                                        \
-  BT2_SB; BT2_MFMA8(0, y) BT2_SB; BT2_LOAD(x, AP, BP) BT2_SB;                                       \
-  BT2_MFMA2(1, y, 0) BT2_SB; BT2_DMA(0) BT2_SB; BT2_MFMA2(1, y, 1) BT2_SB; BT2_DMA(1) BT2_SB;       \
-  BT2_MFMA2(1, y, 2) BT2_SB; BT2_DMA(2) BT2_SB; BT2_MFMA2(1, y, 3) BT2_SB; BT2_DMA(3) BT2_SB;       \
-  BT2_MFMA2(2, y, 0) BT2_SB; BT2_DMA(4) BT2_SB; BT2_MFMA2(2, y, 1) BT2_SB; BT2_DMA(5) BT2_SB;       \
-  BT2_MFMA2(2, y, 2) BT2_SB; BT2_DMA(6) BT2_SB; BT2_MFMA2(2, y, 3) BT2_SB; BT2_DMA(7) BT2_SB;       \
-  BT2_MFMA2(3, y, 0) BT2_MFMA2(3, y, 1) BT2_SB; if (last) dma_advance();                            \
+  BT2_MFMA8(0, y) BT2_SB; BT2_LOAD(x, AP, BP) BT2_SB;                                               \
+  BT2_MFMA8(1, y) BT2_MFMA8(2, y) BT2_MFMA8(3, y) BT2_SB;
+#define BT2_STEP_LAST()                                                                             \
+  early_barrier();                                                                                  \
+  BT2_SB; BT2_MFMA8(0, y) BT2_SB; BT2_LOAD(x, An, Bn) BT2_SB;                                       \
+  BT2_MFMA2(1, y, 0) BT2_SB; dma_piece(0); BT2_SB; BT2_MFMA2(1, y, 1) BT2_SB; dma_piece(1); BT2_SB; \
+  BT2_MFMA2(1, y, 2) BT2_SB; dma_piece(2); BT2_SB; BT2_MFMA2(1, y, 3) BT2_SB; dma_piece(3); BT2_SB; \
+  BT2_MFMA2(2, y, 0) BT2_SB; dma_piece(4); BT2_SB; BT2_MFMA2(2, y, 1) BT2_SB; dma_piece(5); BT2_SB; \
+  BT2_MFMA2(2, y, 2) BT2_SB; dma_piece(6); BT2_SB; BT2_MFMA2(2, y, 3) BT2_SB; dma_piece(7); BT2_SB; \
+  BT2_MFMA2(3, y, 0) BT2_MFMA2(3, y, 1) BT2_SB; dma_advance();                                      \
   BT2_SB; BT2_MFMA2(3, y, 2) BT2_MFMA2(3, y, 3) BT2_SB;
 
 template <int MODE>
@@ -670,13 +676,14 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
         sn = 1;
       }
 #pragma unroll 1
-      for (; sn < np; sn += 2) {
-        const bool last = sn + 2 == np;
+      for (; sn + 2 < np; sn += 2) {
         step_stamp(sn + 1);
         BT2_STEP_FIRST(Ac + (sn + 1) * 512, Bc + (sn + 1) * 512)
-        const f32x4 *Ax = last ? An : Ac + (sn + 2) * 512, *Bx = last ? Bn : Bc + (sn + 2) * 512;
-        BT2_STEP_SECOND(Ax, Bx)
+        BT2_STEP_SECOND(Ac + (sn + 2) * 512, Bc + (sn + 2) * 512)
       }
+      step_stamp(sn + 1);
+      BT2_STEP_FIRST(Ac + (sn + 1) * 512, Bc + (sn + 1) * 512)
+      BT2_STEP_LAST()
       cur ^= 1;
     }
 
@@ -761,8 +768,8 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // no DMA may land in LDS after the workgroup has gone
 }
+#undef BT2_STEP_LAST
 #undef BT2_STEP_SECOND
-#undef BT2_DMA
 #undef BT2_STEP_FIRST
 #undef BT2_STEP_ODD
 #undef BT2_XYC
