@@ -339,8 +339,17 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const double *__restri
   if (gr >= D || gc >= D || gc > gr) return;            // padding, or above the diagonal (skipped or mirrored)
   const double *p = part + (int64_t)(blockIdx.x / 64) * (64 * 256) + tile * 256 + reg * 64 + lane;
   const int splits = I == J ? splits_diag : splits_off;
-  double s = 0.0;
-  for (int z = 0; z < splits; ++z) s += p[(int64_t)z * nP * (64 * 256)];
+  // eight loads in flight per thread (a plain loop over up to 512 splits is a chain of memory latencies);
+  // the order of the additions is fixed, so the result is deterministic
+  const int64_t zs = (int64_t)nP * (64 * 256);
+  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += p[(int64_t)(z + u) * zs];
+  }
+  for (; z < splits; ++z) s8[0] += p[(int64_t)z * zs];
+  const double s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   double *c1 = C + (int64_t)gr * ldc + gc, *c2 = C + (int64_t)gc * ldc + gr;
   const double v1 = alpha * s + (beta != 0.0 ? beta * *c1 : 0.0);
   const double v2 = alpha * s + (beta != 0.0 ? beta * *c2 : 0.0);
