@@ -59,3 +59,83 @@ def test_c2_full_size_properties():
     b = out[50000:54096, :4096].T
     scale = float(a.abs().mean())
     assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+def _model(d, seed):
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    return rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy()
+
+
+def test_c5_full_size_fused_znorm_statistics():
+    """BASELINE C5: 50 000 models x 200 000 cohort vectors (1e10 LLRs, nothing materialised) through the fused
+    z-norm epilogue (MPlda_norm, pldamodule.cpp:196-256), then the 50k x 50k z-normalised trials matrix.
+    Checked against the fp64 GEMM-form oracle on sampled models: mean / population std over the WHOLE cohort
+    within 1e-4, and z-normalised trials within the score tolerance."""
+    import torch
+    from plda_amd import MPlda
+    from oracle import plda_oracle_np as onp
+    dev = torch.device("cuda", 0)
+    D, M, Nb = 200, 50000, 200000
+    mean, T, psi = _model(D, 51)
+    eng = MPlda(0)
+    eng.set_model(mean, T, psi)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    bkg = torch.rand((Nb, D), dtype=torch.float64, device=dev, generator=g)
+    models = torch.randn((M, D), dtype=torch.float64, device=dev, generator=g)
+    zm = torch.empty(M, dtype=torch.float64, device=dev); zs = torch.empty(M, dtype=torch.float64, device=dev)
+    eng.znorm_stats_dev(bkg.data_ptr(), Nb, Nb, D, models.data_ptr(), M, zm.data_ptr(), zs.data_ptr())
+    torch.cuda.synchronize()
+    sel = np.array([0, 1, 777, 25000, 49999])
+    model = dict(mean=mean, transform=T, psi=psi, offset=-T @ mean)
+    rm, rs = onp.norm(model, bkg.cpu().numpy(), models[torch.from_numpy(sel).to(dev)].cpu().numpy())
+    gm, gs = zm[torch.from_numpy(sel).to(dev)].cpu().numpy(), zs[torch.from_numpy(sel).to(dev)].cpu().numpy()
+    assert (np.abs(gm - rm) <= 1e-4 * np.maximum(np.abs(rm), np.abs(rm).mean())).all(), np.abs(gm - rm).max()
+    assert (np.abs(gs - rs) <= 1e-4 * rs).all(), (np.abs(gs - rs) / rs).max()
+    # 50k x 50k z-normalised trials (default dispatch: the 256 x 256 kernel with the map folded into the operands)
+    tests = torch.randn((M, D), dtype=torch.float64, device=dev, generator=g)
+    out = torch.empty((M, M), dtype=torch.float32, device=dev)
+    eng.score_matrix_dev(models.data_ptr(), None, 1, M, tests.data_ptr(), M, out.data_ptr(), M, zm.data_ptr(), zs.data_ptr())
+    torch.cuda.synchronize()
+    cols = np.random.default_rng(3).integers(0, M, 2048)
+    tc = torch.from_numpy(cols).to(dev); ts = torch.from_numpy(sel).to(dev)
+    raw = onp.llr_matrix(psi, models[ts].cpu().numpy(), 1, tests[tc].cpu().numpy())
+    ref = (raw - zm[ts].cpu().numpy()[:, None]) / zs[ts].cpu().numpy()[:, None]
+    got = out[ts][:, tc].cpu().numpy().astype(np.float64)
+    tol = 1e-4 * np.maximum(np.abs(ref), np.abs(ref).mean())
+    assert (np.abs(got - ref) <= tol).all(), (np.abs(got - ref) / tol).max()
+
+
+def test_c3_and_c4_shard_full_size():
+    """BASELINE C3 (10k models, n = 100, x 1M tests, D = 512) and one of C4's eight shards (5k models, n in 1..5, x 1.2M
+    tests, D = 256, GEMM depth 512) at full size through default dispatch, checked on sampled rows x columns
+    against the fp64 GEMM-form oracle."""
+    import torch
+    from plda_amd import MPlda
+    from oracle import plda_oracle_np as onp
+    dev = torch.device("cuda", 0)
+    for (D, M, Nt, counts, seed) in [(512, 10000, 1000000, 100, 61), (256, 5000, 1200000, None, 62)]:
+        mean, T, psi = _model(D, seed)
+        eng = MPlda(0)
+        eng.set_model(mean, T, psi)
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+        g = torch.Generator(device=dev); g.manual_seed(seed)
+        dU = torch.randn((M, D), dtype=torch.float64, device=dev, generator=g)
+        dV = torch.randn((Nt, D), dtype=torch.float64, device=dev, generator=g)
+        n = None
+        if counts is None:
+            n = torch.randint(1, 6, (M,), device=dev, dtype=torch.int32, generator=g)
+        out = torch.empty((M, Nt), dtype=torch.float32, device=dev)
+        eng.score_matrix_dev(dU.data_ptr(), n.data_ptr() if n is not None else None, counts or 0, M, dV.data_ptr(), Nt,
+                             out.data_ptr(), Nt)
+        torch.cuda.synchronize()
+        rows = np.array([0, 255, 256, M // 2, M - 1])
+        cols = np.unique(np.concatenate([np.random.default_rng(seed).integers(0, Nt, 3000), np.arange(Nt - 64, Nt)]))
+        tr, tc = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
+        ref = onp.llr_matrix(psi, dU[tr].cpu().numpy(), n[tr].cpu().numpy() if n is not None else counts, dV[tc].cpu().numpy())
+        got = out[tr][:, tc].cpu().numpy().astype(np.float64)
+        tol = 1e-4 * np.maximum(np.abs(ref), np.abs(ref).mean())
+        assert (np.abs(got - ref) <= tol).all(), (D, (np.abs(got - ref) / tol).max())
+        del out, dU, dV
+        torch.cuda.empty_cache()
