@@ -494,9 +494,9 @@ constexpr int BT2_LDS = BT2_BIAS + 3 * 4096;       // 159744 B
 #define BT2_STEP_SECOND(AP, BP)                                                                     \
   BT2_MFMA8(0, y) BT2_SB; BT2_LOAD(x, AP, BP) BT2_SB;                                               \
   BT2_MFMA8(1, y) BT2_MFMA8(2, y) BT2_MFMA8(3, y) BT2_SB;
-#define BT2_STEP_LAST(PF)                                                                           \
+#define BT2_STEP_LAST()                                                                             \
   early_barrier();                                                                                  \
-  BT2_SB; BT2_MFMA8(0, y) BT2_SB; if (PF) { BT2_LOAD(x, An, Bn) } BT2_SB;                           \
+  BT2_SB; BT2_MFMA8(0, y) BT2_SB; BT2_LOAD(x, An, Bn) BT2_SB;                                       \
   BT2_MFMA2(1, y, 0) BT2_SB; dma_piece(0); BT2_SB; BT2_MFMA2(1, y, 1) BT2_SB; dma_piece(1); BT2_SB; \
   BT2_MFMA2(1, y, 2) BT2_SB; dma_piece(2); BT2_SB; BT2_MFMA2(1, y, 3) BT2_SB; dma_piece(3); BT2_SB; \
   BT2_MFMA2(2, y, 0) BT2_SB; dma_piece(4); BT2_SB; BT2_MFMA2(2, y, 1) BT2_SB; dma_piece(5); BT2_SB; \
@@ -626,18 +626,15 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
       if (blockIdx.x == 0 && lane == 0 && tseq < 8 && st < 16) dbg[(((size_t)tseq * 16 + st) * 8 + wave) * 8 + 1 + sn] = ts;
     }
   };
-  // ---- prologue: stage 0 of the first tile, barrier, then (short tiles) stage 1 in a burst ----
+  // ---- prologue: stage 0 of the first tile, barrier, then stage 1 in a burst ----
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
   dma_advance();
   __builtin_amdgcn_s_waitcnt(0x0070);
   __builtin_amdgcn_s_barrier();
-  const bool split = nst >= 3;     // tile-boundary schedule (see the stage loop): stage 1 is fetched at stage 0's barrier
-  if (!split) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
-    dma_advance();
-  }
+  for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
+  dma_advance();
 
   int cur = 0, c_slot = 0;                                         // buffer / queue slot of the compute cursor
   int r0 = q_r0[0], c0 = q_c0[0];
@@ -672,47 +669,21 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
       const int np = sbase + (st < srem ? 1 : 0);
       const f32x4 *Ac = Abase + cur * 4096, *Bc = Bbase + cur * 4096;
       const f32x4 *An = Abase + (cur ^ 1) * 4096, *Bn = Bbase + (cur ^ 1) * 4096;
-      // Tile-boundary schedule (tiles of >= 3 stages).  The two waves of a SIMD take turns on the matrix
-      // pipe -- the older runs ahead at full rate, waits at the next barrier, the younger then has the pipe
-      // alone -- so between two barriers each does ALL its MFMAs in one run.  With the barrier in front of
-      // the tile's last step the two ~6 k-cycle epilogues started one step (2 k cycles) apart and
-      // overlapped for ~4 k cycles with the pipe idle.  Now the tile's LAST stage takes its barrier at
-      // its START (both its data and the next tile's first stage have landed by then) and runs
-      // barrier-free through the epilogue into the next tile's first stage: leader 3-4 steps, leader's
-      // epilogue beside the trailer's 3-4 steps, trailer's epilogue beside the leader's next 3 steps.
-      // The price: that stage frees no buffer, so the next tile's SECOND stage is fetched one barrier late
-      // (at the first stage's barrier instead of this one's) and needs a barrier of its own when it starts.
-      const bool kindL = split && st == nst - 1;    // last stage of a tile: barrier first, no DMA issue
-      const bool kindF0 = split && st == 0;          // first stage: its barrier fetches stage 1 (not 2); no fragment prefetch
-      const bool kindF1 = split && st == 1;          // second stage: own barrier, fragments fetched in the open, fetches stage 2
-      if (kindF1) {
-        early_barrier();
-        BT2_LOAD(x, Ac, Bc)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
-        dma_advance();
-      }
-      if (kindL) early_barrier();
       int sn = 0;                // step whose fragments are in x
       if (np & 1) {
         step_stamp(1);
         BT2_STEP_ODD(Ac + 512, Bc + 512)
         sn = 1;
       }
-      const int pair_end = kindL ? np : np - 2;      // kind L runs its final pair in the loop (no end-of-stage work)
 #pragma unroll 1
-      for (; sn < pair_end; sn += 2) {
+      for (; sn + 2 < np; sn += 2) {
         step_stamp(sn + 1);
         BT2_STEP_FIRST(Ac + (sn + 1) * 512, Bc + (sn + 1) * 512)
-        const bool fin = sn + 2 == np;                // (kind L only) the following fragments are the next tile's
-        const f32x4 *Ax = fin ? An : Ac + (sn + 2) * 512, *Bx = fin ? Bn : Bc + (sn + 2) * 512;
-        BT2_STEP_SECOND(Ax, Bx)
+        BT2_STEP_SECOND(Ac + (sn + 2) * 512, Bc + (sn + 2) * 512)
       }
-      if (!kindL) {
-        step_stamp(sn + 1);
-        BT2_STEP_FIRST(Ac + (sn + 1) * 512, Bc + (sn + 1) * 512)
-        BT2_STEP_LAST(!kindF0)
-      }
+      step_stamp(sn + 1);
+      BT2_STEP_FIRST(Ac + (sn + 1) * 512, Bc + (sn + 1) * 512)
+      BT2_STEP_LAST()
       cur ^= 1;
     }
 
