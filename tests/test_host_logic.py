@@ -180,3 +180,22 @@ def test_sharded_trials_matrix_gloo_world2(oracle, gather):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_block_cyclic_rows_tile_exactly():
+    """The Python mirror of plda_score_matrix_sharded_dev's partition (csrc/comm.hip): every row belongs to exactly
+    one rank, blocks are multiples of 256 rows, the remainder is dealt out in equal smaller blocks."""
+    from plda_amd.sharding import block_cyclic_rows
+    for m, world, block in [(1, 1, 256), (5, 4, 256), (2900, 2, 256), (2900, 3, 512), (2900, 8, 256),
+                            (100000, 8, 4096), (100000, 2, 4096), (40000, 8, 4096), (40000, 4, 0), (4096 * 8, 8, 4096)]:
+        cover = np.zeros(m, np.int32)
+        sizes = []
+        for r in range(world):
+            rows = block_cyclic_rows(m, world, r, block)
+            for a, b in rows:
+                assert 0 <= a < b <= m and a % 256 == 0
+                cover[a:b] += 1
+            sizes.append(sum(b - a for a, b in rows))
+        assert (cover == 1).all(), (m, world, block)
+        blk = -(-(block if block > 0 else 4096) // 256) * 256
+        assert max(sizes) - min(sizes) <= max(blk, 256), (m, world, block, sizes)   # balanced to within one block
