@@ -161,6 +161,14 @@ int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double
  * out[tile < 8][stage < 16][wave < 8][8] = {barrier arrive, leave, start of steps 1..3 of the stage (0 if
  * absent), -, epilogue start, epilogue end (the last two in stage slot 15)}. */
 int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words);
+
+/* The symmetric eigensolver of GetOutput on its own (diagnostics and tests; the reference reaches it only through
+ * Plda estimation, pldamodule.cpp:102-106 -> Kaldi SpMatrix::Eig).  G [D,D] row-major symmetric, host pointers.
+ * eigenvalues[D] descending (signed), eigenvectors [D,D] with eigenvector i in ROW i.  method: 0 = what fit uses
+ * (tridiagonalisation + divide and conquer where supported, else block Jacobi), 1 = block Jacobi, 2 = direct
+ * method or PLDA_E_NUMERIC.  *method_used (nullable) reports 1 or 2. */
+int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, double *eigenvalues,
+                 double *eigenvectors, int32_t *method_used);
 /* algorithmic work of the last score_matrix call: flop of the trials GEMM and
  * its depth, for roofline accounting */
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k);

@@ -152,6 +152,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_EIG_VARIANT")) h->eig_variant = std::atoi(v);
     *out = h;
     return PLDA_OK;
   });
@@ -166,7 +167,7 @@ int plda_destroy(plda_handle *h) {
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
-                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline};
+                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->w) b.release();
     if (h->one_host) (void)hipHostFree(h->one_host);
@@ -610,6 +611,46 @@ int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words) {
     PLDA_TRY(set_device(h));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
     PLDA_HIP(h, hipMemcpy(out, h->timeline.p, TIMELINE_WORDS * 8, hipMemcpyDeviceToHost));
+    return PLDA_OK;
+  });
+}
+
+int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, double *eigenvalues, double *eigenvectors,
+                 int32_t *method_used) {
+  return guarded(h, "plda_sym_eig", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!G || !eigenvalues || !eigenvectors || D <= 0 || D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: bad argument");
+    if (method < 0 || method > 2) return fail(h, PLDA_E_INVAL, "sym_eig: method must be 0 (default), 1 (Jacobi) or 2 (direct)");
+    PLDA_TRY(set_device(h));
+    const size_t DD = (size_t)D * D;
+    Tmp dG, dS, dV;
+    PLDA_HIP(h, dG.alloc(DD * 8));
+    PLDA_HIP(h, dS.alloc((size_t)D * 8));
+    PLDA_HIP(h, dV.alloc(DD * 8));
+    PLDA_HIP(h, hipMemcpyAsync(dG.p, G, DD * 8, hipMemcpyHostToDevice, h->stream));
+    const bool keep = h->eig_keep_sign;
+    const int variant = h->eig_variant;
+    h->eig_keep_sign = true;                       // signed eigenvalues: this entry point floors nothing
+    int rc = PLDA_OK, status = 1;
+    if (method == 2 || (method == 0 && variant != 1)) {
+      rc = sym_eig_dc_f64(h, dG.as<double>(), D, dS.as<double>(), dV.as<double>(), &status);
+      if (rc == PLDA_OK && status != 0 && method == 2) {
+        h->eig_keep_sign = keep;
+        return fail(h, PLDA_E_NUMERIC, "sym_eig: the direct method does not handle this input (status %d)", status);
+      }
+    }
+    if (rc == PLDA_OK && status != 0) {
+      rc = sym_eig_f64(h, dG.as<double>(), D, dS.as<double>(), dV.as<double>(), nullptr, nullptr);
+      if (method_used) *method_used = 1;
+    } else if (method_used) {
+      *method_used = 2;
+    }
+    h->eig_keep_sign = keep;
+    PLDA_TRY(rc);
+    PLDA_HIP(h, hipMemcpyAsync(eigenvalues, dS.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(eigenvectors, dV.p, DD * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
     return PLDA_OK;
   });
 }

@@ -106,6 +106,9 @@ struct plda_handle {
 
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
+  plda::DevBuf eigdc;            // eig_dc.hip workspace
+  int eig_variant = 0;           // PLDA_EIG_VARIANT: 0 = direct method where supported, 1 = block Jacobi always
+  int eig_last_method = 0;       // 1 = block Jacobi, 2 = tridiagonalisation + divide and conquer
 };
 
 namespace plda {
@@ -156,6 +159,9 @@ int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t
 // descending in s[D] (floored at 0), eigenvectors in the ROWS of Vrows.
 int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,
                 const double *warm);
+// direct method (eig_dc.hip): Householder tridiagonalisation + divide and conquer + back-transformation.
+// *status != 0: not supported / gave up -> use sym_eig_f64.  G is not modified.
+int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vrows, int *status);
 // simultaneous diagonalisation of (W,B): T W T^T = I, T B T^T = diag(psi);
 // T [D,D], Tinv = T^{-1} (nullable), psi[D].  W,B are not modified.
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T,

@@ -1,0 +1,942 @@
+// plda_amd/csrc/eig_dc.hip -- symmetric eigensolver of GetOutput (K7), direct method:
+//
+//   Householder tridiagonalisation  ->  divide and conquer on the tridiagonal  ->  back-transformation
+//
+// The reference's GetOutput (Kaldi PldaEstimator::GetOutput as driven by pldamodule.cpp:102-106; restated in
+// oracle/plda_oracle.c:432-485) diagonalises the whitened between-class covariance with SpMatrix::Eig, which is
+// itself tridiagonalisation + QL.  The one-sided block Jacobi of linalg.hip needs ~11 sweeps of D/4 launches
+// (5.3 ms at D = 200); everything here is O(log D) launches after one D-step tridiagonalisation.
+//
+//   tridiag_reg_kernel    D <= 256: the matrix lives in the registers of ONE workgroup (lower-triangle 32 x 32
+//                         block ownership as chol_small_kernel), D - 2 steps of (publish column -> v, tau ->
+//                         p = A v -> w -> rank-2 update), three barriers per step, no global synchronisation
+//   tridiag_rows_kernel   D <= 1024: rows dealt cyclically to D/8 workgroups (LDS-resident), ONE all-gather
+//                         per step through agent-scope atomics (p_i and the next column travel together)
+//   dc_leaf_kernel        implicit QL (Wilkinson shift) on leaves of <= 16, one wave per leaf, d / e in lanes
+//   dc_merge_roots_kernel per merge: rank sort, deflation (dlaed2's two criteria), secular roots by the two-pole
+//                         rational iteration with a bisection safeguard, 8 lanes per root
+//   dc_merge_vectors_kernel  Gu-Eisenstat z, normalised eigenvectors of D + rho z z^T -> the level's update matrix
+//   (one dense fp64 MFMA GEMM per level applies it to the eigenvector rows)
+//   householder_rows_kernel  back-transformation, one wave per eigenvector
+//
+// scripts/proto_dc_eig.py is the NumPy prototype of the same algorithm (same deflation rule, same iteration).
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace plda {
+
+namespace {
+
+constexpr double DC_EPS = 2.220446049250313e-16;
+constexpr int DC_LEAF = 16;       // leaves have ceil(n / 2^depth) <= 16 rows
+constexpr int DC_NMAX = 1024;
+constexpr int DC_G = 8;           // lanes per secular root
+constexpr int DC_RS = 32;         // roots per workgroup of dc_merge_roots_kernel (256 threads)
+
+__device__ __forceinline__ double dc_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double dc_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
+// segment `idx` of the 2^depth-way recursive halving of [0, n): the left part gets floor(len / 2)
+__host__ __device__ inline void dc_segment(int n, int depth, int idx, int &off, int &len) {
+  off = 0;
+  len = n;
+  for (int bit = depth - 1; bit >= 0; --bit) {
+    const int h1 = len / 2;
+    if ((idx >> bit) & 1) { off += h1; len -= h1; }
+    else len = h1;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// scale = 2^-floor(log2 max|g_ij|): sums of squares then neither overflow nor underflow
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void eig_scale_kernel(const double *__restrict__ G, int n, double *__restrict__ scale,
+                                                         int *__restrict__ flag) {
+  __shared__ double red[16];
+  double m = 0.0;
+  bool bad = false;
+  for (int i = threadIdx.x; i < n * n; i += 1024) {
+    const double x = fabs(G[i]);
+    if (!(x <= 1.7976931348623157e308)) bad = true;   // NaN or inf
+    m = fmax(m, x);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  const int anybad = __syncthreads_or(bad ? 1 : 0);
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
+    double s = 1.0;
+    if (m > 0.0 && !anybad) {
+      int ex;
+      (void)frexp(m, &ex);          // m = f 2^ex, f in [0.5, 1)
+      s = ldexp(1.0, 1 - ex);       // m s in [1, 2)
+    }
+    scale[0] = s;
+    scale[1] = 1.0 / s;
+    if (anybad) atomicOr(flag, 4);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// tridiagonalisation, matrix in the registers of one workgroup (n <= 32 NB <= 256)
+// thread (ty, tx) of the 32 x 32 grid owns A[32a + ty][32b + tx] for the blocks a >= b (diagonal blocks whole)
+// ------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(1024) void tridiag_reg_kernel(const double *__restrict__ G, int n,
+                                                           const double *__restrict__ scale,
+                                                           double *__restrict__ dd, double *__restrict__ ee,
+                                                           double *__restrict__ Vh, double *__restrict__ tau) {
+  constexpr int NE = NB * (NB + 1) / 2;
+  constexpr int NR = NB * 32;
+  constexpr int NW = (NR + 63) / 64;          // waves that hold the NR p-values
+  __shared__ double xs[2][NR];
+  __shared__ double ps[NR];
+  __shared__ double prow[NR];
+  __shared__ double part[16][NR];
+  __shared__ double red[4];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5, lane = t & 63, wave = t >> 6;
+  const double sc = scale[0];
+  double r[NE];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 32 + ty, j = b * 32 + tx;
+      r[a * (a + 1) / 2 + b] = (i < n && j < n) ? G[(size_t)i * n + j] * sc : 0.0;
+    }
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    for (int kl = 0; kl < 32; ++kl) {
+      const int j = kb * 32 + kl;
+      if (j >= n - 2) break;
+      double *x = xs[j & 1];
+      // ---- publish column j below the diagonal (zeros above it) ----
+      if (tx == kl) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const int i = a * 32 + ty;
+          double v = 0.0;
+          if (a >= kb) v = (i > j) ? r[a * (a + 1) / 2 + kb] : 0.0;
+          x[i] = v;
+        }
+        if (ty == kl) dd[j] = r[kb * (kb + 1) / 2 + kb];
+      }
+      __syncthreads();
+      // ---- v, tau (every wave for itself) ----
+      double s2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < (NR + 63) / 64; ++q) {
+        const int i = lane + 64 * q;
+        const double xv = i < NR ? x[i] : 0.0;
+        s2 += (i > j + 1) ? xv * xv : 0.0;
+      }
+      s2 = wave_sum_f64(s2);
+      const double x0 = x[j + 1];
+      if (s2 == 0.0) {   // column already tridiagonal (uniform over the workgroup)
+        if (t == 0) { ee[j] = x0; tau[j] = 0.0; }
+        continue;
+      }
+      const double nx2 = fma(x0, x0, s2);
+      const double nx = nx2 * dc_rsqrt(nx2);
+      const double alpha = x0 >= 0.0 ? -nx : nx;
+      const double v0 = x0 - alpha;
+      const double tt = 2.0 * dc_rcp(fma(v0, v0, s2));
+      double vc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int c = b * 32 + tx;
+        vc[b] = b >= kb ? (c == j + 1 ? v0 : x[c]) : 0.0;
+      }
+      // ---- p = A v: row sums over the stored blocks + column sums of the strictly-lower blocks ----
+      double pc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) pc[b] = 0.0;
+#pragma unroll
+      for (int a = kb; a < NB; ++a) {
+        const int i = a * 32 + ty;
+        const double vra = i == j + 1 ? v0 : x[i];
+        double pr = 0.0;
+#pragma unroll
+        for (int b = kb; b <= a; ++b) pr = fma(r[a * (a + 1) / 2 + b], vc[b], pr);
+#pragma unroll
+        for (int b = kb; b < a; ++b) pc[b] = fma(r[a * (a + 1) / 2 + b], vra, pc[b]);
+        // sum over tx: the 16-lane rows by DPP, the two rows of each half through readlane
+        pr += dpp_f64<0xB1>(pr);
+        pr += dpp_f64<0x4E>(pr);
+        pr += dpp_f64<0x141>(pr);
+        pr += dpp_f64<0x140>(pr);
+        const double h0 = readlane_f64(pr, 0) + readlane_f64(pr, 16);
+        const double h1 = readlane_f64(pr, 32) + readlane_f64(pr, 48);
+        if (lane == 0) {
+          prow[a * 32 + 2 * wave] = h0;
+          prow[a * 32 + 2 * wave + 1] = h1;
+        }
+      }
+#pragma unroll
+      for (int b = kb; b < NB - 1; ++b) {
+        double c = pc[b];
+        c += __shfl_xor(c, 32);
+        if (lane < 32) part[wave][b * 32 + tx] = c;
+      }
+      __syncthreads();
+      double vp = 0.0;
+      if (t < NR) {
+        const int bb = t >> 5;
+        double p = 0.0;
+        if (bb >= kb && t > j) {
+          p = prow[t];
+          if (bb < NB - 1) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) p += part[w][t];
+          }
+        }
+        const double vi = t == j + 1 ? v0 : x[t];
+        ps[t] = p;
+        vp = vi * p;
+        if (t < n) Vh[(size_t)j * n + t] = vi;
+      }
+      if (wave < NW) {
+        vp = wave_sum_f64(vp);
+        if (lane == 0) red[wave] = vp;
+      }
+      if (t == 0) { ee[j] = alpha; tau[j] = tt; }
+      __syncthreads();
+      double vtp = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) vtp += red[w];
+      const double beta = 0.5 * tt * tt * vtp;
+      // ---- w = tt p - beta v; A -= v w^T + w v^T on the trailing blocks ----
+      double wc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) wc[b] = b >= kb ? fma(tt, ps[b * 32 + tx], -beta * vc[b]) : 0.0;
+#pragma unroll
+      for (int a = kb; a < NB; ++a) {
+        const int i = a * 32 + ty;
+        const double vra = i == j + 1 ? v0 : x[i];
+        const double wra = fma(tt, ps[i], -beta * vra);
+#pragma unroll
+        for (int b = kb; b <= a; ++b)
+          r[a * (a + 1) / 2 + b] = fma(-vra, wc[b], fma(-wra, vc[b], r[a * (a + 1) / 2 + b]));
+      }
+    }
+  }
+  // ---- the last 2 x 2 block ----
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 32 + ty, j = b * 32 + tx;
+      const double v = r[a * (a + 1) / 2 + b];
+      if (i == j && i < n && i >= n - 2) dd[i] = v;
+      if (n >= 2 && i == n - 1 && j == n - 2) ee[n - 2] = v;
+    }
+  if (t == 0) {
+    if (n >= 2) tau[n - 2] = 0.0;
+    tau[n - 1] = 0.0;
+    ee[n - 1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// tridiagonalisation, rows dealt cyclically to W = ceil(n / 8) workgroups (LDS-resident), n <= 1024.
+// Step j, every workgroup: v, tau from column j (all hold it) -> p_i = A_i . v for its rows -> publish p_i
+// together with A[i][j+1] -> ONE all-gather (agent-scope atomics: data words stored / loaded coherently, a flag
+// per workgroup counts the steps) -> w, and column j+1 of the UPDATED matrix follows locally as
+// A[i][j+1] - v_i w_{j+1} - w_i v_{j+1} -> rank-2 update of the own rows.  Launched cooperatively (all workgroups
+// resident: they wait for each other).
+// ------------------------------------------------------------------------------------
+constexpr int TR_ROWS = 8;
+
+__device__ __forceinline__ double tr_block_sum(double x, double *red, int lane, int wave) {
+  x = wave_sum_f64(x);
+  __syncthreads();                 // red may still be read from the previous sum
+  if (lane == 0) red[wave] = x;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void tridiag_rows_kernel(const double *__restrict__ G, int n, int W,
+                                                           const double *__restrict__ scale, double *__restrict__ dd,
+                                                           double *__restrict__ ee, double *__restrict__ Vh,
+                                                           double *__restrict__ tau, double *Pg, double *Cg, int *flags) {
+  extern __shared__ __attribute__((aligned(16))) double tr_sm[];
+  double *rows = tr_sm;                       // [TR_ROWS][n]
+  double *xcol = rows + (size_t)TR_ROWS * n;  // column j of the current matrix
+  double *vv = xcol + n, *pp = vv + n, *cc = pp + n, *ww = cc + n;
+  __shared__ double red[4];
+  const int t = threadIdx.x, slot = t >> 5, l = t & 31, lane = t & 63, wave = t >> 6, w = blockIdx.x;
+  const double sc = scale[0];
+  const int myrow = w + slot * W;
+  const bool rowok = myrow < n;
+  for (int s2 = 0; s2 < TR_ROWS; ++s2) {
+    const int gi = w + s2 * W;
+    for (int k = t; k < n; k += 256) rows[(size_t)s2 * n + k] = gi < n ? G[(size_t)gi * n + k] * sc : 0.0;
+  }
+  for (int k = t; k < n; k += 256) xcol[k] = G[k] * sc;   // column 0 = row 0 (symmetric)
+  __syncthreads();
+  double *myr = rows + (size_t)slot * n;
+  for (int j = 0; j < n - 2; ++j) {
+    // ---- v, tau ----
+    double part = 0.0;
+    for (int k = t; k < n; k += 256) {
+      const double xv = xcol[k];
+      part += k > j + 1 ? xv * xv : 0.0;
+    }
+    const double s2 = tr_block_sum(part, red, lane, wave);
+    const double x0 = xcol[j + 1];
+    const bool skip = s2 == 0.0;
+    double alpha = x0, v0 = 0.0, tt = 0.0;
+    if (!skip) {
+      const double nx2 = fma(x0, x0, s2);
+      const double nx = nx2 * dc_rsqrt(nx2);
+      alpha = x0 >= 0.0 ? -nx : nx;
+      v0 = x0 - alpha;
+      tt = 2.0 * dc_rcp(fma(v0, v0, s2));
+    }
+    for (int k = t; k < n; k += 256) {
+      const double vk = skip ? 0.0 : (k > j + 1 ? xcol[k] : (k == j + 1 ? v0 : 0.0));
+      vv[k] = vk;
+      if (w == 0) Vh[(size_t)j * n + k] = vk;
+    }
+    if (w == 0 && t == 0) { ee[j] = alpha; tau[j] = tt; }
+    if (w == j % W && t == 0) dd[j] = rows[(size_t)(j / W) * n + j];
+    __syncthreads();
+    // ---- p_i for the own rows ----
+    double acc = 0.0;
+    if (rowok && myrow > j && !skip)
+      for (int k = l; k < n; k += 32) acc = fma(myr[k], vv[k], acc);
+    acc += dpp_f64<0xB1>(acc);
+    acc += dpp_f64<0x4E>(acc);
+    acc += dpp_f64<0x141>(acc);
+    acc += dpp_f64<0x140>(acc);
+    acc += __shfl_xor(acc, 16);
+    const int par = j & 1;
+    if (l == 0 && rowok) {
+      __hip_atomic_store(&Pg[(size_t)par * n + myrow], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&Cg[(size_t)par * n + myrow], myr[j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&flags[w], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- all-gather ----
+    if (t < W)
+      while (__hip_atomic_load(&flags[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < j + 1) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    for (int k = t; k < n; k += 256) {
+      pp[k] = __hip_atomic_load(&Pg[(size_t)par * n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cc[k] = __hip_atomic_load(&Cg[(size_t)par * n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // ---- w, next column ----
+    part = 0.0;
+    for (int k = t; k < n; k += 256) part = fma(vv[k], pp[k], part);
+    const double vtp = tr_block_sum(part, red, lane, wave);
+    const double beta = 0.5 * tt * tt * vtp;
+    const double vj1 = vv[j + 1];
+    const double wj1 = fma(tt, pp[j + 1], -beta * vj1);
+    for (int k = t; k < n; k += 256) {
+      const double vk = vv[k];
+      const double wk = k > j ? fma(tt, pp[k], -beta * vk) : 0.0;
+      ww[k] = wk;
+      xcol[k] = cc[k] - vk * wj1 - wk * vj1;
+    }
+    __syncthreads();
+    // ---- A_i -= v_i w + w_i v ----
+    if (rowok && myrow > j && !skip) {
+      const double vi = vv[myrow], wi = ww[myrow];
+      for (int k = l; k < n; k += 32) myr[k] = fma(-vi, ww[k], fma(-wi, vv[k], myr[k]));
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    if (n >= 2 && w == (n - 2) % W) dd[n - 2] = rows[(size_t)((n - 2) / W) * n + n - 2];
+    if (w == (n - 1) % W) {
+      dd[n - 1] = rows[(size_t)((n - 1) / W) * n + n - 1];
+      if (n >= 2) ee[n - 2] = rows[(size_t)((n - 1) / W) * n + n - 2];
+      ee[n - 1] = 0.0;
+      tau[n - 1] = 0.0;
+      if (n >= 2) tau[n - 2] = 0.0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// leaves: implicit QL with Wilkinson shift, one wave per leaf.  Lane i holds d_i and e_i (uniform
+// indices -> readlane), lane k holds row k of the eigenvector matrix in LDS.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ dd, const double *__restrict__ ee, int n,
+                                                     int depth, double *__restrict__ lam, double *__restrict__ Qt,
+                                                     int *__restrict__ flag) {
+  __shared__ double Z[DC_LEAF][DC_LEAF + 1];
+  const int lane = threadIdx.x;
+  int off, m;
+  dc_segment(n, depth, blockIdx.x, off, m);
+  double d = 0.0, e = 0.0;
+  if (lane < m) {
+    d = dd[off + lane];
+    if (lane == 0 && off > 0) d -= fabs(ee[off - 1]);
+    if (lane == m - 1 && off + m < n) d -= fabs(ee[off + m - 1]);
+    if (lane < m - 1) e = ee[off + lane];
+  }
+  if (lane < DC_LEAF)
+    for (int c = 0; c < DC_LEAF; ++c) Z[lane][c] = lane == c ? 1.0 : 0.0;
+  auto getd = [&](int i) { return readlane_f64(d, __builtin_amdgcn_readfirstlane(i)); };
+  auto gete = [&](int i) { return readlane_f64(e, __builtin_amdgcn_readfirstlane(i)); };
+  bool failed = false;
+  for (int l = 0; l < m && !failed; ++l) {
+    int iter = 0;
+    while (true) {
+      // smallest mm >= l with a negligible e[mm] (mm = m - 1 if none)
+      const double dn = dpp_f64<0x130>(d);   // wave_shl 1: lane i reads lane i + 1
+      const bool small = fabs(e) <= DC_EPS * (fabs(d) + fabs(dn));
+      const unsigned long long mask = __ballot(small && lane >= l && lane < m - 1);
+      const int mm = mask ? __builtin_ctzll(mask) : m - 1;
+      if (mm == l) break;
+      if (++iter > 80) { failed = true; break; }
+      const double dl = getd(l), el = gete(l);
+      double g = (getd(l + 1) - dl) * dc_rcp(2.0 * el);
+      const double rr = sqrt(fma(g, g, 1.0));
+      g = getd(mm) - dl + el * dc_rcp(g + (g >= 0.0 ? rr : -rr));
+      double s = 1.0, c = 1.0, p = 0.0;
+      bool underflow = false;
+      for (int i = mm - 1; i >= l; --i) {
+        const double ei = gete(i), di = getd(i), di1 = getd(i + 1);
+        const double f = s * ei, b = c * ei;
+        const double h2 = fma(f, f, g * g);
+        if (h2 == 0.0) {
+          if (lane == i + 1) { d -= p; e = 0.0; }
+          if (lane == mm) e = 0.0;
+          underflow = true;
+          break;
+        }
+        const double hinv = dc_rsqrt(h2);
+        if (lane == i + 1) e = h2 * hinv;
+        s = f * hinv;
+        c = g * hinv;
+        g = di1 - p;
+        const double r2 = fma(di - g, s, 2.0 * c * b);
+        p = s * r2;
+        if (lane == i + 1) d = g + p;
+        g = fma(c, r2, -b);
+        if (lane < m) {
+          const double z0 = Z[lane][i], z1 = Z[lane][i + 1];
+          Z[lane][i + 1] = fma(s, z0, c * z1);
+          Z[lane][i] = fma(c, z0, -s * z1);
+        }
+      }
+      if (underflow) continue;
+      if (lane == l) { d -= p; e = g; }
+      if (lane == mm) e = 0.0;
+    }
+  }
+  if (failed && lane == 0) atomicOr(flag, 1);
+  if (lane < m) lam[off + lane] = d;
+  // eigenvector i of the leaf = column i of Z -> row off + i of Qt (the rest of the row is zero: memset)
+  for (int i = 0; i < m; ++i)
+    if (lane < m) Qt[(size_t)(off + i) * n + off + lane] = Z[lane][i];
+}
+
+// ------------------------------------------------------------------------------------
+// merge, part 1: sort, deflate, secular roots.  grid (merges of the level, slices of DC_RS roots); every
+// slice repeats the (deterministic) sort + deflation and solves its own roots; slice 0 also writes the lists
+// dc_merge_vectors_kernel needs.
+//   lam_in / Qt_in: eigenvalues / eigenvector rows of the two children (rows off .. off + nn)
+//   meta (ints per merge, stride 4): k, number of rotations
+//   keep[off + i]   child row of kept slot i (ascending d);      defl[off + t] child row of deflated slot t
+//   dk / zk[off+i]  poles and weights of the secular problem;    lam_out: roots, then the deflated values
+//   deltaT[(off + j) n + off + i] = d_i - lam_j
+// ------------------------------------------------------------------------------------
+struct DcRot { int p, q; double c, s; };
+
+__global__ __launch_bounds__(256) void dc_merge_roots_kernel(const double *__restrict__ lam_in,
+                                                             const double *__restrict__ Qt_in,
+                                                             const double *__restrict__ ee, int n, int depth,
+                                                             double *__restrict__ lam_out, double *__restrict__ deltaT,
+                                                             int *__restrict__ meta, int *__restrict__ keep,
+                                                             int *__restrict__ defl, double *__restrict__ dkg,
+                                                             double *__restrict__ zkg, DcRot *__restrict__ rots,
+                                                             int *__restrict__ flag) {
+  __shared__ double ds[DC_NMAX], zs[DC_NMAX];
+  __shared__ int orig[DC_NMAX];
+  __shared__ int kidx[DC_NMAX], didx[DC_NMAX];
+  __shared__ double redd[8];
+  __shared__ int sh_k, sh_nd, sh_nrot, sh_need;
+  __shared__ int wcnt[4][2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int mg = blockIdx.x, slice = blockIdx.y;
+  int off, nn;
+  dc_segment(n, depth, mg, off, nn);
+  const int n1 = nn / 2;
+  const double emid = ee[off + n1 - 1];
+  const double rho = 2.0 * fabs(emid);
+  const double sgn = emid >= 0.0 ? 1.0 : -1.0;
+  // ---- z and d of the children, rank sort ascending (ties by child row) ----
+  double dv[DC_NMAX / 256], zv[DC_NMAX / 256];
+#pragma unroll
+  for (int q = 0; q < DC_NMAX / 256; ++q) {
+    const int c = t + 256 * q;
+    dv[q] = 0.0; zv[q] = 0.0;
+    if (c < nn) {
+      dv[q] = lam_in[off + c];
+      const double zr = c < n1 ? Qt_in[(size_t)(off + c) * n + off + n1 - 1] : sgn * Qt_in[(size_t)(off + c) * n + off + n1];
+      zv[q] = zr * 0.70710678118654752440;
+      ds[c] = dv[q];          // unsorted copy for the ranking
+    }
+  }
+  __syncthreads();
+  int rk[DC_NMAX / 256];
+#pragma unroll
+  for (int q = 0; q < DC_NMAX / 256; ++q) {
+    const int c = t + 256 * q;
+    int rank = 0;
+    if (c < nn) {
+      const double mine = dv[q];
+      for (int o = 0; o < nn; ++o) {
+        const double other = ds[o];
+        rank += (other < mine || (other == mine && o < c)) ? 1 : 0;
+      }
+    }
+    rk[q] = rank;
+  }
+  __syncthreads();
+  double dmax = 0.0, zmax = 0.0;
+#pragma unroll
+  for (int q = 0; q < DC_NMAX / 256; ++q) {
+    const int c = t + 256 * q;
+    if (c < nn) {
+      ds[rk[q]] = dv[q];
+      zs[rk[q]] = zv[q];
+      orig[rk[q]] = c;
+      dmax = fmax(dmax, fabs(dv[q]));
+      zmax = fmax(zmax, fabs(zv[q]));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    dmax = fmax(dmax, __shfl_xor(dmax, o));
+    zmax = fmax(zmax, __shfl_xor(zmax, o));
+  }
+  if (lane == 0) { redd[wave] = dmax; redd[4 + wave] = zmax; }
+  if (t == 0) { sh_need = 0; sh_nrot = 0; }
+  __syncthreads();
+  dmax = fmax(fmax(redd[0], redd[1]), fmax(redd[2], redd[3]));
+  zmax = fmax(fmax(redd[4], redd[5]), fmax(redd[6], redd[7]));
+  const double tol = 8.0 * DC_EPS * fmax(dmax, zmax);
+  int k = 0, nd = 0;
+  if (rho * zmax <= tol) {
+    // nothing couples: every child pair is an eigenpair of the merged problem
+    for (int i = t; i < nn; i += 256) didx[i] = i;
+    k = 0; nd = nn;
+    __syncthreads();
+  } else {
+    // ---- can any neighbouring pair of coupled entries be rotated?  (if not, deflation is the type-1 test alone) ----
+    for (int i = t; i < nn; i += 256) {
+      if (rho * fabs(zs[i]) > tol) {
+        int p = i - 1;
+        while (p >= 0 && rho * fabs(zs[p]) <= tol) --p;
+        if (p >= 0) {
+          const double zi = zs[i], zp = zs[p];
+          const double cs = zi * zp / (zi * zi + zp * zp);
+          if (fabs((ds[i] - ds[p]) * cs) <= tol) sh_need = 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (!sh_need) {
+      // compaction by ballots: kept entries ascending, deflated entries ascending
+      int basek = 0, based = 0;
+      for (int i0 = 0; i0 < nn; i0 += 256) {
+        const int i = i0 + t;
+        const bool valid = i < nn;
+        const bool kp = valid && rho * fabs(zs[i]) > tol;
+        const bool df = valid && !kp;
+        const unsigned long long mk = __ballot(kp), md = __ballot(df);
+        if (lane == 0) { wcnt[wave][0] = __popcll(mk); wcnt[wave][1] = __popcll(md); }
+        __syncthreads();
+        int pk = basek, pd = based;
+        for (int w = 0; w < wave; ++w) { pk += wcnt[w][0]; pd += wcnt[w][1]; }
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (kp) kidx[pk + __popcll(mk & below)] = i;
+        if (df) didx[pd + __popcll(md & below)] = i;
+        basek += wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0];
+        based += wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
+        __syncthreads();
+      }
+      k = basek; nd = based;
+    } else {
+      // ---- sequential scan (dlaed2): rotate z_pj into z_i when that perturbs the matrix by <= tol ----
+      if (t == 0) {
+        int kk = 0, dn = 0, nr = 0, pj = -1;
+        for (int i = 0; i < nn; ++i) {
+          if (rho * fabs(zs[i]) <= tol) { didx[dn++] = i; continue; }
+          if (pj < 0) { pj = i; continue; }
+          const double zp = zs[pj], zi = zs[i];
+          const double tau = sqrt(zp * zp + zi * zi);
+          const double c = zi / tau, s = -zp / tau;
+          if (fabs((ds[i] - ds[pj]) * c * s) <= tol) {
+            zs[i] = tau;
+            zs[pj] = 0.0;
+            const double dp = ds[pj] * c * c + ds[i] * s * s;
+            const double di = ds[pj] * s * s + ds[i] * c * c;
+            ds[pj] = dp;
+            ds[i] = di;
+            if (slice == 0) {
+              DcRot rt;
+              rt.p = orig[pj]; rt.q = orig[i]; rt.c = c; rt.s = s;
+              rots[off + nr] = rt;
+            }
+            nr++;
+            didx[dn++] = pj;
+            pj = i;
+          } else {
+            kidx[kk++] = pj;
+            pj = i;
+          }
+        }
+        kidx[kk++] = pj;
+        sh_k = kk; sh_nd = dn; sh_nrot = nr;
+      }
+      __syncthreads();
+      k = sh_k; nd = sh_nd;
+    }
+  }
+  const int nrot = sh_nrot;
+  // ---- lists for the second kernel ----
+  if (slice == 0) {
+    if (t == 0) { meta[4 * mg] = k; meta[4 * mg + 1] = nrot; }
+    for (int i = t; i < k; i += 256) {
+      keep[off + i] = orig[kidx[i]];
+      dkg[off + i] = ds[kidx[i]];
+      zkg[off + i] = zs[kidx[i]];
+    }
+    for (int i = t; i < nd; i += 256) {
+      defl[off + i] = orig[didx[i]];
+      lam_out[off + k + i] = ds[didx[i]];
+    }
+  }
+  if (slice * DC_RS >= k) return;
+  __syncthreads();
+  // compact poles / weights (reuse the rank-sort scratch: dv is dead)
+  double *dk = ds, *z2 = zs;
+  {
+    double tmpd[DC_NMAX / 256], tmpz[DC_NMAX / 256];
+#pragma unroll
+    for (int q = 0; q < DC_NMAX / 256; ++q) {
+      const int i = t + 256 * q;
+      tmpd[q] = 0.0; tmpz[q] = 0.0;
+      if (i < k) { tmpd[q] = ds[kidx[i]]; tmpz[q] = zs[kidx[i]]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DC_NMAX / 256; ++q) {
+      const int i = t + 256 * q;
+      if (i < k) { dk[i] = tmpd[q]; z2[i] = tmpz[q] * tmpz[q]; }
+    }
+    __syncthreads();
+  }
+  // ---- secular roots: DC_G lanes per root ----
+  const int g = t & (DC_G - 1);
+  const int j = slice * DC_RS + (t / DC_G);
+  const bool active = j < k;
+  const int jj = active ? j : k - 1;          // inactive groups shadow the last root (results discarded)
+  const int jn = jj + 1 < k ? jj + 1 : k - 1;
+  const bool last = jj == k - 1;
+  auto gsum = [&](double x) {
+    x += dpp_f64<0xB1>(x);
+    x += dpp_f64<0x4E>(x);
+    x += dpp_f64<0x141>(x);
+    return x;
+  };
+  double zz = 0.0;
+  for (int i = g; i < k; i += DC_G) zz += z2[i];
+  zz = gsum(zz);
+  const double dj = dk[jj];
+  const double gap = last ? rho * zz : dk[jn] - dj;
+  const double mid = 0.5 * gap;
+  int org = jj;
+  double lo = 0.0, hi = mid, mu;
+  if (k == 1) {
+    mu = rho * z2[0];
+    lo = hi = mu;
+  } else {
+    if (!last) {
+      double f = 0.0;
+      for (int i = g; i < k; i += DC_G) f += z2[i] * dc_rcp((dk[i] - dj) - mid);
+      f = fma(rho, gsum(f), 1.0);
+      if (!(f >= 0.0)) { org = jn; lo = -mid; hi = 0.0; }
+    } else {
+      hi = gap;
+    }
+    mu = last ? 0.5 * gap : (org == jj ? 0.5 * hi : 0.5 * lo);
+  }
+  const double dorg = dk[org];
+  const double polea = dj - dorg, poleb = dk[jn] - dorg;
+  bool done = k == 1;
+  int it = 0;
+  for (; it < 100; ++it) {
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+    double psi = 0.0, phi = 0.0, dpsi = 0.0, dphi = 0.0;
+    for (int i = g; i < k; i += DC_G) {
+      const double inv = dc_rcp((dk[i] - dorg) - mu);
+      const double tq = z2[i] * inv, tq2 = tq * inv;
+      if (i <= jj) { psi += tq; dpsi += tq2; }
+      else { phi += tq; dphi += tq2; }
+    }
+    psi = rho * gsum(psi); phi = rho * gsum(phi);
+    dpsi = rho * gsum(dpsi); dphi = rho * gsum(dphi);
+    const double gv = 1.0 + psi + phi;
+    if (!done) {
+      const bool fin = fabs(gv) <= 1.7976931348623157e308;
+      if (fin) { if (gv > 0.0) hi = mu; else lo = mu; }
+      if (!fin || fabs(gv) <= 8.0 * DC_EPS * (1.0 + fabs(psi) + fabs(phi))) done = true;
+      if (hi - lo <= 2.0 * DC_EPS * fmax(fabs(lo), fabs(hi))) done = true;
+    }
+    if (!done) {
+      const double a = polea - mu, b = poleb - mu;
+      const double s_psi = dpsi * a * a, r_psi = psi - dpsi * a;
+      double eta;
+      if (last) {
+        eta = a + s_psi * dc_rcp(1.0 + r_psi);
+      } else {
+        const double s_phi = dphi * b * b, r_phi = phi - dphi * b;
+        const double c = 1.0 + r_psi + r_phi;
+        const double B = c * (a + b) + s_psi + s_phi;
+        const double C = a * b * gv;
+        const double disc = fmax(B * B - 4.0 * c * C, 0.0);
+        const double sq = sqrt(disc);
+        const double q = 0.5 * (B + (B >= 0.0 ? sq : -sq));
+        const double e1 = q / c, e2 = C / q;
+        const bool in1 = e1 > a && e1 < b, in2 = e2 > a && e2 < b;
+        eta = in1 ? e1 : e2;
+        if (in1 && in2 && fabs(e2) < fabs(e1)) eta = e2;
+      }
+      double cand = mu + eta;
+      if (!(cand > lo && cand < hi)) cand = 0.5 * (lo + hi);
+      mu = cand;
+    }
+  }
+  if (!done) atomicOr(flag, 2);
+  if (active) {
+    for (int i = g; i < k; i += DC_G) deltaT[(size_t)(off + j) * n + off + i] = (dk[i] - dorg) - mu;
+    if (g == 0) lam_out[off + j] = dorg + mu;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// merge, part 2 (one workgroup per merge): apply the deflation rotations to the children's eigenvector rows,
+// Gu-Eisenstat z, normalised eigenvectors of the rank-one update -> UmatT[out row][child row] of the level
+// (the dense GEMM Qt_out = UmatT Qt_in then forms the merged eigenvectors; UmatT is zeroed by the host).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dc_merge_vectors_kernel(double *__restrict__ Qt_in, int n, int depth,
+                                                                const double *__restrict__ deltaT,
+                                                                const int *__restrict__ meta,
+                                                                const int *__restrict__ keep,
+                                                                const int *__restrict__ defl,
+                                                                const double *__restrict__ dkg,
+                                                                const double *__restrict__ zkg,
+                                                                const DcRot *__restrict__ rots,
+                                                                double *__restrict__ UmatT) {
+  __shared__ double dk[DC_NMAX], zh[DC_NMAX];
+  __shared__ int kp[DC_NMAX];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int mg = blockIdx.x;
+  int off, nn;
+  dc_segment(n, depth, mg, off, nn);
+  const int k = meta[4 * mg], nrot = meta[4 * mg + 1];
+  for (int rix = 0; rix < nrot; ++rix) {
+    const DcRot rt = rots[off + rix];
+    double *rp = Qt_in + (size_t)(off + rt.p) * n + off, *rq = Qt_in + (size_t)(off + rt.q) * n + off;
+    for (int c = t; c < nn; c += 1024) {
+      const double qp = rp[c], qq = rq[c];
+      rp[c] = fma(rt.c, qp, rt.s * qq);
+      rq[c] = fma(-rt.s, qp, rt.c * qq);
+    }
+  }
+  for (int i = t; i < k; i += 1024) { dk[i] = dkg[off + i]; kp[i] = keep[off + i]; }
+  __syncthreads();
+  for (int i = t; i < k; i += 1024) {
+    const double di = dk[i];
+    double prod = 1.0;
+    for (int j = 0; j < k; ++j) {
+      const double num = -deltaT[(size_t)(off + j) * n + off + i];          // lam_j - d_i
+      const double den = j == i ? 1.0 : dk[j] - di;
+      prod *= num / den;
+    }
+    const double z = sqrt(fabs(prod));
+    zh[i] = zkg[off + i] >= 0.0 ? z : -z;
+  }
+  __syncthreads();
+  for (int j = wave; j < k; j += 16) {
+    const double *drow = deltaT + (size_t)(off + j) * n + off;
+    double ss = 0.0;
+    for (int i = lane; i < k; i += 64) {
+      const double u = zh[i] / drow[i];
+      ss = fma(u, u, ss);
+    }
+    ss = wave_sum_f64(ss);
+    const double inv = dc_rsqrt(ss);
+    double *urow = UmatT + (size_t)(off + j) * n + off;
+    for (int i = lane; i < k; i += 64) urow[kp[i]] = zh[i] / drow[i] * inv;
+  }
+  for (int i = t; i < nn - k; i += 1024) UmatT[(size_t)(off + k + i) * n + off + defl[off + i]] = 1.0;
+}
+
+// ------------------------------------------------------------------------------------
+// back-transformation: eigenvector rows y <- H_0 H_1 ... H_{n-3} y, H_j = I - tau_j v_j v_j^T (v_j = row j of Vh)
+// one wave per row; eigenvalues are unscaled on the way
+// ------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void householder_rows_kernel(const double *__restrict__ Qt, int n,
+                                                               const double *__restrict__ Vh,
+                                                               const double *__restrict__ tau,
+                                                               const double *__restrict__ lam_in,
+                                                               const double *__restrict__ scale,
+                                                               double *__restrict__ Vout, double *__restrict__ lam_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  double y[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const int c = lane + 64 * q;
+    y[q] = c < n ? Qt[(size_t)row * n + c] : 0.0;
+  }
+  double v[E], vn[E];
+  auto loadv = [&](int j, double *dst) {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int c = lane + 64 * q;
+      dst[q] = (c < n && c > j) ? Vh[(size_t)j * n + c] : 0.0;
+    }
+  };
+  if (n >= 3) loadv(n - 3, v);
+  for (int j = n - 3; j >= 0; --j) {
+    const double tj = tau[j];
+    if (j > 0) loadv(j - 1, vn);
+    if (tj != 0.0) {
+      double dot = 0.0;
+#pragma unroll
+      for (int q = 0; q < E; ++q) dot = fma(v[q], y[q], dot);
+      dot = wave_sum_f64(dot) * tj;
+#pragma unroll
+      for (int q = 0; q < E; ++q) y[q] = fma(-dot, v[q], y[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = vn[q];
+  }
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const int c = lane + 64 * q;
+    if (c < n) Vout[(size_t)row * n + c] = y[q];
+  }
+  if (lane == 0) lam_out[row] = lam_in[row] * scale[1];
+}
+
+}  // namespace
+
+// eig_sort_kernel of linalg.hip (rank sort descending, optional floor at zero, row permutation)
+int eig_sort_rows(plda_handle *h, const double *lam, const double *V, int D, double *s, double *Vsorted);
+
+// Returns PLDA_OK with *status = 0 when the decomposition is in s / Vrows, *status != 0 when the direct method
+// gave up (non-finite input, an iteration cap): the caller then falls back to the Jacobi solver.  G is not modified.
+int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vrows, int *status) {
+  *status = 0;
+  if (D > DC_NMAX) { *status = 8; return PLDA_OK; }
+  const int n = D;
+  const size_t DD = (size_t)n * n;
+  // workspace: Vh, QtA, QtB, UmatT, deltaT (n^2 each), then vectors and lists
+  const size_t vec = (size_t)round_up(n, 32);
+  const size_t need = DD * 8 * 5 + vec * 8 * 14 + vec * 4 * 5 + vec * sizeof(DcRot) + 4096;
+  PLDA_HIP(h, h->eigdc.reserve(need));
+  double *Vh = h->eigdc.as<double>();
+  double *QtA = Vh + DD, *QtB = QtA + DD, *UmatT = QtB + DD, *deltaT = UmatT + DD;
+  double *dd = deltaT + DD, *ee = dd + vec, *tau = ee + vec, *lamA = tau + vec, *lamB = lamA + vec;
+  double *dkg = lamB + vec, *zkg = dkg + vec, *lamU = zkg + vec, *scale = lamU + vec;   // scale: 2 doubles
+  double *Pg = scale + vec, *Cg = Pg + 2 * vec;                                         // all-gather buffers, two step parities
+  int *keep = reinterpret_cast<int *>(Cg + 2 * vec);
+  int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
+  int *trflags = flag + vec;
+  DcRot *rots = reinterpret_cast<DcRot *>(trflags + vec);
+  PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  eig_scale_kernel<<<1, 1024, 0, h->stream>>>(G, n, scale, flag);
+  // tridiagonalisation: one workgroup with the matrix in registers while that fits without spilling (n <= 160),
+  // else rows over ceil(n / 8) cooperating workgroups (PLDA_EIG_VARIANT=2 / 3 force one or the other)
+  const bool reg_kernel = h->eig_variant == 2 ? n <= 256 : (h->eig_variant == 3 ? false : n <= 160);
+  if (reg_kernel) {
+    const int nb = (int)ceil_div(n, 32);
+#define TR(NBB) tridiag_reg_kernel<NBB><<<1, 1024, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
+    switch (nb) {
+      case 1: TR(1); break;
+      case 2: TR(2); break;
+      case 3: TR(3); break;
+      case 4: TR(4); break;
+      case 5: TR(5); break;
+      case 6: TR(6); break;
+      case 7: TR(7); break;
+      default: TR(8); break;
+    }
+#undef TR
+  } else {
+    int W = (int)ceil_div(n, TR_ROWS);
+    const size_t lds = ((size_t)TR_ROWS + 5) * n * sizeof(double);
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&tridiag_rows_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PLDA_HIP(h, hipMemsetAsync(trflags, 0, (size_t)W * sizeof(int), h->stream));
+    int nn = n;
+    const double *Gp = G;
+    const double *scp = scale;
+    void *args[] = {&Gp, &nn, &W, &scp, &dd, &ee, &Vh, &tau, &Pg, &Cg, &trflags};
+    PLDA_HIP(h, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&tridiag_rows_kernel), dim3(W), dim3(256), args,
+                                           lds, h->stream));
+  }
+  PLDA_LAUNCH_CHECK(h);
+  int depth = 0;
+  while ((int)ceil_div(n, 1 << depth) > DC_LEAF) depth++;
+  PLDA_HIP(h, hipMemsetAsync(QtA, 0, DD * 8, h->stream));
+  dc_leaf_kernel<<<1 << depth, 64, 0, h->stream>>>(dd, ee, n, depth, lamA, QtA, flag);
+  PLDA_LAUNCH_CHECK(h);
+  double *qin = QtA, *qout = QtB, *lin = lamA, *lout = lamB;
+  for (int dl = depth - 1; dl >= 0; --dl) {
+    const int merges = 1 << dl;
+    const int maxn = (int)ceil_div(n, merges);
+    const int slices = (int)ceil_div(maxn, DC_RS);
+    PLDA_HIP(h, hipMemsetAsync(UmatT, 0, DD * 8, h->stream));
+    dc_merge_roots_kernel<<<dim3(merges, slices), 256, 0, h->stream>>>(lin, qin, ee, n, dl, lout, deltaT, meta, keep,
+                                                                        defl, dkg, zkg, rots, flag);
+    dc_merge_vectors_kernel<<<merges, 1024, 0, h->stream>>>(qin, n, dl, deltaT, meta, keep, defl, dkg, zkg, rots, UmatT);
+    PLDA_LAUNCH_CHECK(h);
+    PLDA_TRY(gemm_f64(h, n, n, n, 1.0, UmatT, n, 1, qin, n, 1, nullptr, 0.0, qout, n));
+    std::swap(qin, qout);
+    std::swap(lin, lout);
+  }
+  {
+    const int E = (int)ceil_div(n, 64);
+    const unsigned grid = (unsigned)ceil_div(n, 4);
+#define HR(EE) householder_rows_kernel<EE><<<grid, 256, 0, h->stream>>>(qin, n, Vh, tau, lin, scale, qout, lamU)
+    if (E <= 1) HR(1);
+    else if (E <= 2) HR(2);
+    else if (E <= 4) HR(4);
+    else if (E <= 8) HR(8);
+    else HR(16);
+#undef HR
+  }
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_TRY(eig_sort_rows(h, lamU, qout, n, s, Vrows));
+  int hflag = 0;
+  PLDA_HIP(h, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  *status = hflag;
+  return PLDA_OK;
+}
+
+}  // namespace plda

@@ -1202,6 +1202,12 @@ __global__ void eig_sort_kernel(const double *__restrict__ lam, const double *__
   for (int d = threadIdx.x; d < D; d += blockDim.x) Vsorted[(size_t)r * D + d] = V[(size_t)p * D + d];
 }
 
+int eig_sort_rows(plda_handle *h, const double *lam, const double *V, int D, double *s, double *Vsorted) {
+  eig_sort_kernel<<<D, 64, 0, h->stream>>>(lam, V, D, s, Vsorted, !h->eig_keep_sign);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 // One sweep = nb_even - 1 outer rounds; its launches are captured once into a hipGraph
 // (per handle, re-captured when D or the buffers change) and replayed.
 static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, double tol, int *drot) {
@@ -1357,8 +1363,15 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
   symmetrize_kernel<<<(unsigned)ceil_div((int64_t)DD, 256), 256, 0, h->stream>>>(G, D);
   PLDA_LAUNCH_CHECK(h);
-  PLDA_TRY(sym_eig_f64(h, G, D, psi, warm ? tmp : Vr, nullptr, warm ? Vr : nullptr));
-  if (warm) PLDA_HIP(h, hipMemcpyAsync(Vr, tmp, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+  // direct method first (cold starts: the closed-form EM never diagonalises, so GetOutput always starts cold);
+  // block Jacobi when it declines (D > its limit, an iteration cap) or for warm starts of the per-iteration EM arm
+  int dc_status = 1;
+  if (!warm && h->eig_variant != 1) PLDA_TRY(sym_eig_dc_f64(h, G, D, psi, Vr, &dc_status));
+  h->eig_last_method = dc_status == 0 ? 2 : 1;
+  if (dc_status != 0) {
+    PLDA_TRY(sym_eig_f64(h, G, D, psi, warm ? tmp : Vr, nullptr, warm ? Vr : nullptr));
+    if (warm) PLDA_HIP(h, hipMemcpyAsync(Vr, tmp, DD * 8, hipMemcpyDeviceToDevice, h->stream));
+  }
   h->simdiag_has_vr = true;
   // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = T^-1 = W T^T (from T W T^T = I)
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));

@@ -378,6 +378,17 @@ class MPlda(object):
     def synchronize(self):
         self._ck(self._lib.plda_synchronize(self._h))
 
+    def sym_eig(self, G, method=0):
+        """Eigen-decomposition of a symmetric matrix by the GetOutput eigensolver (diagnostics / tests):
+        (eigenvalues descending, eigenvectors in ROWS, method used: 1 = block Jacobi, 2 = direct)."""
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        if G.ndim != 2 or G.shape[0] != G.shape[1]:
+            raise ValueError("sym_eig: square matrix expected")
+        d = G.shape[0]
+        lam, vec, used = np.zeros(d), np.zeros((d, d)), C.c_int32(0)
+        self._ck(self._lib.plda_sym_eig(self._h, _ptr(G), d, int(method), _ptr(lam), _ptr(vec), C.byref(used)))
+        return lam, vec, used.value
+
     def profile_enable(self, on=True):
         self._ck(self._lib.plda_profile_enable(self._h, 1 if on else 0))
 
