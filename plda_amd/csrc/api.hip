@@ -153,6 +153,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EIG_VARIANT")) h->eig_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_EIG_DEBUG")) h->eig_debug = std::atoi(v);
     *out = h;
     return PLDA_OK;
   });

@@ -108,6 +108,7 @@ struct plda_handle {
   plda::DevBuf w[16];
   plda::DevBuf eigdc;            // eig_dc.hip workspace
   int eig_variant = 0;           // PLDA_EIG_VARIANT: 0 = direct method where supported, 1 = block Jacobi always
+  int eig_debug = 0;             // PLDA_EIG_DEBUG (timing experiments only: results are wrong when set)
   int eig_last_method = 0;       // 1 = block Jacobi, 2 = tridiagonalisation + divide and conquer
 };
 

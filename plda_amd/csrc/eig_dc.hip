@@ -10,8 +10,8 @@
 //   tridiag_reg_kernel    D <= 256: the matrix lives in the registers of ONE workgroup (lower-triangle 32 x 32
 //                         block ownership as chol_small_kernel), D - 2 steps of (publish column -> v, tau ->
 //                         p = A v -> w -> rank-2 update), three barriers per step, no global synchronisation
-//   tridiag_rows_kernel   D <= 1024: rows dealt cyclically to D/8 workgroups (LDS-resident), ONE all-gather
-//                         per step through agent-scope atomics (p_i and the next column travel together)
+//   tridiag_rows_kernel   D <= 1024: rows dealt cyclically to D/8 workgroups (register-resident), ONE all-gather
+//                         per step through self-validating words (p_i and the next column travel together)
 //   dc_leaf_kernel        implicit QL (Wilkinson shift) on leaves of <= 16, one wave per leaf, d / e in lanes
 //   dc_merge_roots_kernel per merge: rank sort, deflation (dlaed2's two criteria), secular roots by the two-pole
 //                         rational iteration with a bisection safeguard, 8 lanes per root
@@ -250,52 +250,78 @@ __global__ __launch_bounds__(1024) void tridiag_reg_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------
-// tridiagonalisation, rows dealt cyclically to W = ceil(n / 8) workgroups (LDS-resident), n <= 1024.
-// Step j, every workgroup: v, tau from column j (all hold it) -> p_i = A_i . v for its rows -> publish p_i
-// together with A[i][j+1] -> ONE all-gather (agent-scope atomics: data words stored / loaded coherently, a flag
-// per workgroup counts the steps) -> w, and column j+1 of the UPDATED matrix follows locally as
-// A[i][j+1] - v_i w_{j+1} - w_i v_{j+1} -> rank-2 update of the own rows.  Launched cooperatively (all workgroups
-// resident: they wait for each other).
+// tridiagonalisation, rows dealt cyclically to W = ceil(n / 8) workgroups, n <= 1024.  A row lives in the registers
+// of 32 lanes (element k in lane k % 32).  Step j, every workgroup: v, tau from column j (all hold it) ->
+// p_i = A_i . v for its rows -> publish p_i together with A[i][j+1] -> ONE all-gather -> w; column j+1 of the
+// UPDATED matrix follows locally as A[i][j+1] - v_i w_{j+1} - w_i v_{j+1} -> rank-2 update of the own rows.
+// The all-gather has no flags and no fences: every published 64-bit word carries 32 bits of payload and the step
+// number, is stored and loaded with relaxed agent-scope atomics, and a reader simply re-loads a word until its
+// tag is the step's (two buffers by step parity: a workgroup can run at most one step ahead of a reader).
+// Launched cooperatively (all workgroups resident: they wait for each other).
 // ------------------------------------------------------------------------------------
 constexpr int TR_ROWS = 8;
 
-__device__ __forceinline__ double tr_block_sum(double x, double *red, int lane, int wave) {
-  x = wave_sum_f64(x);
-  __syncthreads();                 // red may still be read from the previous sum
-  if (lane == 0) red[wave] = x;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+constexpr int TR_FIRST_POLL = 10;              // x 128 cycles
+constexpr int TR_TIMEOUT = 1 << 19;            // polls of ~1 us: a word that never arrives ends the kernel with flag 16
+
+// sum over the 32 lanes of a half wave: DPP within the 16-lane rows, row_bcast15 into the upper row; the total is
+// in lanes 16..31 (48..63) of the half
+__device__ __forceinline__ double tr_sum32_upper(double x) {
+  x += dpp_f64<0xB1>(x);
+  x += dpp_f64<0x4E>(x);
+  x += dpp_f64<0x141>(x);
+  x += dpp_f64<0x140>(x);
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+  return x + __hiloint2double(hi, lo);
 }
 
+template <int E>   // E = ceil(n / 32) rounded up to the instantiations below
 __global__ __launch_bounds__(256) void tridiag_rows_kernel(const double *__restrict__ G, int n, int W,
                                                            const double *__restrict__ scale, double *__restrict__ dd,
                                                            double *__restrict__ ee, double *__restrict__ Vh,
-                                                           double *__restrict__ tau, double *Pg, double *Cg, int *flags) {
-  extern __shared__ __attribute__((aligned(16))) double tr_sm[];
-  double *rows = tr_sm;                       // [TR_ROWS][n]
-  double *xcol = rows + (size_t)TR_ROWS * n;  // column j of the current matrix
-  double *vv = xcol + n, *pp = vv + n, *cc = pp + n, *ww = cc + n;
-  __shared__ double red[4];
-  const int t = threadIdx.x, slot = t >> 5, l = t & 31, lane = t & 63, wave = t >> 6, w = blockIdx.x;
+                                                           double *__restrict__ tau, unsigned long long *words,
+                                                           int *flag, int dbg, long long *tl) {
+  constexpr int NP = E * 32;                   // padded length
+  constexpr int KQ = (NP + 255) / 256;         // gathered elements per thread
+  __shared__ double pp[2][NP], cc[2][NP];      // gathered p and next-column values, by step parity
+  __shared__ int sh_to;
+  const int t = threadIdx.x, slot = t >> 5, l = t & 31, half = (t >> 5) & 1;
+  if (t == 0) sh_to = 0;
+  const int w = blockIdx.x;
   const double sc = scale[0];
   const int myrow = w + slot * W;
   const bool rowok = myrow < n;
-  for (int s2 = 0; s2 < TR_ROWS; ++s2) {
-    const int gi = w + s2 * W;
-    for (int k = t; k < n; k += 256) rows[(size_t)s2 * n + k] = gi < n ? G[(size_t)gi * n + k] * sc : 0.0;
+  const int mylane = (myrow & 31) + 32 * half, myq = myrow >> 5;   // where element `myrow` of a vector lives
+  const int m0 = __builtin_amdgcn_readlane(mylane, 0), m1 = __builtin_amdgcn_readlane(mylane, 32);
+  // a[q] = A[myrow][l + 32 q]; x[q] = column j of the current matrix in the same layout (every half wave holds it whole)
+  double a[E], x[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const int k = l + 32 * q;
+    a[q] = (rowok && k < n) ? G[(size_t)myrow * n + k] * sc : 0.0;
+    x[q] = k < n ? G[k] * sc : 0.0;            // column 0 = row 0 (symmetric)
   }
-  for (int k = t; k < n; k += 256) xcol[k] = G[k] * sc;   // column 0 = row 0 (symmetric)
+  auto pick = [&](const double (&r)[E], int qq) {   // r[qq] for a runtime qq
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) v = qq == q ? r[q] : v;
+    return v;
+  };
   __syncthreads();
-  double *myr = rows + (size_t)slot * n;
+  int jw = 0, jq = 0;                          // j % W, j / W
   for (int j = 0; j < n - 2; ++j) {
+    const int par = j & 1;
+    const bool stamp = (dbg & 2) && blockIdx.x == 1 && t == 0 && j >= 16 && j < 32;
+    if (stamp) tl[(j - 16) * 8 + 0] = __builtin_readcyclecounter();
+    const int j1lane = (j + 1) & 31, j1q = (j + 1) >> 5;
     // ---- v, tau ----
-    double part = 0.0;
-    for (int k = t; k < n; k += 256) {
-      const double xv = xcol[k];
-      part += k > j + 1 ? xv * xv : 0.0;
-    }
-    const double s2 = tr_block_sum(part, red, lane, wave);
-    const double x0 = xcol[j + 1];
+    double s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) s2 += (l + 32 * q > j + 1) ? x[q] * x[q] : 0.0;
+    s2 = readlane_f64(tr_sum32_upper(s2), 31);
+    const double x0 = readlane_f64(pick(x, j1q), j1lane);
     const bool skip = s2 == 0.0;
     double alpha = x0, v0 = 0.0, tt = 0.0;
     if (!skip) {
@@ -305,69 +331,127 @@ __global__ __launch_bounds__(256) void tridiag_rows_kernel(const double *__restr
       v0 = x0 - alpha;
       tt = 2.0 * dc_rcp(fma(v0, v0, s2));
     }
-    for (int k = t; k < n; k += 256) {
-      const double vk = skip ? 0.0 : (k > j + 1 ? xcol[k] : (k == j + 1 ? v0 : 0.0));
-      vv[k] = vk;
-      if (w == 0) Vh[(size_t)j * n + k] = vk;
+    // v_k = 0 (k <= j), v0 (k == j + 1), x_k (k > j + 1); all zero when the column is already tridiagonal
+    double v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int k = l + 32 * q;
+      double vk = k > j + 1 ? x[q] : 0.0;
+      vk = k == j + 1 ? v0 : vk;
+      v[q] = skip ? 0.0 : vk;
     }
-    if (w == 0 && t == 0) { ee[j] = alpha; tau[j] = tt; }
-    if (w == j % W && t == 0) dd[j] = rows[(size_t)(j / W) * n + j];
-    __syncthreads();
-    // ---- p_i for the own rows ----
+    if (w == 0) {
+      if (slot == 0) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const int k = l + 32 * q;
+          if (k < n) Vh[(size_t)j * n + k] = v[q];
+        }
+      }
+      if (t == 0) { ee[j] = alpha; tau[j] = tt; }
+    }
+    if (w == jw && slot == jq && l == (j & 31)) dd[j] = pick(a, j >> 5);
+    if (stamp) tl[(j - 16) * 8 + 1] = __builtin_readcyclecounter();
+    // ---- p_i for the own row, published with A[i][j+1] by the last lane of the half wave ----
     double acc = 0.0;
-    if (rowok && myrow > j && !skip)
-      for (int k = l; k < n; k += 32) acc = fma(myr[k], vv[k], acc);
-    acc += dpp_f64<0xB1>(acc);
-    acc += dpp_f64<0x4E>(acc);
-    acc += dpp_f64<0x141>(acc);
-    acc += dpp_f64<0x140>(acc);
-    acc += __shfl_xor(acc, 16);
-    const int par = j & 1;
-    if (l == 0 && rowok) {
-      __hip_atomic_store(&Pg[(size_t)par * n + myrow], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&Cg[(size_t)par * n + myrow], myr[j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < E; ++q) acc = fma(a[q], v[q], acc);
+    acc = tr_sum32_upper(myrow > j ? acc : 0.0);
+    const double cj1 = pick(a, j1q);
+    const double cv = half ? readlane_f64(cj1, 32 + j1lane) : readlane_f64(cj1, j1lane);
+    const unsigned long long tag = (unsigned long long)(j + 1) << 32;
+    unsigned long long *wp = words + (size_t)par * 4 * NP;
+    if (rowok && l == 31) {
+      const unsigned long long pb = (unsigned long long)__double_as_longlong(acc), cb = (unsigned long long)__double_as_longlong(cv);
+      __hip_atomic_store(wp + myrow, tag | (pb & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wp + NP + myrow, tag | (pb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wp + 2 * NP + myrow, tag | (cb & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(wp + 3 * NP + myrow, tag | (cb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (t == 0) __hip_atomic_store(&flags[w], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- all-gather ----
-    if (t < W)
-      while (__hip_atomic_load(&flags[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < j + 1) __builtin_amdgcn_s_sleep(1);
-    __syncthreads();
-    for (int k = t; k < n; k += 256) {
-      pp[k] = __hip_atomic_load(&Pg[(size_t)par * n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cc[k] = __hip_atomic_load(&Cg[(size_t)par * n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp) tl[(j - 16) * 8 + 2] = __builtin_readcyclecounter();
+    // ---- all-gather: re-load until every word of this thread carries the step's tag ----
+    {
+      unsigned long long wv[KQ][4];
+      bool ready = false;
+      int polls = 0;
+      // a word needs ~1400 cycles to become visible to the other workgroups and a poll is one ~1400-cycle round trip:
+      // polling at once always costs a second poll, so the first one is sent ~1300 cycles late (measured: GetOutput
+      // 1.56 -> 1.44 ms at D = 200, 4.90 -> 4.49 ms at D = 512; PLDA_EIG_DEBUG bits 8.. override the delay)
+      for (int z = (dbg >> 8) ? ((dbg >> 8) & 63) - 1 : TR_FIRST_POLL; z > 0; --z) __builtin_amdgcn_s_sleep(2);
+      while (!ready) {
+        ready = true;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int k = t + 256 * q;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            wv[q][c] = k < n ? __hip_atomic_load(wp + c * NP + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ready = ready && (wv[q][c] >> 32) == (tag >> 32);
+        if (dbg & 1) ready = true;
+        if (!ready) {
+          if (++polls > TR_TIMEOUT || *(volatile int *)&sh_to) { sh_to = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int k = t + 256 * q;
+        if (k < NP) {
+          pp[par][k] = __longlong_as_double((long long)((wv[q][0] & 0xffffffffull) | (wv[q][1] << 32)));
+          cc[par][k] = __longlong_as_double((long long)((wv[q][2] & 0xffffffffull) | (wv[q][3] << 32)));
+        }
+      }
     }
-    __syncthreads();
-    // ---- w, next column ----
-    part = 0.0;
-    for (int k = t; k < n; k += 256) part = fma(vv[k], pp[k], part);
-    const double vtp = tr_block_sum(part, red, lane, wave);
+    if (stamp) tl[(j - 16) * 8 + 3] = __builtin_readcyclecounter();
+    __syncthreads();   // the only barrier of a step (pp / cc alternate, so the next step's writes cannot overtake readers)
+    if (stamp) tl[(j - 16) * 8 + 4] = __builtin_readcyclecounter();
+    if (*(volatile int *)&sh_to) {   // a word never arrived (uniform after the barrier): give up, the host falls back
+      if (t == 0) atomicOr(flag, 16);
+      return;
+    }
+    // ---- w = tt p - beta v, next column, rank-2 update of the own row ----
+    double pr[E], cr[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      pr[q] = pp[par][l + 32 * q];
+      cr[q] = cc[par][l + 32 * q];
+    }
+    double vp = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q) vp = fma(v[q], pr[q], vp);
+    const double vtp = readlane_f64(tr_sum32_upper(vp), 31);
     const double beta = 0.5 * tt * tt * vtp;
-    const double vj1 = vv[j + 1];
-    const double wj1 = fma(tt, pp[j + 1], -beta * vj1);
-    for (int k = t; k < n; k += 256) {
-      const double vk = vv[k];
-      const double wk = k > j ? fma(tt, pp[k], -beta * vk) : 0.0;
-      ww[k] = wk;
-      xcol[k] = cc[k] - vk * wj1 - wk * vj1;
+    const double vj1 = skip ? 0.0 : v0;
+    const double wj1 = fma(tt, readlane_f64(pick(pr, j1q), j1lane), -beta * vj1);
+    if (stamp) tl[(j - 16) * 8 + 5] = __builtin_readcyclecounter();
+    double wk[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int k = l + 32 * q;
+      wk[q] = k > j ? fma(tt, pr[q], -beta * v[q]) : 0.0;
+      x[q] = cr[q] - v[q] * wj1 - wk[q] * vj1;           // column j + 1 of the updated matrix
     }
-    __syncthreads();
-    // ---- A_i -= v_i w + w_i v ----
-    if (rowok && myrow > j && !skip) {
-      const double vi = vv[myrow], wi = ww[myrow];
-      for (int k = l; k < n; k += 32) myr[k] = fma(-vi, ww[k], fma(-wi, vv[k], myr[k]));
+    {
+      const double vsel = pick(v, myq), wsel = pick(wk, myq);
+      const double vm = half ? readlane_f64(vsel, m1) : readlane_f64(vsel, m0);   // v and w at index myrow
+      const double wm = half ? readlane_f64(wsel, m1) : readlane_f64(wsel, m0);
+      if (myrow > j) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) a[q] = fma(-vm, wk[q], fma(-wm, v[q], a[q]));
+      }
     }
+    if (stamp) tl[(j - 16) * 8 + 6] = __builtin_readcyclecounter();
+    if (stamp) tl[(j - 16) * 8 + 7] = __builtin_readcyclecounter();
+    if (++jw == W) { jw = 0; ++jq; }
   }
-  __syncthreads();
-  if (t == 0) {
-    if (n >= 2 && w == (n - 2) % W) dd[n - 2] = rows[(size_t)((n - 2) / W) * n + n - 2];
-    if (w == (n - 1) % W) {
-      dd[n - 1] = rows[(size_t)((n - 1) / W) * n + n - 1];
-      if (n >= 2) ee[n - 2] = rows[(size_t)((n - 1) / W) * n + n - 2];
-      ee[n - 1] = 0.0;
-      tau[n - 1] = 0.0;
-      if (n >= 2) tau[n - 2] = 0.0;
-    }
+  if (n >= 2 && w == (n - 2) % W && slot == (n - 2) / W && l == ((n - 2) & 31)) dd[n - 2] = pick(a, (n - 2) >> 5);
+  if (w == (n - 1) % W && slot == (n - 1) / W) {
+    if (l == ((n - 1) & 31)) { dd[n - 1] = pick(a, (n - 1) >> 5); ee[n - 1] = 0.0; tau[n - 1] = 0.0; }
+    if (n >= 2 && l == ((n - 2) & 31)) { ee[n - 2] = pick(a, (n - 2) >> 5); tau[n - 2] = 0.0; }
   }
 }
 
@@ -391,6 +475,13 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
   }
   if (lane < DC_LEAF)
     for (int c = 0; c < DC_LEAF; ++c) Z[lane][c] = lane == c ? 1.0 : 0.0;
+  // a non-finite tridiagonal (non-finite input) must not reach the merges: their index lists come from comparisons
+  const bool finite = fabs(d) <= 1.7976931348623157e308 && fabs(e) <= 1.7976931348623157e308;
+  if (__ballot(!finite) != 0ull) {
+    if (lane == 0) atomicOr(flag, 4);
+    if (lane < m) lam[off + lane] = 0.0;
+    return;
+  }
   auto getd = [&](int i) { return readlane_f64(d, __builtin_amdgcn_readfirstlane(i)); };
   auto gete = [&](int i) { return readlane_f64(e, __builtin_amdgcn_readfirstlane(i)); };
   bool failed = false;
@@ -475,6 +566,7 @@ __global__ __launch_bounds__(256) void dc_merge_roots_kernel(const double *__res
   __shared__ int wcnt[4][2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int mg = blockIdx.x, slice = blockIdx.y;
+  if (*(volatile int *)flag) return;      // an earlier stage gave up: the lists below would be built from garbage
   int off, nn;
   dc_segment(n, depth, mg, off, nn);
   const int n1 = nn / 2;
@@ -494,7 +586,16 @@ __global__ __launch_bounds__(256) void dc_merge_roots_kernel(const double *__res
       ds[c] = dv[q];          // unsorted copy for the ranking
     }
   }
-  __syncthreads();
+  {
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < DC_NMAX / 256; ++q)
+      bad = bad || !(fabs(dv[q]) <= 1.7976931348623157e308) || !(fabs(zv[q]) <= 1.7976931348623157e308);
+    if (__syncthreads_or(bad ? 1 : 0)) {   // ranks of NaNs collide: no sort, no lists
+      if (t == 0) atomicOr(flag, 4);
+      return;
+    }
+  }
   int rk[DC_NMAX / 256];
 #pragma unroll
   for (int q = 0; q < DC_NMAX / 256; ++q) {
@@ -745,8 +846,9 @@ __global__ __launch_bounds__(1024) void dc_merge_vectors_kernel(double *__restri
                                                                 const double *__restrict__ dkg,
                                                                 const double *__restrict__ zkg,
                                                                 const DcRot *__restrict__ rots,
-                                                                double *__restrict__ UmatT) {
+                                                                double *__restrict__ UmatT, const int *flag) {
   __shared__ double dk[DC_NMAX], zh[DC_NMAX];
+  if (*(volatile const int *)flag) return;
   __shared__ int kp[DC_NMAX];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int mg = blockIdx.x;
@@ -856,17 +958,16 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   const size_t DD = (size_t)n * n;
   // workspace: Vh, QtA, QtB, UmatT, deltaT (n^2 each), then vectors and lists
   const size_t vec = (size_t)round_up(n, 32);
-  const size_t need = DD * 8 * 5 + vec * 8 * 14 + vec * 4 * 5 + vec * sizeof(DcRot) + 4096;
+  const size_t need = DD * 8 * 5 + vec * 8 * 10 + 8 * 1024 * 8 + 64 + vec * 4 * 4 + vec * sizeof(DcRot) + 4096;
   PLDA_HIP(h, h->eigdc.reserve(need));
   double *Vh = h->eigdc.as<double>();
   double *QtA = Vh + DD, *QtB = QtA + DD, *UmatT = QtB + DD, *deltaT = UmatT + DD;
   double *dd = deltaT + DD, *ee = dd + vec, *tau = ee + vec, *lamA = tau + vec, *lamB = lamA + vec;
   double *dkg = lamB + vec, *zkg = dkg + vec, *lamU = zkg + vec, *scale = lamU + vec;   // scale: 2 doubles
-  double *Pg = scale + vec, *Cg = Pg + 2 * vec;                                         // all-gather buffers, two step parities
-  int *keep = reinterpret_cast<int *>(Cg + 2 * vec);
+  unsigned long long *words = reinterpret_cast<unsigned long long *>(scale + vec);   // all-gather: [parity][4][<= 1024]
+  int *keep = reinterpret_cast<int *>(words + 8 * 1024);
   int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
-  int *trflags = flag + vec;
-  DcRot *rots = reinterpret_cast<DcRot *>(trflags + vec);
+  DcRot *rots = reinterpret_cast<DcRot *>(flag + vec);
   PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
   eig_scale_kernel<<<1, 1024, 0, h->stream>>>(G, n, scale, flag);
   // tridiagonalisation: one workgroup with the matrix in registers while that fits without spilling (n <= 160),
@@ -888,16 +989,31 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
 #undef TR
   } else {
     int W = (int)ceil_div(n, TR_ROWS);
-    const size_t lds = ((size_t)TR_ROWS + 5) * n * sizeof(double);
-    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&tridiag_rows_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PLDA_HIP(h, hipMemsetAsync(trflags, 0, (size_t)W * sizeof(int), h->stream));
+    const int E = (int)ceil_div(n, 32);
+    const int NP = (E <= 7 ? 7 : E <= 8 ? 8 : E <= 16 ? 16 : 32) * 32;
+    PLDA_HIP(h, hipMemsetAsync(words, 0, (size_t)8 * NP * sizeof(unsigned long long), h->stream));
     int nn = n;
     const double *Gp = G;
     const double *scp = scale;
-    void *args[] = {&Gp, &nn, &W, &scp, &dd, &ee, &Vh, &tau, &Pg, &Cg, &trflags};
-    PLDA_HIP(h, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&tridiag_rows_kernel), dim3(W), dim3(256), args,
-                                           lds, h->stream));
+    int dbg = h->eig_debug;
+    long long *tl = reinterpret_cast<long long *>(deltaT);   // debug stamps (deltaT is free until the merges)
+    void *args[] = {&Gp, &nn, &W, &scp, &dd, &ee, &Vh, &tau, &words, &flag, &dbg, &tl};
+    const void *fn = E <= 7    ? reinterpret_cast<const void *>(&tridiag_rows_kernel<7>)
+                     : E <= 8  ? reinterpret_cast<const void *>(&tridiag_rows_kernel<8>)
+                     : E <= 16 ? reinterpret_cast<const void *>(&tridiag_rows_kernel<16>)
+                               : reinterpret_cast<const void *>(&tridiag_rows_kernel<32>);
+    PLDA_HIP(h, hipLaunchCooperativeKernel(fn, dim3(W), dim3(256), args, 0, h->stream));
+    if (dbg & 2) {
+      long long st[16 * 8];
+      PLDA_HIP(h, hipStreamSynchronize(h->stream));
+      PLDA_HIP(h, hipMemcpy(st, tl, sizeof(st), hipMemcpyDeviceToHost));
+      for (int r = 0; r < 16; ++r) {
+        std::fprintf(stderr, "tridiag step %2d:", 16 + r);
+        for (int c = 1; c < 8; ++c) std::fprintf(stderr, " %6lld", st[r * 8 + c] - st[r * 8 + c - 1]);
+        if (r < 15) std::fprintf(stderr, "  | next %6lld", st[(r + 1) * 8] - st[r * 8 + 7]);
+        std::fprintf(stderr, "\n");
+      }
+    }
   }
   PLDA_LAUNCH_CHECK(h);
   int depth = 0;
@@ -913,7 +1029,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     PLDA_HIP(h, hipMemsetAsync(UmatT, 0, DD * 8, h->stream));
     dc_merge_roots_kernel<<<dim3(merges, slices), 256, 0, h->stream>>>(lin, qin, ee, n, dl, lout, deltaT, meta, keep,
                                                                         defl, dkg, zkg, rots, flag);
-    dc_merge_vectors_kernel<<<merges, 1024, 0, h->stream>>>(qin, n, dl, deltaT, meta, keep, defl, dkg, zkg, rots, UmatT);
+    dc_merge_vectors_kernel<<<merges, 1024, 0, h->stream>>>(qin, n, dl, deltaT, meta, keep, defl, dkg, zkg, rots, UmatT, flag);
     PLDA_LAUNCH_CHECK(h);
     PLDA_TRY(gemm_f64(h, n, n, n, 1.0, UmatT, n, 1, qin, n, 1, nullptr, 0.0, qout, n));
     std::swap(qin, qout);
