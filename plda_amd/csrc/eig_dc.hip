@@ -17,7 +17,7 @@
 //                         rational iteration with a bisection safeguard, 8 lanes per root
 //   dc_merge_vectors_kernel  Gu-Eisenstat z, normalised eigenvectors of D + rho z z^T -> the level's update matrix
 //   (one dense fp64 MFMA GEMM per level applies it to the eigenvector rows)
-//   householder_rows_kernel  back-transformation, one wave per eigenvector
+//   householder_T / _rows_kernel  back-transformation in compact-WY blocks of 8 reflectors, two eigenvectors per wave
 //
 // scripts/proto_dc_eig.py is the NumPy prototype of the same algorithm (same deflation rule, same iteration).
 #include <algorithm>
@@ -32,8 +32,8 @@ namespace {
 constexpr double DC_EPS = 2.220446049250313e-16;
 constexpr int DC_LEAF = 16;       // leaves have ceil(n / 2^depth) <= 16 rows
 constexpr int DC_NMAX = 1024;
-constexpr int DC_G = 8;           // lanes per secular root
-constexpr int DC_RS = 32;         // roots per workgroup of dc_merge_roots_kernel (256 threads)
+constexpr int DC_G = 16;          // lanes per secular root (one DPP row)
+constexpr int DC_RS = 16;         // roots per workgroup of dc_merge_roots_kernel (256 threads)
 
 __device__ __forceinline__ double dc_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -62,31 +62,30 @@ __host__ __device__ inline void dc_segment(int n, int depth, int idx, int &off, 
 // ------------------------------------------------------------------------------------
 // scale = 2^-floor(log2 max|g_ij|): sums of squares then neither overflow nor underflow
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void eig_scale_kernel(const double *__restrict__ G, int n, double *__restrict__ scale,
-                                                         int *__restrict__ flag) {
-  __shared__ double red[16];
+__global__ __launch_bounds__(256) void eig_absmax_kernel(const double *__restrict__ G, int n,
+                                                         unsigned long long *__restrict__ amax_bits, int *__restrict__ flag) {
   double m = 0.0;
   bool bad = false;
-  for (int i = threadIdx.x; i < n * n; i += 1024) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n * n; i += gridDim.x * 256) {
     const double x = fabs(G[i]);
     if (!(x <= 1.7976931348623157e308)) bad = true;   // NaN or inf
     m = fmax(m, x);
   }
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  const int anybad = __syncthreads_or(bad ? 1 : 0);
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
-    double s = 1.0;
-    if (m > 0.0 && !anybad) {
-      int ex;
-      (void)frexp(m, &ex);          // m = f 2^ex, f in [0.5, 1)
-      s = ldexp(1.0, 1 - ex);       // m s in [1, 2)
-    }
-    scale[0] = s;
-    scale[1] = 1.0 / s;
-    if (anybad) atomicOr(flag, 4);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(m));   // non-negative doubles order as integers
+  if (bad) atomicOr(flag, 4);
+}
+__global__ void eig_scale_kernel(const unsigned long long *__restrict__ amax_bits, double *__restrict__ scale,
+                                 const int *__restrict__ flag) {
+  const double m = __longlong_as_double((long long)*amax_bits);
+  double s = 1.0;
+  if (m > 0.0 && !*flag) {
+    int ex;
+    (void)frexp(m, &ex);          // m = f 2^ex, f in [0.5, 1)
+    s = ldexp(1.0, 1 - ex);       // m s in [1, 2)
   }
+  scale[0] = s;
+  scale[1] = 1.0 / s;
 }
 
 // ------------------------------------------------------------------------------------
@@ -752,10 +751,11 @@ __global__ __launch_bounds__(256) void dc_merge_roots_kernel(const double *__res
   const int jj = active ? j : k - 1;          // inactive groups shadow the last root (results discarded)
   const int jn = jj + 1 < k ? jj + 1 : k - 1;
   const bool last = jj == k - 1;
-  auto gsum = [&](double x) {
+  auto gsum = [&](double x) {   // sum over the 16 lanes of a root (a DPP row); every lane gets it
     x += dpp_f64<0xB1>(x);
     x += dpp_f64<0x4E>(x);
     x += dpp_f64<0x141>(x);
+    x += dpp_f64<0x140>(x);
     return x;
   };
   double zz = 0.0;
@@ -834,10 +834,15 @@ __global__ __launch_bounds__(256) void dc_merge_roots_kernel(const double *__res
 }
 
 // ------------------------------------------------------------------------------------
-// merge, part 2 (one workgroup per merge): apply the deflation rotations to the children's eigenvector rows,
-// Gu-Eisenstat z, normalised eigenvectors of the rank-one update -> UmatT[out row][child row] of the level
-// (the dense GEMM Qt_out = UmatT Qt_in then forms the merged eigenvectors; UmatT is zeroed by the host).
+// merge, part 2: grid (merges of the level, slices of DC_VS columns).  Every workgroup recomputes the Gu-Eisenstat
+// z (products of k ratios per entry, split over the threads in chunks of j and combined through LDS), then
+// normalises its own columns of the rank-one update's eigenvector matrix, one wave per column -> UmatT[out row]
+// [child row] of the level (the dense GEMM Qt_out = UmatT Qt_in forms the merged eigenvectors; UmatT is zeroed by
+// the host).  Slice 0 also applies the deflation rotations to the children's eigenvector rows and places the
+// deflated columns.
 // ------------------------------------------------------------------------------------
+constexpr int DC_VS = 64;
+
 __global__ __launch_bounds__(1024) void dc_merge_vectors_kernel(double *__restrict__ Qt_in, int n, int depth,
                                                                 const double *__restrict__ deltaT,
                                                                 const int *__restrict__ meta,
@@ -848,100 +853,239 @@ __global__ __launch_bounds__(1024) void dc_merge_vectors_kernel(double *__restri
                                                                 const DcRot *__restrict__ rots,
                                                                 double *__restrict__ UmatT, const int *flag) {
   __shared__ double dk[DC_NMAX], zh[DC_NMAX];
-  if (*(volatile const int *)flag) return;
   __shared__ int kp[DC_NMAX];
+  if (*(volatile const int *)flag) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int mg = blockIdx.x;
+  const int mg = blockIdx.x, slice = blockIdx.y;
   int off, nn;
   dc_segment(n, depth, mg, off, nn);
   const int k = meta[4 * mg], nrot = meta[4 * mg + 1];
-  for (int rix = 0; rix < nrot; ++rix) {
-    const DcRot rt = rots[off + rix];
-    double *rp = Qt_in + (size_t)(off + rt.p) * n + off, *rq = Qt_in + (size_t)(off + rt.q) * n + off;
-    for (int c = t; c < nn; c += 1024) {
-      const double qp = rp[c], qq = rq[c];
-      rp[c] = fma(rt.c, qp, rt.s * qq);
-      rq[c] = fma(-rt.s, qp, rt.c * qq);
+  if (slice == 0) {
+    for (int rix = 0; rix < nrot; ++rix) {
+      const DcRot rt = rots[off + rix];
+      double *rp = Qt_in + (size_t)(off + rt.p) * n + off, *rq = Qt_in + (size_t)(off + rt.q) * n + off;
+      for (int c = t; c < nn; c += 1024) {
+        const double qp = rp[c], qq = rq[c];
+        rp[c] = fma(rt.c, qp, rt.s * qq);
+        rq[c] = fma(-rt.s, qp, rt.c * qq);
+      }
+    }
+    for (int i = t; i < nn - k; i += 1024) UmatT[(size_t)(off + k + i) * n + off + defl[off + i]] = 1.0;
+  }
+  if (slice * DC_VS >= k) return;
+  for (int i = t; i < k; i += 1024) { dk[i] = dkg[off + i]; kp[i] = keep[off + i]; zh[i] = 1.0; }
+  __syncthreads();
+  // zhat_i^2 = |prod_j (lam_j - d_i) / (d_j - d_i)| (j != i in the denominator): thread (i, chunk) multiplies the
+  // ratios of j = chunk, chunk + C, ...; ratio by ratio the running product stays O(1) (interlacing)
+  {
+    const int kpad = (k + 63) & ~63;
+    const int C = 1024 / kpad > 0 ? 1024 / kpad : 1;
+    for (int i0 = 0; i0 < kpad; i0 += 1024) {          // one pass unless k > 1024 / C
+      const int i = i0 + t % kpad, c = t / kpad;
+      double prod = 1.0;
+      if (i < k && c < C) {
+        const double di = dk[i];
+        for (int j = c; j < k; j += C) {
+          const double num = -deltaT[(size_t)(off + j) * n + off + i];          // lam_j - d_i
+          const double den = j == i ? 1.0 : dk[j] - di;
+          prod *= num * dc_rcp(den);
+        }
+      }
+      // combine the chunks: zh[i] *= prod, one chunk at a time
+      for (int cc = 0; cc < C; ++cc) {
+        if (i < k && c == cc) zh[i] *= prod;
+        __syncthreads();
+      }
     }
   }
-  for (int i = t; i < k; i += 1024) { dk[i] = dkg[off + i]; kp[i] = keep[off + i]; }
-  __syncthreads();
   for (int i = t; i < k; i += 1024) {
-    const double di = dk[i];
-    double prod = 1.0;
-    for (int j = 0; j < k; ++j) {
-      const double num = -deltaT[(size_t)(off + j) * n + off + i];          // lam_j - d_i
-      const double den = j == i ? 1.0 : dk[j] - di;
-      prod *= num / den;
-    }
-    const double z = sqrt(fabs(prod));
+    const double z = sqrt(fabs(zh[i]));
     zh[i] = zkg[off + i] >= 0.0 ? z : -z;
   }
   __syncthreads();
-  for (int j = wave; j < k; j += 16) {
+  for (int jj = wave; jj < DC_VS; jj += 16) {
+    const int j = slice * DC_VS + jj;
+    if (j >= k) break;
     const double *drow = deltaT + (size_t)(off + j) * n + off;
+    double u[DC_NMAX / 64];
     double ss = 0.0;
-    for (int i = lane; i < k; i += 64) {
-      const double u = zh[i] / drow[i];
-      ss = fma(u, u, ss);
+#pragma unroll
+    for (int q = 0; q < DC_NMAX / 64; ++q) {
+      const int i = lane + 64 * q;
+      u[q] = 0.0;
+      if (i < k) {
+        u[q] = zh[i] * dc_rcp(drow[i]);
+        ss = fma(u[q], u[q], ss);
+      }
     }
     ss = wave_sum_f64(ss);
     const double inv = dc_rsqrt(ss);
     double *urow = UmatT + (size_t)(off + j) * n + off;
-    for (int i = lane; i < k; i += 64) urow[kp[i]] = zh[i] / drow[i] * inv;
+#pragma unroll
+    for (int q = 0; q < DC_NMAX / 64; ++q) {
+      const int i = lane + 64 * q;
+      if (i < k) urow[kp[i]] = u[q] * inv;
+    }
   }
-  for (int i = t; i < nn - k; i += 1024) UmatT[(size_t)(off + k + i) * n + off + defl[off + i]] = 1.0;
 }
 
 // ------------------------------------------------------------------------------------
-// back-transformation: eigenvector rows y <- H_0 H_1 ... H_{n-3} y, H_j = I - tau_j v_j v_j^T (v_j = row j of Vh)
-// one wave per row; eigenvalues are unscaled on the way
+// back-transformation: eigenvector rows y <- H_0 H_1 ... H_{n-3} y, H_j = I - tau_j v_j v_j^T (v_j = row j of Vh).
+// Reflector by reflector this is a chain of n - 2 dependent (dot -> wave reduction -> update) steps per row.  In
+// blocks of HB = 8 (compact WY, LAPACK dlarft): H_j0 ... H_j0+7 = I - V T V^T with an 8 x 8 upper-triangular T, so
+// a block costs 8 INDEPENDENT dots, one tiny T z and one update: 95 -> 21 us at n = 200, 318 -> 52 us at n = 512.
+//   householder_T_kernel     T of every block (Gram matrix of its 8 reflectors -> dlarft recurrence)
+//   householder_rows_kernel  two rows per wave; the V block is staged through LDS (next block prefetched into
+//                            registers while the current one is applied); eigenvalues are unscaled on the way
 // ------------------------------------------------------------------------------------
+constexpr int HB = 8;
+
+__global__ __launch_bounds__(256) void householder_T_kernel(const double *__restrict__ Vh, const double *__restrict__ tau,
+                                                            int n, double *__restrict__ Tg) {
+  __shared__ double S[HB][HB];
+  __shared__ double part[4][HB * (HB + 1) / 2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int j0 = blockIdx.x * HB;
+  double acc[HB * (HB + 1) / 2];
+#pragma unroll
+  for (int e = 0; e < HB * (HB + 1) / 2; ++e) acc[e] = 0.0;
+  for (int k = t; k < n; k += 256) {
+    double v[HB];
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      const int j = j0 + i;
+      v[i] = (j <= n - 3 && k > j) ? Vh[(size_t)j * n + k] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+#pragma unroll
+      for (int c = 0; c <= i; ++c) acc[i * (i + 1) / 2 + c] = fma(v[i], v[c], acc[i * (i + 1) / 2 + c]);
+  }
+#pragma unroll
+  for (int e = 0; e < HB * (HB + 1) / 2; ++e) {
+    const double sum = wave_sum_f64(acc[e]);
+    if (lane == 0) part[wave][e] = sum;
+  }
+  __syncthreads();
+  if (t < HB * (HB + 1) / 2) {
+    const double sum = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    const int c = t - i * (i + 1) / 2;
+    S[i][c] = sum;
+    S[c][i] = sum;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double T[HB][HB];
+    for (int i = 0; i < HB; ++i)
+      for (int c = 0; c < HB; ++c) T[i][c] = 0.0;
+    for (int i = 0; i < HB; ++i) {
+      const int j = j0 + i;
+      const double ti = j <= n - 3 ? tau[j] : 0.0;
+      // T[0:i, i] = -tau_i T[0:i, 0:i] (V[:, 0:i]^T v_i)
+      for (int r = 0; r < i; ++r) {
+        double sum = 0.0;
+        for (int c = r; c < i; ++c) sum = fma(T[r][c], S[c][i], sum);
+        T[r][i] = -ti * sum;
+      }
+      T[i][i] = ti;
+    }
+    for (int i = 0; i < HB; ++i)
+      for (int c = 0; c < HB; ++c) Tg[(size_t)blockIdx.x * HB * HB + i * HB + c] = T[i][c];
+  }
+}
+
 template <int E>
 __global__ __launch_bounds__(256) void householder_rows_kernel(const double *__restrict__ Qt, int n,
                                                                const double *__restrict__ Vh,
-                                                               const double *__restrict__ tau,
+                                                               const double *__restrict__ Tg,
                                                                const double *__restrict__ lam_in,
                                                                const double *__restrict__ scale,
                                                                double *__restrict__ Vout, double *__restrict__ lam_out) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  double y[E];
+  constexpr int R = 2;                       // rows per wave
+  constexpr int NP = E * 64;                 // padded row length
+  constexpr int PRE = HB * NP / 256;         // V-block elements staged by one thread
+  extern __shared__ __attribute__((aligned(16))) double hh_sm[];
+  double *vt = hh_sm;                        // [HB][NP]
+  double *Tt = hh_sm + HB * NP;              // [HB][HB]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * R;
+  double y[R][E];
 #pragma unroll
-  for (int q = 0; q < E; ++q) {
-    const int c = lane + 64 * q;
-    y[q] = c < n ? Qt[(size_t)row * n + c] : 0.0;
-  }
-  double v[E], vn[E];
-  auto loadv = [&](int j, double *dst) {
+  for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const int c = lane + 64 * q;
-      dst[q] = (c < n && c > j) ? Vh[(size_t)j * n + c] : 0.0;
+      y[r][q] = (row0 + r < n && c < n) ? Qt[(size_t)(row0 + r) * n + c] : 0.0;
     }
+  const int ntiles = n >= 3 ? (n - 2 + HB - 1) / HB : 0;
+  double pre[PRE];
+  double tpre = 0.0;
+  auto prefetch = [&](int b) {
+#pragma unroll
+    for (int e = 0; e < PRE; ++e) {
+      const int idx = t + 256 * e, i = idx / NP, k = idx % NP, j = b * HB + i;
+      pre[e] = (j <= n - 3 && k > j && k < n) ? Vh[(size_t)j * n + k] : 0.0;
+    }
+    if (t < HB * HB) tpre = Tg[(size_t)b * HB * HB + t];
   };
-  if (n >= 3) loadv(n - 3, v);
-  for (int j = n - 3; j >= 0; --j) {
-    const double tj = tau[j];
-    if (j > 0) loadv(j - 1, vn);
-    if (tj != 0.0) {
-      double dot = 0.0;
+  if (ntiles) prefetch(ntiles - 1);
+  for (int b = ntiles - 1; b >= 0; --b) {
+    __syncthreads();                         // the previous block has been applied
 #pragma unroll
-      for (int q = 0; q < E; ++q) dot = fma(v[q], y[q], dot);
-      dot = wave_sum_f64(dot) * tj;
+    for (int e = 0; e < PRE; ++e) vt[t + 256 * e] = pre[e];
+    if (t < HB * HB) Tt[t] = tpre;
+    __syncthreads();
+    if (b > 0) prefetch(b - 1);
+    double z[R][HB];
 #pragma unroll
-      for (int q = 0; q < E; ++q) y[q] = fma(-dot, v[q], y[q]);
+    for (int i = 0; i < HB; ++i) {
+      double vv[E];
+#pragma unroll
+      for (int q = 0; q < E; ++q) vv[q] = vt[i * NP + lane + 64 * q];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double d = 0.0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) d = fma(vv[q], y[r][q], d);
+        z[r][i] = d;
+      }
     }
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = vn[q];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < HB; ++i) z[r][i] = wave_sum_f64(z[r][i]);
+    double u[R][HB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c = i; c < HB; ++c) sum = fma(Tt[i * HB + c], z[r][c], sum);
+        u[r][i] = sum;
+      }
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+#pragma unroll
+      for (int q = 0; q < E; ++q) {
+        const double vq = vt[i * NP + lane + 64 * q];
+#pragma unroll
+        for (int r = 0; r < R; ++r) y[r][q] = fma(-u[r][i], vq, y[r][q]);
+      }
+    }
   }
 #pragma unroll
-  for (int q = 0; q < E; ++q) {
-    const int c = lane + 64 * q;
-    if (c < n) Vout[(size_t)row * n + c] = y[q];
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= n) continue;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int c = lane + 64 * q;
+      if (c < n) Vout[(size_t)(row0 + r) * n + c] = y[r][q];
+    }
+    if (lane == 0) lam_out[row0 + r] = lam_in[row0 + r] * scale[1];
   }
-  if (lane == 0) lam_out[row] = lam_in[row] * scale[1];
 }
 
 }  // namespace
@@ -969,7 +1113,10 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
   DcRot *rots = reinterpret_cast<DcRot *>(flag + vec);
   PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-  eig_scale_kernel<<<1, 1024, 0, h->stream>>>(G, n, scale, flag);
+  PLDA_HIP(h, hipMemsetAsync(scale + 2, 0, 8, h->stream));   // running max |g_ij| (as bits)
+  eig_absmax_kernel<<<(unsigned)std::min<int64_t>(ceil_div((int64_t)DD, 1024), 128), 256, 0, h->stream>>>(
+      G, n, reinterpret_cast<unsigned long long *>(scale + 2), flag);
+  eig_scale_kernel<<<1, 1, 0, h->stream>>>(reinterpret_cast<unsigned long long *>(scale + 2), scale, flag);
   // tridiagonalisation: one workgroup with the matrix in registers while that fits without spilling (n <= 160),
   // else rows over ceil(n / 8) cooperating workgroups (PLDA_EIG_VARIANT=2 / 3 force one or the other)
   const bool reg_kernel = h->eig_variant == 2 ? n <= 256 : (h->eig_variant == 3 ? false : n <= 160);
@@ -1029,7 +1176,8 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     PLDA_HIP(h, hipMemsetAsync(UmatT, 0, DD * 8, h->stream));
     dc_merge_roots_kernel<<<dim3(merges, slices), 256, 0, h->stream>>>(lin, qin, ee, n, dl, lout, deltaT, meta, keep,
                                                                         defl, dkg, zkg, rots, flag);
-    dc_merge_vectors_kernel<<<merges, 1024, 0, h->stream>>>(qin, n, dl, deltaT, meta, keep, defl, dkg, zkg, rots, UmatT, flag);
+    dc_merge_vectors_kernel<<<dim3(merges, (unsigned)ceil_div(maxn, DC_VS)), 1024, 0, h->stream>>>(qin, n, dl, deltaT, meta, keep, defl,
+                                                                                             dkg, zkg, rots, UmatT, flag);
     PLDA_LAUNCH_CHECK(h);
     PLDA_TRY(gemm_f64(h, n, n, n, 1.0, UmatT, n, 1, qin, n, 1, nullptr, 0.0, qout, n));
     std::swap(qin, qout);
@@ -1037,12 +1185,22 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   }
   {
     const int E = (int)ceil_div(n, 64);
-    const unsigned grid = (unsigned)ceil_div(n, 4);
-#define HR(EE) householder_rows_kernel<EE><<<grid, 256, 0, h->stream>>>(qin, n, Vh, tau, lin, scale, qout, lamU)
-    if (E <= 1) HR(1);
-    else if (E <= 2) HR(2);
-    else if (E <= 4) HR(4);
-    else if (E <= 8) HR(8);
+    const int EE = E <= 1 ? 1 : E <= 2 ? 2 : E <= 4 ? 4 : E <= 8 ? 8 : 16;
+    const int ntiles = n >= 3 ? (n - 2 + HB - 1) / HB : 0;
+    double *Tg = deltaT;                                  // free again after the merges; ntiles * 64 <= n^2 / 8 + 64
+    if (ntiles) householder_T_kernel<<<ntiles, 256, 0, h->stream>>>(Vh, tau, n, Tg);
+    const unsigned grid = (unsigned)ceil_div(n, 8);
+    const size_t lds = ((size_t)HB * EE * 64 + HB * HB) * sizeof(double);
+#define HR(E2)                                                                                                         \
+  do {                                                                                                                 \
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&householder_rows_kernel<E2>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    householder_rows_kernel<E2><<<grid, 256, lds, h->stream>>>(qin, n, Vh, Tg, lin, scale, qout, lamU);               \
+  } while (0)
+    if (EE == 1) HR(1);
+    else if (EE == 2) HR(2);
+    else if (EE == 4) HR(4);
+    else if (EE == 8) HR(8);
     else HR(16);
 #undef HR
   }
