@@ -107,6 +107,7 @@ struct plda_handle {
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
   plda::DevBuf eigdc;            // eig_dc.hip workspace
+  const int *eigdc_flag = nullptr;   // device flag of the last direct decomposition (sym_eig_dc_status)
   int eig_variant = 0;           // PLDA_EIG_VARIANT: 0 = direct method where supported, 1 = block Jacobi always
   int eig_debug = 0;             // PLDA_EIG_DEBUG (timing experiments only: results are wrong when set)
   int eig_last_method = 0;       // 1 = block Jacobi, 2 = tridiagonalisation + divide and conquer
@@ -162,7 +163,12 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
                 const double *warm);
 // direct method (eig_dc.hip): Householder tridiagonalisation + divide and conquer + back-transformation.
 // *status != 0: not supported / gave up -> use sym_eig_f64.  G is not modified.
-int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vrows, int *status);
+int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vrows, int *status);   // status == nullptr: deferred
+int sym_eig_dc_status(plda_handle *h, int *status);
+int simdiag_enqueue(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                    bool *pending);
+int simdiag_finish(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                   bool *redo);
 // simultaneous diagonalisation of (W,B): T W T^T = I, T B T^T = diag(psi);
 // T [D,D], Tinv = T^{-1} (nullable), psi[D].  W,B are not modified.
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T,

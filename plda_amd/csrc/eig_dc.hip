@@ -1093,11 +1093,25 @@ __global__ __launch_bounds__(256) void householder_rows_kernel(const double *__r
 // eig_sort_kernel of linalg.hip (rank sort descending, optional floor at zero, row permutation)
 int eig_sort_rows(plda_handle *h, const double *lam, const double *V, int D, double *s, double *Vsorted);
 
+int sym_eig_dc_status(plda_handle *h, int *status) {
+  *status = 8;
+  if (!h->eigdc_flag) return PLDA_OK;
+  int hflag = 0;
+  PLDA_HIP(h, hipMemcpyAsync(&hflag, h->eigdc_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  *status = hflag;
+  return PLDA_OK;
+}
+
 // Returns PLDA_OK with *status = 0 when the decomposition is in s / Vrows, *status != 0 when the direct method
 // gave up (non-finite input, an iteration cap): the caller then falls back to the Jacobi solver.  G is not modified.
 int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vrows, int *status) {
-  *status = 0;
-  if (D > DC_NMAX) { *status = 8; return PLDA_OK; }
+  if (status) *status = 0;
+  h->eigdc_flag = nullptr;
+  if (D > DC_NMAX) {
+    if (status) *status = 8;
+    return status ? PLDA_OK : fail(h, PLDA_E_INVAL, "sym_eig_dc: D=%d > %d", D, DC_NMAX);
+  }
   const int n = D;
   const size_t DD = (size_t)n * n;
   // workspace: Vh, QtA, QtB, UmatT, deltaT (n^2 each), then vectors and lists
@@ -1206,10 +1220,8 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   }
   PLDA_LAUNCH_CHECK(h);
   PLDA_TRY(eig_sort_rows(h, lamU, qout, n, s, Vrows));
-  int hflag = 0;
-  PLDA_HIP(h, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  *status = hflag;
+  h->eigdc_flag = flag;
+  if (status) PLDA_TRY(sym_eig_dc_status(h, status));   // status == nullptr: the caller reads it later (sym_eig_dc_status)
   return PLDA_OK;
 }
 

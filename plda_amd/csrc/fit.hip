@@ -601,16 +601,28 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   PLDA_HIP(h, h->d_transform.reserve(DD * 8));
   PLDA_HIP(h, h->d_psi.reserve((size_t)D * 8));
   PLDA_HIP(h, h->d_offset.reserve((size_t)D * 8));
-  PLDA_TRY(simdiag_f64(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), iters > 0));
+  // enqueue only: with the direct eigensolver GetOutput reads nothing back before the model copies below
+  bool pending = false;
+  if (iters > 0 && h->simdiag_has_vr)   // the per-iteration EM arm ran: warm start from its last eigenvectors
+    PLDA_TRY(simdiag_f64(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), true));
+  else
+    PLDA_TRY(simdiag_enqueue(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), &pending));
   PLDA_HIP(h, hipMemcpyAsync(h->d_mean.p, mu, (size_t)D * 8, hipMemcpyDeviceToDevice, h->stream));
   h->Dout = D; h->Din = D;
-  PLDA_TRY(compute_offset_device(h));
   h->h_mean.resize(D); h->h_transform.resize(DD); h->h_psi.resize(D); h->h_offset.resize(D);
-  PLDA_HIP(h, hipMemcpyAsync(h->h_mean.data(), h->d_mean.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, DD * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(h->h_offset.data(), h->d_offset.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    PLDA_TRY(compute_offset_device(h));
+    PLDA_HIP(h, hipMemcpyAsync(h->h_mean.data(), h->d_mean.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, DD * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(h->h_offset.data(), h->d_offset.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (!pending) break;
+    pending = false;
+    bool redo = false;
+    PLDA_TRY(simdiag_finish(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), &redo));
+    if (!redo) break;
+  }
   const double t3 = now_ms();
   h->fitted = true;
   h->fit_K = K; h->fit_D = D;

@@ -1335,8 +1335,14 @@ __global__ void symmetrize_kernel(double *G, int D) {
   }
 }
 
-int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv,
-                double *psi, bool warm_start) {
+// The work is enqueued in two parts so that GetOutput needs no host round trip of its own:
+//   simdiag_enqueue   Cholesky whitening, congruence, eigensolver, T (and Tinv).  With the direct eigensolver
+//                     nothing is read back; *pending = true and the device flags are left for
+//   simdiag_finish    reads the Cholesky and eigensolver flags (after a synchronisation the caller needs
+//                     anyway) and, if the direct method gave up, repeats the decomposition with block Jacobi.
+// simdiag_f64 = both, for callers that want the result at once.
+static int simdiag_run(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                       bool warm_start, bool allow_direct, bool defer, bool *pending) {
   const size_t DD = (size_t)D * D;
   const size_t need = DD * 8 * 6 + 64;
   const bool fresh = h->w[13].cap < need || h->simdiag_D != D;
@@ -1346,13 +1352,16 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   double *T1 = scr + 2 * DD, *tmp = T1 + DD, *G = tmp + DD, *Vr = G + DD;   // Vr persists: next call's warm start
   int *dflag = reinterpret_cast<int *>(Vr + DD);
   const bool warm = warm_start && !fresh && h->simdiag_has_vr;
+  const bool direct = allow_direct && !warm && h->eig_variant != 1;
+  if (pending) *pending = false;
   PLDA_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
   // T1 = chol(W)^-1.  (Any T1 with T1 W T1^T = I gives the same final transform up to row signs; this is
   // the Cholesky one, as in the reference's GetOutput.)
   PLDA_TRY(whiten_blocked(h, W, D, D, T1, D, scr, dflag));
-  {
-    // checked HERE: with a W that is not positive definite T1 is full of NaNs, and the eigensolver would
-    // run its 40 sweeps on garbage and report "did not converge" instead of the actual cause
+  if (!direct) {
+    // checked HERE for the Jacobi solver: with a W that is not positive definite T1 is full of NaNs, and it would
+    // run its 40 sweeps on garbage and report "did not converge" instead of the actual cause.  (The direct
+    // method refuses non-finite input at once and sets its flag: simdiag_finish then finds the Cholesky flag.)
     int hflag = 0;
     PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
@@ -1366,9 +1375,17 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   // direct method first (cold starts: the closed-form EM never diagonalises, so GetOutput always starts cold);
   // block Jacobi when it declines (D > its limit, an iteration cap) or for warm starts of the per-iteration EM arm
   int dc_status = 1;
-  if (!warm && h->eig_variant != 1) PLDA_TRY(sym_eig_dc_f64(h, G, D, psi, Vr, &dc_status));
+  if (direct) {
+    PLDA_TRY(sym_eig_dc_f64(h, G, D, psi, Vr, defer ? nullptr : &dc_status));
+    if (defer) dc_status = 0;   // assumed; simdiag_finish checks
+  }
   h->eig_last_method = dc_status == 0 ? 2 : 1;
   if (dc_status != 0) {
+    if (direct) {   // the direct method gave up: was it the Cholesky factor?
+      int hflag = 0;
+      PLDA_HIP(h, hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost));
+      if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
+    }
     PLDA_TRY(sym_eig_f64(h, G, D, psi, warm ? tmp : Vr, nullptr, warm ? Vr : nullptr));
     if (warm) PLDA_HIP(h, hipMemcpyAsync(Vr, tmp, DD * 8, hipMemcpyDeviceToDevice, h->stream));
   }
@@ -1376,7 +1393,34 @@ int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double 
   // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = T^-1 = W T^T (from T W T^T = I)
   PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));
   if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, W, D, 1, T, 1, D, nullptr, 0.0, Tinv, D));
+  if (pending) *pending = direct && defer;
   return PLDA_OK;
+}
+
+int simdiag_enqueue(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                    bool *pending) {
+  return simdiag_run(h, W, B, D, T, Tinv, psi, false, true, true, pending);
+}
+
+// after the stream has been synchronised by the caller's own copies: *redo = true when the decomposition had to be
+// repeated (T / Tinv / psi were rewritten and the caller's copies of them are stale)
+int simdiag_finish(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                   bool *redo) {
+  *redo = false;
+  const size_t DD = (size_t)D * D;
+  const int *dflag = reinterpret_cast<const int *>(h->w[13].as<double>() + 6 * DD);
+  int hflag = 0, status = 0;
+  PLDA_HIP(h, hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost));
+  if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
+  PLDA_TRY(sym_eig_dc_status(h, &status));
+  if (status == 0) return PLDA_OK;
+  *redo = true;
+  return simdiag_run(h, W, B, D, T, Tinv, psi, false, false, false, nullptr);
+}
+
+int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv,
+                double *psi, bool warm_start) {
+  return simdiag_run(h, W, B, D, T, Tinv, psi, warm_start, true, false, nullptr);
 }
 
 }  // namespace plda
