@@ -213,13 +213,30 @@ def main():
         torch.cuda.synchronize(dev)
         fit_wall = time.perf_counter() - t0
         ft = eng.fit_timings()
+        # per-stage spans of one more fit (HIP events on the stream around each stage: include/plda_hip.h plda_trace_*)
+        eng.trace_enable(True)
+        eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)
+        torch.cuda.synchronize(dev)
+        spans = eng.trace_read()
+        eng.trace_enable(False)
+        stages = []
+        for sp in spans:
+            st = {"name": sp["name"], "ms": round(sp["ms"], 4)}
+            if sp["unit"] == "bytes" and sp["ms"] > 0:
+                st["GBps"] = round(sp["work"] / sp["ms"] / 1e6, 1)
+                st["frac_hbm_8TBps"] = round(sp["work"] / sp["ms"] / 1e6 / 8000.0, 4)
+            if sp["unit"] == "flop" and sp["ms"] > 0:
+                st["TFLOPps"] = round(sp["work"] / sp["ms"] / 1e9, 2)
+                st["frac_fp64_mfma_78.6"] = round(sp["work"] / sp["ms"] / 1e9 / 78.6, 4)
+            stages.append(st)
         fit_info = {"stats_ms": round(ft["stats_ms"], 3), "em_ms": round(ft["em_ms"], 3),
                     "output_ms": round(ft["output_ms"], 3), "iters": ft["iters"],
                     "em_iters_per_s": round(ft["iters"] / (ft["em_ms"] / 1e3), 2) if ft["em_ms"] > 0 else None,
                     "fit_wall_s": round(fit_wall, 4), "N": N, "D": D, "K": K,
-                    # roofline of the statistics pass: K1 reads N D 8 bytes once, K2 = 2 N D^2 flop
-                    "stats_roofline": {"k1k2_ms": round(ft["stats_ms"], 3), "bytes": N * D * 8, "syrk_flop": 2.0 * N * D * D,
-                                       "note": "per-kernel split: profiles/ (rocprofv3 kernel trace of this command)"}}
+                    # roofline of the statistics pass: K1 reads N D 8 bytes once (HBM bound),
+                    # K2 = 2 N D^2 algorithmic flop on the fp64 MFMA pipe (78.6 TFLOP/s); stage times are HIP-event
+                    # spans and include the stage's small helper kernels
+                    "stages": stages}
         del dX, dy
         model = eng.get_model()
         packed = np.concatenate([model["mean"], model["transform"].ravel(), model["psi"]])

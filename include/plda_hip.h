@@ -162,6 +162,16 @@ int plda_profile_read(plda_handle *h, double *gemm_ms, int64_t *launches, double
  * absent), -, epilogue start, epilogue end (the last two in stage slot 15)}. */
 int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words);
 
+/* Per-stage timing (PLDA_HIP_TRACE): named spans bracketed by HIP events on the stream around
+ * the stages of fit (label sort, centroids K1, scatter SYRK K2, EM, GetOutput: whitening / tridiagonalisation /
+ * divide and conquer / back-transformation), transform and scoring.  plda_trace_read synchronises the stream and
+ * writes a JSON array [{"name", "calls", "ms", "work", "unit"}] aggregated by name ("work" = algorithmic flop or
+ * bytes of the stage where one is defined) into json[cap]; PLDA_E_CAPACITY if it does not fit.  With the
+ * environment variable PLDA_HIP_TRACE=1 tracing is on from plda_create and the summary is printed to stderr by
+ * plda_destroy.  The reference has no counterpart (its stages are Kaldi calls inside pldamodule.cpp:76-106). */
+int plda_trace_enable(plda_handle *h, int32_t on);
+int plda_trace_read(plda_handle *h, char *json, int64_t cap, int32_t reset);
+
 /* The symmetric eigensolver of GetOutput on its own (diagnostics and tests; the reference reaches it only through
  * Plda estimation, pldamodule.cpp:102-106 -> Kaldi SpMatrix::Eig).  G [D,D] row-major symmetric, host pointers.
  * eigenvalues[D] descending (signed), eigenvectors [D,D] with eigenvector i in ROW i.  method: 0 = what fit uses

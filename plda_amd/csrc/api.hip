@@ -154,16 +154,24 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EIG_VARIANT")) h->eig_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EIG_DEBUG")) h->eig_debug = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
     *out = h;
     return PLDA_OK;
   });
 }
+
+static int trace_summary(plda_handle *h, std::string &out, bool reset);
 
 int plda_destroy(plda_handle *h) {
   return guarded(h, "plda_destroy", [&]() -> int {
     if (!h) return PLDA_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->trace_print && h->trace_used) {   // PLDA_HIP_TRACE=1: the summary goes to stderr when the handle dies
+      std::string js;
+      if (trace_summary(h, js, true) == PLDA_OK) std::fprintf(stderr, "[plda_hip trace] %s\n", js.c_str());
+    }
+    for (auto &sp : h->trace_spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
     (void)comm_destroy(h);
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
@@ -570,6 +578,57 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
       PLDA_HIP(h, hipStreamSynchronize(h->stream));
     }
     h->last_M = M;
+    return PLDA_OK;
+  });
+}
+
+// spans aggregated by name, in order of first appearance: [{"name": .., "calls": n, "ms": total, "work": w, "unit": "flop"|"bytes"|""}, ..]
+static int trace_summary(plda_handle *h, std::string &out, bool reset) {
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  struct Agg { const char *name; long calls; double ms, work; int unit; };
+  std::vector<Agg> agg;
+  for (size_t i = 0; i < h->trace_used; ++i) {
+    auto &sp = h->trace_spans[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.e0, sp.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+    Agg *a = nullptr;
+    for (auto &x : agg)
+      if (std::strcmp(x.name, sp.name) == 0) { a = &x; break; }
+    if (!a) { agg.push_back(Agg{sp.name, 0, 0.0, 0.0, sp.unit}); a = &agg.back(); }
+    a->calls++; a->ms += ms; a->work += sp.work;
+  }
+  out = "[";
+  char buf[256];
+  for (size_t i = 0; i < agg.size(); ++i) {
+    std::snprintf(buf, sizeof buf, "%s{\"name\": \"%s\", \"calls\": %ld, \"ms\": %.6f, \"work\": %.6g, \"unit\": \"%s\"}", i ? ", " : "",
+                  agg[i].name, agg[i].calls, agg[i].ms, agg[i].work, agg[i].unit == 1 ? "flop" : agg[i].unit == 2 ? "bytes" : "");
+    out += buf;
+  }
+  out += "]";
+  if (reset) h->trace_used = 0;
+  return PLDA_OK;
+}
+
+int plda_trace_enable(plda_handle *h, int32_t on) {
+  return guarded(h, "plda_trace_enable", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    h->trace_on = on != 0;
+    return PLDA_OK;
+  });
+}
+
+int plda_trace_read(plda_handle *h, char *json, int64_t cap, int32_t reset) {
+  return guarded(h, "plda_trace_read", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!json || cap <= 0) return fail(h, PLDA_E_INVAL, "trace_read: bad argument");
+    PLDA_TRY(set_device(h));
+    std::string js;
+    PLDA_TRY(trace_summary(h, js, false));
+    if ((int64_t)js.size() + 1 > cap) return fail(h, PLDA_E_CAPACITY, "trace_read: need %zu bytes", js.size() + 1);
+    std::memcpy(json, js.c_str(), js.size() + 1);
+    if (reset) h->trace_used = 0;
     return PLDA_OK;
   });
 }

@@ -97,6 +97,12 @@ struct plda_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
   double prof_flop = 0.0;
+  // ---- PLDA_HIP_TRACE / plda_trace_*: named spans (HIP event pairs on the stream) around the stages of fit,
+  // transform and scoring; unit 1 = flop, 2 = bytes of algorithmic work ----
+  struct TraceSpan { const char *name; hipEvent_t e0, e1; double work; int unit; };
+  bool trace_on = false, trace_print = false;
+  std::vector<TraceSpan> trace_spans;
+  size_t trace_used = 0;
 
   // ---- multi-GPU (comm.hip): RCCL communicator, side stream for the gather, ordering events ----
   void *comm = nullptr;          // ncclComm_t
@@ -131,6 +137,36 @@ int hip_fail(plda_handle *h, hipError_t e, const char *what, const char *file, i
   } while (0)
 
 #define PLDA_LAUNCH_CHECK(h) PLDA_HIP(h, hipGetLastError())
+
+// RAII span of the trace: records an event on h->stream at construction and destruction (nothing when tracing is off;
+// never inside a stream capture).  `name` must be a string literal.
+struct TraceScope {
+  plda_handle *h;
+  long idx = -1;
+  TraceScope(plda_handle *hh, const char *name, double work = 0.0, int unit = 0) : h(hh) { open(name, work, unit); }
+  // closes the running span and opens the next stage's
+  void next(const char *name, double work = 0.0, int unit = 0) {
+    close();
+    open(name, work, unit);
+  }
+  void close() {
+    if (idx >= 0) (void)hipEventRecord(h->trace_spans[idx].e1, h->stream);
+    idx = -1;
+  }
+  void open(const char *name, double work, int unit) {
+    if (!h->trace_on) return;
+    if (h->trace_used == h->trace_spans.size()) {
+      plda_handle::TraceSpan sp{name, nullptr, nullptr, 0.0, 0};
+      if (hipEventCreate(&sp.e0) != hipSuccess || hipEventCreate(&sp.e1) != hipSuccess) return;
+      h->trace_spans.push_back(sp);
+    }
+    idx = (long)h->trace_used++;
+    auto &sp = h->trace_spans[idx];
+    sp.name = name; sp.work = work; sp.unit = unit;
+    (void)hipEventRecord(sp.e0, h->stream);
+  }
+  ~TraceScope() { close(); }
+};
 
 constexpr size_t TIMELINE_WORDS = 8 * 16 * 8 * 8;   // [tile < 8][stage < 16][wave < 8][8] shader-clock stamps
 

@@ -1127,6 +1127,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
   DcRot *rots = reinterpret_cast<DcRot *>(flag + vec);
   PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  TraceScope ts(h, "getoutput.eig.tridiagonalise", 4.0 / 3.0 * (double)n * n * n, 1);
   PLDA_HIP(h, hipMemsetAsync(scale + 2, 0, 8, h->stream));   // running max |g_ij| (as bits)
   eig_absmax_kernel<<<(unsigned)std::min<int64_t>(ceil_div((int64_t)DD, 1024), 128), 256, 0, h->stream>>>(
       G, n, reinterpret_cast<unsigned long long *>(scale + 2), flag);
@@ -1177,6 +1178,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     }
   }
   PLDA_LAUNCH_CHECK(h);
+  ts.next("getoutput.eig.divide_and_conquer");
   int depth = 0;
   while ((int)ceil_div(n, 1 << depth) > DC_LEAF) depth++;
   PLDA_HIP(h, hipMemsetAsync(QtA, 0, DD * 8, h->stream));
@@ -1197,6 +1199,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     std::swap(qin, qout);
     std::swap(lin, lout);
   }
+  ts.next("getoutput.eig.back_transform", 2.0 * (double)n * n * n, 1);
   {
     const int E = (int)ceil_div(n, 64);
     const int EE = E <= 1 ? 1 : E <= 2 ? 2 : E <= 4 ? 4 : E <= 8 ? 8 : 16;
@@ -1220,6 +1223,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   }
   PLDA_LAUNCH_CHECK(h);
   PLDA_TRY(eig_sort_rows(h, lamU, qout, n, s, Vrows));
+  ts.close();
   h->eigdc_flag = flag;
   if (status) PLDA_TRY(sym_eig_dc_status(h, status));   // status == nullptr: the caller reads it later (sym_eig_dc_status)
   return PLDA_OK;

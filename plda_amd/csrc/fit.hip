@@ -348,18 +348,30 @@ int compute_offset_device(plda_handle *h) {
 
 // Sort rows by label: outputs perm (row ids grouped by label, ascending row within label)
 // and offsets[K+1] in h->w[0], h->w[1].
+// defer_bad != nullptr: the range check is NOT read back here; *defer_bad receives the device flag (bit 0: a label
+// >= K; dense_check_kernel adds bit 1: an unused label, first one in [1]) for the caller to read with its own
+// synchronisation.  Everything enqueued after a failed check works on valid indices (garbage values only).
+__global__ void dense_check_kernel(const int *__restrict__ offsets, int64_t K, int *__restrict__ bad) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K && offsets[k + 1] == offsets[k]) {
+    atomicOr(bad, 2);
+    atomicMin(bad + 1, (int)k);
+  }
+}
+
 static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int64_t K, uint32_t **perm_out,
-                         int **offsets_out) {
+                         int **offsets_out, int **defer_bad = nullptr) {
   if (N >= (1ll << 31)) return fail(h, PLDA_E_INVAL, "fit: N too large");
   const int nblocks = (int)ceil_div(N, RS_CHUNK);
   PLDA_HIP(h, h->w[0].reserve((size_t)N * 4 * 4));                  // keys a/b, vals a/b
-  PLDA_HIP(h, h->w[1].reserve((size_t)(K + 2) * 4 + 64));          // counts -> offsets (+ bad flag)
+  PLDA_HIP(h, h->w[1].reserve((size_t)(K + 3) * 4 + 64));          // counts -> offsets (+ bad flag, first unused label)
   PLDA_HIP(h, h->w[2].reserve((size_t)256 * nblocks * 4));          // digit histograms
   uint32_t *ka = h->w[0].as<uint32_t>(), *va = ka + N, *kb = va + N, *vb = kb + N;
   int *offsets = h->w[1].as<int>();
   int *bad = offsets + K + 1;
   int *hist = h->w[2].as<int>();
   PLDA_HIP(h, hipMemsetAsync(offsets, 0, (size_t)(K + 2) * 4, h->stream));
+  PLDA_HIP(h, hipMemsetAsync(bad + 1, 0x7f, 4, h->stream));
   labels_check_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, h->stream>>>(dlabels, N, K, ka, va, offsets, bad);
   PLDA_LAUNCH_CHECK(h);
   int bits = 1;
@@ -372,13 +384,19 @@ static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int
     std::swap(ka, kb);
     std::swap(va, vb);
   }
-  int hbad = 0;
-  PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
   // counts -> exclusive offsets (K+1 entries: the (K+1)-th input is 0 so offsets[K] = N)
   scan_kernel<<<1, 1024, 0, h->stream>>>(offsets, K + 1);
   PLDA_LAUNCH_CHECK(h);
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  if (hbad) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  if (defer_bad) {
+    dense_check_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, h->stream>>>(offsets, K, bad);
+    PLDA_LAUNCH_CHECK(h);
+    *defer_bad = bad;
+  } else {
+    int hbad = 0;
+    PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (hbad) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  }
   *perm_out = va;
   *offsets_out = offsets;
   return PLDA_OK;
@@ -397,11 +415,10 @@ int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const u
 
   // ---------------- statistics (K1a, K1, K2) ----------------
   uint32_t *perm = nullptr;
-  int *offsets = nullptr;
-  PLDA_TRY(sort_by_label(h, dlabels, N, K, &perm, &offsets));
+  int *offsets = nullptr, *dbad = nullptr;
   {
-    // every label 0..K-1 must occur (dense): check min count on host-free path by offsets diff
-    // (an empty class would give n = 0 -> inf weight); verified via counts kernel below.
+    TraceScope ts(h, "fit.label_sort (K1a)", (double)N * 8.0, 2);
+    PLDA_TRY(sort_by_label(h, dlabels, N, K, &perm, &offsets, &dbad));
   }
   PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
   PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
@@ -412,18 +429,26 @@ int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const u
   double *roww = h->w[3].as<double>();
   counts_to_i64_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, h->stream>>>(offsets, K, h->f_counts.as<int64_t>());
   {
-    std::vector<int> hoff((size_t)K + 1);
-    PLDA_HIP(h, hipMemcpyAsync(hoff.data(), offsets, (size_t)(K + 1) * 4, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    for (int64_t k = 0; k < K; ++k)
-      if (hoff[k + 1] == hoff[k]) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1 (label %lld unused)", (long long)k);
+    TraceScope ts(h, "fit.centroids (K1)", (double)N * D * 8.0, 2);
+    centroid_kernel<<<(unsigned)K, 256, 0, h->stream>>>(dX, D, perm, offsets, means, roww);
+    PLDA_LAUNCH_CHECK(h);
   }
-  centroid_kernel<<<(unsigned)K, 256, 0, h->stream>>>(dX, D, perm, offsets, means, roww);
-  PLDA_LAUNCH_CHECK(h);
   // offset_scatter = X^T diag(1/n_label) X - sum_k (n_k w_k) m_k m_k^T,  n_k w_k = 1
-  PLDA_TRY(gemm_f64(h, D, D, N, 1.0, dX, 1, D, dX, D, 1, roww, 0.0, S, D));
-  PLDA_TRY(gemm_f64(h, D, D, K, -1.0, means, 1, D, means, D, 1, nullptr, 1.0, S, D));
+  {
+    TraceScope ts(h, "fit.scatter_syrk (K2)", 2.0 * (double)N * D * D, 1);
+    PLDA_TRY(gemm_f64(h, D, D, N, 1.0, dX, 1, D, dX, D, 1, roww, 0.0, S, D));
+  }
+  {
+    TraceScope ts(h, "fit.means_syrk", 2.0 * (double)K * D * D, 1);
+    PLDA_TRY(gemm_f64(h, D, D, K, -1.0, means, 1, D, means, D, 1, nullptr, 1.0, S, D));
+  }
+  // the label checks are read back only now, with the synchronisation the pass ends on anyway: a failed check
+  // leaves garbage values (never an invalid index) in what was enqueued after it
+  int hbad[2] = {0, 0};
+  PLDA_HIP(h, hipMemcpyAsync(hbad, dbad, 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (hbad[0] & 1) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  if (hbad[0] & 2) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1 (label %d unused)", hbad[1]);
   h->fit_K = K; h->fit_D = D;
   h->fit_ms[0] = now_ms() - t0;
   h->fit_ms[1] = h->fit_ms[2] = h->fit_ms[3] = 0.0;
@@ -456,6 +481,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   h->jac_total_sweeps = 0;
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t1 = now_ms();
+  TraceScope ts_em(h, "fit.em (all iterations)");
   PLDA_HIP(h, h->f_sum.reserve((size_t)D * 8));
   PLDA_HIP(h, h->f_W.reserve(DD * 8));
   PLDA_HIP(h, h->f_B.reserve(DD * 8));
@@ -593,6 +619,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     PLDA_LAUNCH_CHECK(h);
   }
   }
+  ts_em.close();
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t2 = now_ms();
 

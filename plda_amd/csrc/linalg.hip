@@ -1357,7 +1357,10 @@ static int simdiag_run(plda_handle *h, const double *W, const double *B, int D, 
   PLDA_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), h->stream));
   // T1 = chol(W)^-1.  (Any T1 with T1 W T1^T = I gives the same final transform up to row signs; this is
   // the Cholesky one, as in the reference's GetOutput.)
-  PLDA_TRY(whiten_blocked(h, W, D, D, T1, D, scr, dflag));
+  {
+    TraceScope ts(h, "getoutput.whiten (chol + inverse)");
+    PLDA_TRY(whiten_blocked(h, W, D, D, T1, D, scr, dflag));
+  }
   if (!direct) {
     // checked HERE for the Jacobi solver: with a W that is not positive definite T1 is full of NaNs, and it would
     // run its 40 sweeps on garbage and report "did not converge" instead of the actual cause.  (The direct
@@ -1368,10 +1371,13 @@ static int simdiag_run(plda_handle *h, const double *W, const double *B, int D, 
     if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
   }
   // tmp = T1 B ; G = tmp T1^T
-  PLDA_TRY(gemm_f64(h, D, D, D, 1.0, T1, D, 1, B, D, 1, nullptr, 0.0, tmp, D));
-  PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
-  symmetrize_kernel<<<(unsigned)ceil_div((int64_t)DD, 256), 256, 0, h->stream>>>(G, D);
-  PLDA_LAUNCH_CHECK(h);
+  {
+    TraceScope ts(h, "getoutput.congruence", 4.0 * (double)D * D * D, 1);
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, T1, D, 1, B, D, 1, nullptr, 0.0, tmp, D));
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, tmp, D, 1, T1, 1, D, nullptr, 0.0, G, D));
+    symmetrize_kernel<<<(unsigned)ceil_div((int64_t)DD, 256), 256, 0, h->stream>>>(G, D);
+    PLDA_LAUNCH_CHECK(h);
+  }
   // direct method first (cold starts: the closed-form EM never diagonalises, so GetOutput always starts cold);
   // block Jacobi when it declines (D > its limit, an iteration cap) or for warm starts of the per-iteration EM arm
   int dc_status = 1;
@@ -1386,13 +1392,17 @@ static int simdiag_run(plda_handle *h, const double *W, const double *B, int D, 
       PLDA_HIP(h, hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost));
       if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
     }
+    TraceScope ts(h, "getoutput.eig.jacobi");
     PLDA_TRY(sym_eig_f64(h, G, D, psi, warm ? tmp : Vr, nullptr, warm ? Vr : nullptr));
     if (warm) PLDA_HIP(h, hipMemcpyAsync(Vr, tmp, DD * 8, hipMemcpyDeviceToDevice, h->stream));
   }
   h->simdiag_has_vr = true;
   // T = Vr T1 (rows of Vr are eigenvectors) ; Tinv = T^-1 = W T^T (from T W T^T = I)
-  PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));
-  if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, W, D, 1, T, 1, D, nullptr, 0.0, Tinv, D));
+  {
+    TraceScope ts(h, "getoutput.transform");
+    PLDA_TRY(gemm_f64(h, D, D, D, 1.0, Vr, D, 1, T1, D, 1, nullptr, 0.0, T, D));
+    if (Tinv) PLDA_TRY(gemm_f64(h, D, D, D, 1.0, W, D, 1, T, 1, D, nullptr, 0.0, Tinv, D));
+  }
   if (pending) *pending = direct && defer;
   return PLDA_OK;
 }

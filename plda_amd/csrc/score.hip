@@ -858,6 +858,7 @@ int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, 
   if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
   if (R <= 0) return PLDA_OK;
   // out[r][o] = sum_k X[r][k] T[o][k]
+  TraceScope ts(h, "transform.gemm + length_norm (K4)", 2.0 * (double)R * h->Dout * Din, 1);
   PLDA_TRY(gemm_f64(h, R, h->Dout, Din, 1.0, dX, Din, 1, h->d_transform.as<double>(), 1, Din,
                     nullptr, 0.0, dout, h->Dout));
   const int wpb = 4;
@@ -883,6 +884,7 @@ struct TrialOperands {
 static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform,
                             int64_t M, const double *dV, int64_t Nt, const double *dzmean,
                             const double *dzstd, TrialOperands &op, bool doA = true, bool doB = true) {
+  TraceScope ts(h, "score.pack_operands");
   const int D = h->Dout;
   const int Dp = (int)round_up(D, 8);
   op.mixed = dn != nullptr;
@@ -958,6 +960,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   const int64_t numPatches = (int64_t)patchesM * patchesN;
   const int64_t grid = round_up(numPatches, 8) * PATCH_M * PATCH_N;
   if (grid > 0x7fffffffLL) return fail(h, PLDA_E_INVAL, "score_matrix: block too large, shard it");
+  TraceScope ts(h, EPI == 0 ? "score.trials_gemm (K5)" : "score.znorm_stats_gemm (K8)", 2.0 * (double)op.Kg_alg * (double)M * (double)Nt, 1);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->prof_on) {
     if (h->prof_used == h->prof_events.size()) {

@@ -378,6 +378,17 @@ class MPlda(object):
     def synchronize(self):
         self._ck(self._lib.plda_synchronize(self._h))
 
+    def trace_enable(self, on=True):
+        """Per-stage timing spans (include/plda_hip.h: plda_trace_*; PLDA_HIP_TRACE=1 turns it on from creation)."""
+        self._ck(self._lib.plda_trace_enable(self._h, 1 if on else 0))
+
+    def trace_read(self, reset=True):
+        """list of dict(name, calls, ms, work, unit) aggregated by stage name."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self._lib.plda_trace_read(self._h, buf, len(buf), 1 if reset else 0))
+        return json.loads(buf.value.decode())
+
     def sym_eig(self, G, method=0):
         """Eigen-decomposition of a symmetric matrix by the GetOutput eigensolver (diagnostics / tests):
         (eigenvalues descending, eigenvectors in ROWS, method used: 1 = block Jacobi, 2 = direct)."""
