@@ -13,6 +13,8 @@
 //   sym_eig_f64   one-sided (Hestenes) block Jacobi: one workgroup per pair of 4-row blocks and outer
 //                 round (Gram matrix on the MFMA pipe, 8x8 two-sided sweep in one wave, one apply pass);
 //                 a sweep's launches are replayed from a hipGraph; optional warm start
+#include <cstdlib>
+
 #include "common.hpp"
 
 #include <algorithm>
@@ -364,7 +366,8 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
   // the rows: 512 workgroups (two per CU, all resident at once), chunks of at least 128 rows (a partial costs
   // 2 KiB per computed tile)
   auto plan = [&](int pairs, int &splits, int64_t &kchunk) {
-    splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(512, pairs), ceil_div(K, 128)));
+    static const int target = std::getenv("PLDA_SYRK_WGS") ? std::atoi(std::getenv("PLDA_SYRK_WGS")) : 512;
+    splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(target, pairs), ceil_div(K, 128)));
     kchunk = round_up(ceil_div(K, splits), GK);
     splits = (int)ceil_div(K, kchunk);
   };
