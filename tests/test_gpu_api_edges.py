@@ -248,3 +248,43 @@ def test_host_score_matrix_row_slabs_pack_the_test_side_once(oracle):
     got = S[np.ix_(rows, cols)].astype(np.float64)
     tol = 1e-4 * np.maximum(np.abs(ref), np.abs(ref).mean())
     assert (np.abs(got - ref) <= tol).all()
+
+
+def test_singular_within_class_covariance_is_reported_by_the_deferred_check():
+    """EM keeps W positive definite for finite data, so the failing input is a NaN feature: after one EM iteration
+    W is NaN and GetOutput's Cholesky fails.  The flag is read back with the model copies at the end of the fit (no
+    host round trip inside GetOutput), and the direct eigensolver, fed the NaNs of the failed factor, must neither
+    fault nor hang on the way there."""
+    from plda_amd import MPlda
+    from plda_amd._native import PldaError
+    rng = np.random.default_rng(5)
+    X = rng.random((400, 24))
+    X[7, 3] = np.nan
+    y = np.repeat(np.arange(40, dtype=np.uint64), 10)
+    eng = MPlda(0)
+    with pytest.raises(PldaError, match="positive definite"):
+        eng.fit(X, y, 1)
+    # the handle stays usable
+    X[7, 3] = 0.5
+    eng.fit(X, y, 2)
+    assert np.isfinite(eng.get_model()["psi"]).all()
+
+
+def test_trace_spans_cover_the_fit_stages():
+    from plda_amd import MPlda
+    rng = np.random.default_rng(6)
+    X = rng.random((600, 40))
+    y = np.repeat(np.arange(60, dtype=np.uint64), 10)
+    eng = MPlda(0)
+    eng.trace_enable(True)
+    eng.fit(X, y, 3)
+    spans = {s["name"]: s for s in eng.trace_read()}
+    for name in ("fit.label_sort (K1a)", "fit.centroids (K1)", "fit.scatter_syrk (K2)", "fit.em (all iterations)",
+                 "getoutput.whiten (chol + inverse)", "getoutput.eig.tridiagonalise", "getoutput.eig.divide_and_conquer",
+                 "getoutput.eig.back_transform", "getoutput.transform"):
+        assert name in spans and spans[name]["calls"] == 1 and spans[name]["ms"] > 0.0, name
+    assert spans["fit.scatter_syrk (K2)"]["work"] == 2.0 * 600 * 40 * 40 and spans["fit.scatter_syrk (K2)"]["unit"] == "flop"
+    assert eng.trace_read() == []          # reset by the first read
+    eng.trace_enable(False)
+    eng.fit(X, y, 1)
+    assert eng.trace_read() == []
