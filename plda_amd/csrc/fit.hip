@@ -494,18 +494,14 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   double *mu = h->w[4].as<double>();
   double *scalars = mu + D;
   int *offsets = h->w[1].as<int>();
-  {
-    int *bad = offsets + K + 1;
-    int hbad = 0;
-    PLDA_HIP(h, hipMemsetAsync(bad, 0, 4, h->stream));
-    counts_to_offsets_kernel<<<(unsigned)ceil_div(K + 1, 256), 256, 0, h->stream>>>(h->f_counts.as<int64_t>(), K,
-                                                                                  offsets, bad);
-    scan_kernel<<<1, 1024, 0, h->stream>>>(offsets, K + 1);
-    PLDA_LAUNCH_CHECK(h);
-    PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    if (hbad) return fail(h, PLDA_E_INVAL, "fit: class counts must be positive");
-  }
+  // one host round trip for everything the group planning needs: the count check, the class weight and the counts
+  int *bad = offsets + K + 1;
+  int hbad = 0;
+  PLDA_HIP(h, hipMemsetAsync(bad, 0, 4, h->stream));
+  counts_to_offsets_kernel<<<(unsigned)ceil_div(K + 1, 256), 256, 0, h->stream>>>(h->f_counts.as<int64_t>(), K,
+                                                                                offsets, bad);
+  scan_kernel<<<1, 1024, 0, h->stream>>>(offsets, K + 1);
+  PLDA_LAUNCH_CHECK(h);
   PLDA_HIP(h, h->w[7].reserve((size_t)CS_SPLIT * (D + 1) * 8));
   {
     double *partial = h->w[7].as<double>(), *wpart = partial + (size_t)CS_SPLIT * D;
@@ -515,8 +511,12 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   }
   PLDA_LAUNCH_CHECK(h);
   double class_weight = 0.0;
+  std::vector<int64_t> hcounts((size_t)K);
+  PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipMemcpyAsync(&class_weight, scalars, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(hcounts.data(), h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (hbad) return fail(h, PLDA_E_INVAL, "fit: class counts must be positive");
   const double example_weight = (double)K;  // sum_k w_k n_k with w_k = 1/n_k
 
   // ---------------- EM (K3) ----------------
@@ -527,9 +527,6 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   // One iteration is then D x D work only -- per group one Cholesky, one triangular inverse and five
   // GEMMs, all batched over the groups -- with no inverse of W or B (B may be singular) and no
   // eigendecomposition.  Same estimator as SURVEY.md A.2, different association of the sums.
-  std::vector<int64_t> hcounts((size_t)K);
-  PLDA_HIP(h, hipMemcpyAsync(hcounts.data(), h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
   std::vector<int> cls((size_t)K);
   for (int64_t k = 0; k < K; ++k) cls[k] = (int)k;
   std::stable_sort(cls.begin(), cls.end(), [&](int a, int b) { return hcounts[a] < hcounts[b]; });
