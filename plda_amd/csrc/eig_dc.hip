@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024) void tridiag_reg_kernel(const double *__restr
 // tag is the step's (two buffers by step parity: a workgroup can run at most one step ahead of a reader).
 // Launched cooperatively (all workgroups resident: they wait for each other).
 // ------------------------------------------------------------------------------------
-constexpr int TR_ROWS = 8;
+constexpr int TR_ROWS = 8;   // GetOutput with 4 / 8 / 16 rows per workgroup: 1.34 / 1.32 / 1.65 ms at D = 200, 4.18 / 4.02 / 4.36 at D = 512
 
 constexpr int TR_FIRST_POLL = 10;              // x 128 cycles
 constexpr int TR_TIMEOUT = 1 << 19;            // polls of ~1 us: a word that never arrives ends the kernel with flag 16
@@ -276,14 +276,15 @@ __device__ __forceinline__ double tr_sum32_upper(double x) {
   return x + __hiloint2double(hi, lo);
 }
 
-template <int E>   // E = ceil(n / 32) rounded up to the instantiations below
-__global__ __launch_bounds__(256) void tridiag_rows_kernel(const double *__restrict__ G, int n, int W,
+template <int E, int ROWS>   // E = ceil(n / 32) rounded up to the instantiations below; ROWS rows per workgroup of 32 ROWS threads
+__global__ __launch_bounds__(ROWS * 32) void tridiag_rows_kernel(const double *__restrict__ G, int n, int W,
                                                            const double *__restrict__ scale, double *__restrict__ dd,
                                                            double *__restrict__ ee, double *__restrict__ Vh,
                                                            double *__restrict__ tau, unsigned long long *words,
                                                            int *flag, int dbg, long long *tl) {
   constexpr int NP = E * 32;                   // padded length
-  constexpr int KQ = (NP + 255) / 256;         // gathered elements per thread
+  constexpr int NT = ROWS * 32;
+  constexpr int KQ = (NP + NT - 1) / NT;       // gathered elements per thread
   __shared__ double pp[2][NP], cc[2][NP];      // gathered p and next-column values, by step parity
   __shared__ int sh_to;
   const int t = threadIdx.x, slot = t >> 5, l = t & 31, half = (t >> 5) & 1;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void tridiag_rows_kernel(const double *__restr
         ready = true;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-          const int k = t + 256 * q;
+          const int k = t + NT * q;
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             wv[q][c] = k < n ? __hip_atomic_load(wp + c * NP + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void tridiag_rows_kernel(const double *__restr
       }
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        const int k = t + 256 * q;
+        const int k = t + NT * q;
         if (k < NP) {
           pp[par][k] = __longlong_as_double((long long)((wv[q][0] & 0xffffffffull) | (wv[q][1] << 32)));
           cc[par][k] = __longlong_as_double((long long)((wv[q][2] & 0xffffffffull) | (wv[q][3] << 32)));
@@ -1150,7 +1151,6 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     }
 #undef TR
   } else {
-    int W = (int)ceil_div(n, TR_ROWS);
     const int E = (int)ceil_div(n, 32);
     const int NP = (E <= 7 ? 7 : E <= 8 ? 8 : E <= 16 ? 16 : 32) * 32;
     PLDA_HIP(h, hipMemsetAsync(words, 0, (size_t)8 * NP * sizeof(unsigned long long), h->stream));
@@ -1158,13 +1158,14 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     const double *Gp = G;
     const double *scp = scale;
     int dbg = h->eig_debug;
+    int W = (int)ceil_div(n, TR_ROWS);
     long long *tl = reinterpret_cast<long long *>(deltaT);   // debug stamps (deltaT is free until the merges)
     void *args[] = {&Gp, &nn, &W, &scp, &dd, &ee, &Vh, &tau, &words, &flag, &dbg, &tl};
-    const void *fn = E <= 7    ? reinterpret_cast<const void *>(&tridiag_rows_kernel<7>)
-                     : E <= 8  ? reinterpret_cast<const void *>(&tridiag_rows_kernel<8>)
-                     : E <= 16 ? reinterpret_cast<const void *>(&tridiag_rows_kernel<16>)
-                               : reinterpret_cast<const void *>(&tridiag_rows_kernel<32>);
-    PLDA_HIP(h, hipLaunchCooperativeKernel(fn, dim3(W), dim3(256), args, 0, h->stream));
+    const void *fn = E <= 7    ? reinterpret_cast<const void *>(&tridiag_rows_kernel<7, TR_ROWS>)
+                     : E <= 8  ? reinterpret_cast<const void *>(&tridiag_rows_kernel<8, TR_ROWS>)
+                     : E <= 16 ? reinterpret_cast<const void *>(&tridiag_rows_kernel<16, TR_ROWS>)
+                               : reinterpret_cast<const void *>(&tridiag_rows_kernel<32, TR_ROWS>);
+    PLDA_HIP(h, hipLaunchCooperativeKernel(fn, dim3(W), dim3(TR_ROWS * 32), args, 0, h->stream));
     if (dbg & 2) {
       long long st[16 * 8];
       PLDA_HIP(h, hipStreamSynchronize(h->stream));
