@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, in
                                                             double *__restrict__ part, int nP) {
   constexpr int TB = 128, LD = TB + 16;
   __shared__ double As[2][GK * LD];
-  __shared__ double Bs[2][GK * LD];
+  __shared__ double Bs[DIAG ? 1 : 2][DIAG ? 1 : GK * LD];   // a diagonal super-tile reads both operands from As
+  __shared__ double Ws[2][GK];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   // blockIdx.x enumerates the diagonal super-tiles (DIAG) or the strictly-lower pairs (I > J) row by row;
@@ -237,81 +238,96 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, in
 
   const int fi = lane & 15, fk = lane >> 4;
   // a 16 (k) x 128 (columns) tile of X: thread t holds column t & 127 of rows (t >> 7) + 2 pass; loads are
-  // unconditional on clamped indices, out-of-range elements are zeroed on the way into LDS.  A diagonal
-  // super-tile fetches its rows ONCE and stores them twice: weighted (row operand) and plain (column
-  // operand) -- the weight enters each product once, as in the general kernel.
-  double ra[8], rb[8], wa[8];
+  // unconditional on clamped indices, out-of-range COLUMNS are zeroed on the way into LDS, out-of-range ROWS
+  // get weight zero.  The row weights go to LDS next to the tile (16 per stage) and multiply the row operand
+  // after its LDS read, so a diagonal super-tile keeps ONE copy of its rows for both operands.
+  // Register prefetch runs TWO stages ahead: at D = 200 a stage's MFMAs (~1 300 cycles) are far shorter than a
+  // memory round trip under load, and with one stage of look-ahead the loop ran at the speed of the loads
+  // (9 600 cycles per stage; K2 at C2 0.49 of the fp64 peak).
   const int tc = t & 127, tk = t >> 7;
-  auto fetch = [&](double (&r)[8], int64_t c0, int64_t k0, bool weights) {
+  const double *Bsel0 = diag ? As[0] : Bs[0], *Bsel1 = diag ? As[1] : Bs[1];
+  auto fetch = [&](double (&r)[8], int64_t c0, int64_t k0) {
     const int64_t gm = min(c0 + tc, (int64_t)D - 1);
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
       const int64_t gk = min(k0 + tk + pass * 2, kend - 1);
       r[pass] = X[gk * ldx + gm];
-      if (weights) wa[pass] = kw ? kw[gk] : 1.0;
     }
   };
-  auto store = [&](double *lds, const double (&r)[8], int64_t c0, int64_t k0, bool weighted) {
+  auto fetch_w = [&](int64_t k0) {   // threads 0..15: the weight of row k0 + t (0 past the end of the chunk)
+    double w = 0.0;
+    if (t < GK && k0 + t < kend) w = kw ? kw[k0 + t] : 1.0;
+    return w;
+  };
+  auto store = [&](double *lds, const double (&r)[8], int64_t c0) {
+    const bool ok = c0 + tc < D;
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const bool ok = (c0 + tc < D) && (k0 + tk + pass * 2 < kend);
-      lds[(tk + pass * 2) * LD + tc] = ok ? (weighted ? r[pass] * wa[pass] : r[pass]) : 0.0;
-    }
+    for (int pass = 0; pass < 8; ++pass) lds[(tk + pass * 2) * LD + tc] = ok ? r[pass] : 0.0;
   };
+  double ra0[8], rb0[8], ra1[8], rb1[8], w0 = 0.0, w1 = 0.0;
+  // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
   if (kbeg < kend) {
-    fetch(ra, m0, kbeg, true);
-    if (!diag) fetch(rb, n0, kbeg, false);
-    store(As[0], ra, m0, kbeg, true);
-    if (diag) store(Bs[0], ra, m0, kbeg, false); else store(Bs[0], rb, n0, kbeg, false);
+    fetch(ra0, m0, kbeg);
+    if (!diag) fetch(rb0, n0, kbeg);
+    w0 = fetch_w(kbeg);
+    if (kbeg + GK < kend) {
+      fetch(ra1, m0, kbeg + GK);
+      if (!diag) fetch(rb1, n0, kbeg + GK);
+      w1 = fetch_w(kbeg + GK);
+    }
+    store(As[0], ra0, m0);
+    if (!diag) store(Bs[0], rb0, n0);
+    if (t < GK) Ws[0][t] = w0;
   }
   __syncthreads();
-  int cur = 0;
-  for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
-    const bool more = k0 + GK < kend;
-    if (more) {
-      fetch(ra, m0, k0 + GK, true);
-      if (!diag) fetch(rb, n0, k0 + GK, false);
+  // one stage: issue the loads of stage k0 + 2 GK into (rn, wn), run the MFMAs of stage k0 out of LDS buffer
+  // `cur`, move stage k0 + GK (loaded one iteration ago into (rs, ws)) to the other buffer
+  auto stage = [&](int64_t k0, int cur, double (&rna)[8], double (&rnb)[8], double &wn, const double (&rsa)[8],
+                   const double (&rsb)[8], const double &ws) {
+    if (k0 + 2 * GK < kend) {
+      fetch(rna, m0, k0 + 2 * GK);
+      if (!diag) fetch(rnb, n0, k0 + 2 * GK);
+      wn = fetch_w(k0 + 2 * GK);
     }
-    const double *Ar = As[cur], *Bc = Bs[cur];
-    // the tile counts of the two lines are wave-uniform: one scalar branch per MFMA slot (specialised
-    // branch-free bodies per count pattern made the register allocator spill the accumulators)
-    auto body = [&](auto c0_, auto c1_) {
-      constexpr int C0 = decltype(c0_)::value, C1 = decltype(c1_)::value;   // -1: run-time counts
+    const double *Ar = As[cur], *Bc = cur ? Bsel1 : Bsel0, *Wr = Ws[cur];
 #pragma unroll
-      for (int kk = 0; kk < GK / 4; ++kk) {
-        const int kb = (kk * 4 + fk) * LD + fi;
-        if (diag) {
-          double a[2], b[8];
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      const int kb = (kk * 4 + fk) * LD + fi;
+      const double wk = Wr[kk * 4 + fk];
+      if (diag) {
+        double a[2], b[8];
 #pragma unroll
-          for (int l = 0; l < 2; ++l) a[l] = Ar[kb + line[l] * 16];
+        for (int l = 0; l < 2; ++l) a[l] = Ar[kb + line[l] * 16] * wk;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) b[c] = Bc[kb + c * 16];
+        for (int c = 0; c < 8; ++c) b[c] = Bc[kb + c * 16];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            if (C0 < 0 ? c < cnt[0] : c < C0) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[c], acc[0][c], 0, 0, 0);
-            if (C1 < 0 ? c < cnt[1] : c < C1) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[c], acc[1][c], 0, 0, 0);
-          }
-        } else {
-          double a[8], b[2];
+        for (int c = 0; c < 8; ++c) {
+          if (c < cnt[0]) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[c], acc[0][c], 0, 0, 0);
+          if (c < cnt[1]) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[c], acc[1][c], 0, 0, 0);
+        }
+      } else {
+        double a[8], b[2];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) a[r] = Ar[kb + r * 16];
+        for (int r = 0; r < 8; ++r) a[r] = Ar[kb + r * 16] * wk;
 #pragma unroll
-          for (int l = 0; l < 2; ++l) b[l] = Bc[kb + line[l] * 16];
+        for (int l = 0; l < 2; ++l) b[l] = Bc[kb + line[l] * 16];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            if (C0 < 0 ? r < cnt[0] : r < C0) acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[0], acc[0][r], 0, 0, 0);
-            if (C1 < 0 ? r < cnt[1] : r < C1) acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[1], acc[1][r], 0, 0, 0);
-          }
+        for (int r = 0; r < 8; ++r) {
+          if (r < cnt[0]) acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[0], acc[0][r], 0, 0, 0);
+          if (r < cnt[1]) acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[1], acc[1][r], 0, 0, 0);
         }
       }
-    };
-    body(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
-    if (more) {
-      store(As[cur ^ 1], ra, m0, k0 + GK, true);
-      if (diag) store(Bs[cur ^ 1], ra, m0, k0 + GK, false); else store(Bs[cur ^ 1], rb, n0, k0 + GK, false);
+    }
+    if (k0 + GK < kend) {
+      store(As[cur ^ 1], rsa, m0);
+      if (!diag) store(Bs[cur ^ 1], rsb, n0);
+      if (t < GK) Ws[cur ^ 1][t] = ws;
     }
     __syncthreads();
-    cur ^= 1;
+  };
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * GK) {
+    stage(k0, 0, ra0, rb0, w0, ra1, rb1, w1);
+    if (k0 + GK < kend) stage(k0 + GK, 1, ra1, rb1, w1, ra0, rb0, w0);
   }
   // partial slab of this (split, pair): 64 tile slots of 256 doubles; only computed tiles are written
   double *slab = part + ((int64_t)blockIdx.y * nP + slot) * (64 * 256);
@@ -359,8 +375,163 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const double *__restri
   if (gr != gc) *c2 = v2;
 }
 
+// ------------------------------------------------------------------------------------
+// D <= 208 (the i-vector sizes; C2 is 200): ONE workgroup per row chunk computes the whole lower triangle.
+// With 128-column super-tiles X is read twice (once by the diagonal, once by the off-diagonal launch) and at
+// C2 the two launches ran at the speed of those reads (2.6-3.7 TB/s of 1 KB row segments), not of the MFMAs.
+// Here a stage is 16 full rows (coalesced 1.6 KB each), read once; the 13 x 13 / 2 MFMA tiles are dealt to 8 waves
+// as tile rows {w, nt-1-w} (nt + 1 tiles per wave, 15 LDS operand reads for 14 MFMAs per k-step); register
+// prefetch two stages ahead; partials of the computed tiles only, summed in fixed order by syrk_tri_reduce_kernel.
+// ------------------------------------------------------------------------------------
+constexpr int TRI_NT = 13;                 // tile rows: D <= 208
+constexpr int TRI_LD = TRI_NT * 16 + 16;   // LDS row stride in doubles
+
+__global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t kchunk, const double *__restrict__ X,
+                                                       int64_t ldx, const double *__restrict__ kw,
+                                                       double *__restrict__ part) {
+  __shared__ double Xs[2][GK * TRI_LD];
+  __shared__ double Ws[2][GK];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
+  const int64_t kbeg = (int64_t)blockIdx.x * kchunk;
+  const int64_t kend = min(K, kbeg + kchunk);
+  // tile rows of this wave: lo = wave (wave + 1 tiles), hi = nt - 1 - wave (nt - wave tiles) when it is a different row
+  const int lo = wave, hi = nt - 1 - wave;
+  const int cnt_lo = lo <= hi ? lo + 1 : 0, cnt_hi = hi > lo ? hi + 1 : 0;
+  f64x4 acc_lo[8], acc_hi[TRI_NT];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc_lo[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < TRI_NT; ++c) acc_hi[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int fi = lane & 15, fk = lane >> 4;
+  const int tc = t & 255, tk = t >> 8;      // column, row offset (rows tk + 2 pass)
+  const int gc = min(tc, D - 1);
+  auto fetch = [&](double (&r)[8], int64_t k0) {
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int64_t gk = min(k0 + tk + pass * 2, kend - 1);
+      r[pass] = X[gk * ldx + gc];
+    }
+  };
+  auto fetch_w = [&](int64_t k0) {
+    double w = 0.0;
+    if (t < GK && k0 + t < kend) w = kw ? kw[k0 + t] : 1.0;
+    return w;
+  };
+  auto store = [&](double *lds, const double (&r)[8]) {
+    if (tc < TRI_LD) {
+      const bool ok = tc < D;
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) lds[(tk + pass * 2) * TRI_LD + tc] = ok ? r[pass] : 0.0;
+    }
+  };
+  double r0[8], r1[8], w0 = 0.0, w1 = 0.0;
+  if (kbeg < kend) {
+    fetch(r0, kbeg);
+    w0 = fetch_w(kbeg);
+    if (kbeg + GK < kend) {
+      fetch(r1, kbeg + GK);
+      w1 = fetch_w(kbeg + GK);
+    }
+    store(Xs[0], r0);
+    if (t < GK) Ws[0][t] = w0;
+  }
+  __syncthreads();
+  auto stage = [&](int64_t k0, int cur, double (&rn)[8], double &wn, const double (&rs)[8], const double &ws) {
+    if (k0 + 2 * GK < kend) {
+      fetch(rn, k0 + 2 * GK);
+      wn = fetch_w(k0 + 2 * GK);
+    }
+    const double *Xr = Xs[cur], *Wr = Ws[cur];
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      const int kb = (kk * 4 + fk) * TRI_LD + fi;
+      const double wk = Wr[kk * 4 + fk];
+      const double a_lo = Xr[kb + lo * 16] * wk, a_hi = Xr[kb + max(hi, 0) * 16] * wk;
+      // column operands in two batches (all 13 at once pushed the kernel over 256 VGPRs)
+#pragma unroll
+      for (int c0 = 0; c0 < TRI_NT; c0 += 7) {
+        double b[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) b[c] = c0 + c < TRI_NT ? Xr[kb + (c0 + c) * 16] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          const int cc = c0 + c;
+          if (cc < 8 && cc < cnt_lo) acc_lo[cc < 8 ? cc : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_lo, b[c], acc_lo[cc < 8 ? cc : 0], 0, 0, 0);
+          if (cc < TRI_NT && cc < cnt_hi) acc_hi[cc < TRI_NT ? cc : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_hi, b[c], acc_hi[cc < TRI_NT ? cc : 0], 0, 0, 0);
+        }
+      }
+    }
+    if (k0 + GK < kend) {
+      store(Xs[cur ^ 1], rs);
+      if (t < GK) Ws[cur ^ 1][t] = ws;
+    }
+    __syncthreads();
+  };
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * GK) {
+    stage(k0, 0, r0, w0, r1, w1);
+    if (k0 + GK < kend) stage(k0 + GK, 1, r1, w1, r0, w0);
+  }
+  // partial: tile (r, c) at slot r (r + 1) / 2 + c, 256 doubles in the MFMA C layout
+  double *slab = part + (int64_t)blockIdx.x * ntri * 256;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < cnt_lo) {
+      double *d = slab + (lo * (lo + 1) / 2 + c) * 256 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r * 64] = acc_lo[c][r];
+    }
+#pragma unroll
+  for (int c = 0; c < TRI_NT; ++c)
+    if (c < cnt_hi) {
+      double *d = slab + (hi * (hi + 1) / 2 + c) * 256 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r * 64] = acc_hi[c][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void syrk_tri_reduce_kernel(const double *__restrict__ part, int splits, int D,
+                                                              double alpha, double beta, double *__restrict__ C,
+                                                              int64_t ldc) {
+  const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
+  int tr = 0, tcol = (int)blockIdx.x;
+  while (tcol > tr) { tcol -= tr + 1; ++tr; }
+  const int lane = threadIdx.x & 63, reg = threadIdx.x >> 6;
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int gr = tr * 16 + (lane >> 4) + 4 * reg, gcol = tcol * 16 + (lane & 15);
+  if (gr >= D || gcol >= D || gcol > gr) return;
+  const double *p = part + (int64_t)blockIdx.x * 256 + reg * 64 + lane;
+  const int64_t zs = (int64_t)ntri * 256;
+  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += p[(int64_t)(z + u) * zs];
+  }
+  for (; z < splits; ++z) s8[0] += p[(int64_t)z * zs];
+  const double sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  double *c1 = C + (int64_t)gr * ldc + gcol, *c2 = C + (int64_t)gcol * ldc + gr;
+  const double v1 = alpha * sum + (beta != 0.0 ? beta * *c1 : 0.0);
+  const double v2 = alpha * sum + (beta != 0.0 ? beta * *c2 : 0.0);
+  *c1 = v1;
+  if (gr != gcol) *c2 = v2;
+}
+
 int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, int64_t ldx, const double *kw,
              double beta, double *C, int64_t ldc) {
+  if (D <= TRI_NT * 16 && h->gemm64_variant != 3) {   // PLDA_GEMM64_VARIANT=3: super-tile path always (A/B arm)
+    const int nt = (int)ceil_div(D, 16), ntri = nt * (nt + 1) / 2;
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(K, 128)));
+    const int64_t kchunk = round_up(ceil_div(K, splits), GK);
+    splits = (int)ceil_div(K, kchunk);
+    PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
+    double *part = h->w[15].as<double>();
+    syrk_tri_kernel<<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, part);
+    syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, alpha, beta, C, ldc);
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
   const int nT = (int)ceil_div(D, 128), nP = nT * (nT + 1) / 2, nO = nP - nT;
   // diagonal and strictly-lower super-tiles are two launches (two tile mappings); each gets its own split of
   // the rows: 512 workgroups (two per CU, all resident at once), chunks of at least 128 rows (a partial costs
