@@ -1165,7 +1165,17 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
                      : E <= 8  ? reinterpret_cast<const void *>(&tridiag_rows_kernel<8, TR_ROWS>)
                      : E <= 16 ? reinterpret_cast<const void *>(&tridiag_rows_kernel<16, TR_ROWS>)
                                : reinterpret_cast<const void *>(&tridiag_rows_kernel<32, TR_ROWS>);
-    PLDA_HIP(h, hipLaunchCooperativeKernel(fn, dim3(W), dim3(TR_ROWS * 32), args, 0, h->stream));
+    {
+      // a device that cannot hold all W workgroups at once (CU masking, a partitioned GPU) refuses the launch:
+      // that is not an error of the fit -- the caller falls back to the block Jacobi solver
+      const hipError_t ce = hipLaunchCooperativeKernel(fn, dim3(W), dim3(TR_ROWS * 32), args, 0, h->stream);
+      if (ce != hipSuccess) {
+        (void)hipGetLastError();
+        h->eigdc_flag = nullptr;         // sym_eig_dc_status then reports 8 ("not handled")
+        if (status) *status = 8;
+        return PLDA_OK;
+      }
+    }
     if (dbg & 2) {
       long long st[16 * 8];
       PLDA_HIP(h, hipStreamSynchronize(h->stream));
