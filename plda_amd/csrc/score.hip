@@ -511,6 +511,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     int numPatches, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
   constexpr bool TL = (MODE & 1) != 0;                            // timeline instrumentation (diagnostic)
+  constexpr bool DIRECT = (MODE & 2) == 0;                        // epilogue stores straight from the accumulator layout (MODE bit 1: the LDS-transpose epilogue, A/B arm)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
@@ -704,7 +705,30 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) stg[(4 * hh + e) * 64 + tn * 32 + i] = acc[tm][tn][4 * q + e];
       };
-      if (interior) {
+      if (DIRECT && interior) {
+        // no LDS round trip: a register of the 32 x 32 accumulator holds rows (8 q + e) and (8 q + e + 4) (lane >> 5)
+        // of 32 consecutive columns, i.e. one store instruction = two full 128-byte row pieces.  The row walks on a
+        // scalar base; the lane offset (half-row, column) is constant.  128 dword stores per tile and wave against
+        // 128 ds_write + 32 ds_read + 32 16-byte stores of the transposing epilogue below: what an epilogue costs
+        // beside an MFMA-dense partner wave is the NUMBER of vector-memory instructions it issues (~31-47 cycles
+        // each), not their bytes -- 87.7 -> 88.8 % at D = 200, 94.2 -> 94.7 % at D = 512 in one interleaved sweep.
+        const char *tb = reinterpret_cast<const char *>(out + (((int64_t)r0 + wm * 128) * ld + c0 + wn * 64));
+        const int64_t ldb = 4 * ld;                             // bytes per row
+        unsigned voff = (unsigned)hh * (4u * (unsigned)ld * 4u) + (unsigned)i * 4u;
+        asm volatile("" : "+v"(voff));
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              __builtin_nontemporal_store(acc[tm][0][4 * q + e], reinterpret_cast<float *>(const_cast<char *>(tb) + voff));
+              __builtin_nontemporal_store(acc[tm][1][4 * q + e], reinterpret_cast<float *>(const_cast<char *>(tb) + 128 + voff));
+              tb += ldb;
+            }
+            tb += 4 * ldb;
+          }
+      } else if (interior) {
         // stores address the tile through a scalar base that walks down the wave's 128 rows, 4 rows per
         // store, plus a constant 32-bit lane offset (the host guarantees ld < 2^22).
         // Software pipeline W(c) R(c) S(c-1): a wave's LDS operations execute in order, so W(c) may be
@@ -981,11 +1005,13 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   // it needs 32-bit byte offsets into each packed operand and into a tile's output rows
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
-                       (h->gemm_variant == 30 || h->gemm_variant == 31 || (h->gemm_variant == 0 && big));
+                       (h->gemm_variant == 30 || h->gemm_variant == 31 || h->gemm_variant == 32 || h->gemm_variant == 33 ||
+                        (h->gemm_variant == 0 && big));
   if (use_bt2) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
-      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>)};
+      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>)};
       for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
@@ -993,12 +1019,15 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   trials_gemm_bt2_kernel<MODE_><<<256, 512, BT2_LDS, h->stream>>>(                                        \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
       h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
-    if (h->gemm_variant == 31) {
+    if (h->gemm_variant == 31 || h->gemm_variant == 33) {
       // diagnostic: per-wave timestamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
-      BT2L(1, h->timeline.as<unsigned long long>());
+      if (h->gemm_variant == 31) BT2L(1, h->timeline.as<unsigned long long>());
+      else BT2L(3, h->timeline.as<unsigned long long>());
       h->timeline_valid = true;
+    } else if (h->gemm_variant == 32) {
+      BT2L(2, nullptr);
     } else {
       BT2L(0, nullptr);
     }

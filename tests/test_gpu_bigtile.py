@@ -107,10 +107,10 @@ def test_kernels_bit_identical(monkeypatch):
     U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
     counts = rng.integers(1, 6, m).astype(np.int32)
     outs = {}
-    for variant in (20, 30):
+    for variant in (20, 30, 32):
         eng, _ = _engine(monkeypatch, variant, d)
         outs[variant] = (eng.score_matrix((2, U), (1, V)), eng.score_matrix((counts, U), (1, V)))
-    for variant in (30,):
+    for variant in (30, 32):       # 32: the 256 x 256 kernel with the LDS-transposing epilogue (A/B arm of the direct stores)
         assert np.array_equal(outs[variant][0], outs[20][0]), variant
         assert np.array_equal(outs[variant][1], outs[20][1]), variant
 
