@@ -200,23 +200,33 @@ template <bool DIAG>   // (two instantiations rather than one kernel with both t
 __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, int64_t kchunk,
                                                             const double *__restrict__ X, int64_t ldx,
                                                             const double *__restrict__ kw,
-                                                            double *__restrict__ part, int nP) {
+                                                            double *__restrict__ part, int nP, int npairs,
+                                                            int splits) {
   constexpr int TB = 128, LD = TB + 16;
   __shared__ double As[2][GK * LD];
   __shared__ double Bs[DIAG ? 1 : 2][DIAG ? 1 : GK * LD];   // a diagonal super-tile reads both operands from As
   __shared__ double Ws[2][GK];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  // blockIdx.x enumerates the diagonal super-tiles (DIAG) or the strictly-lower pairs (I > J) row by row;
+  // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8, and all super-tile pairs of one row chunk meet in ONE L2
+  // (they read the same rows of X: at D = 512 the six strictly-lower pairs use each 128-column slab three times).
+  // So chunk % 8 = L % 8: L = 8 (pair + npairs (chunk / 8)) + chunk % 8.  (Measured: no change at C3 -- the kernel
+  // is not bound by HBM traffic: SQ_VALU_MFMA_BUSY_CYCLES is 41 % of its cycles, 65 % of the wave cycles wait;
+  // MFMAs without the per-tile branches: no change either.)
+  const int Lid = (int)blockIdx.x;
+  const int pair = (Lid >> 3) % npairs;
+  const int chunk = 8 * ((Lid >> 3) / npairs) + (Lid & 7);
+  if (chunk >= splits) return;
+  // `pair` enumerates the diagonal super-tiles (DIAG) or the strictly-lower pairs (I > J) row by row;
   // `slot` is the pair's index in the partial slabs: I (I + 1) / 2 + J
   int I, J;
-  if (DIAG) { I = J = (int)blockIdx.x; }
-  else { I = 1; J = (int)blockIdx.x; while (J >= I) { J -= I; ++I; } }
+  if (DIAG) { I = J = pair; }
+  else { I = 1; J = pair; while (J >= I) { J -= I; ++I; } }
   const int slot = I * (I + 1) / 2 + J;
   constexpr bool diag = DIAG;
   const int64_t m0 = (int64_t)I * TB, n0 = (int64_t)J * TB;
   const int nvr = min(8, (int)((D - m0 + 15) / 16)), nvc = min(8, (int)((D - n0 + 15) / 16));
-  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kbeg = (int64_t)chunk * kchunk;
   const int64_t kend = min(K, kbeg + kchunk);
   // this wave's two "lines" (tile rows on a diagonal super-tile, tile columns otherwise) and, per line,
   // how many tiles of it are computed
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, in
     if (k0 + GK < kend) stage(k0 + GK, 1, ra1, rb1, w1, ra0, rb0, w0);
   }
   // partial slab of this (split, pair): 64 tile slots of 256 doubles; only computed tiles are written
-  double *slab = part + ((int64_t)blockIdx.y * nP + slot) * (64 * 256);
+  double *slab = part + ((int64_t)chunk * nP + slot) * (64 * 256);
 #pragma unroll
   for (int l = 0; l < 2; ++l)
 #pragma unroll
@@ -548,8 +558,8 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
   if (nO) plan(nO, so, ko);
   PLDA_HIP(h, h->w[15].reserve((size_t)std::max(sd, so) * nP * 64 * 256 * 8));
   double *part = h->w[15].as<double>();
-  syrk_lower_kernel<true><<<dim3((unsigned)nT, (unsigned)sd), 256, 0, h->stream>>>(D, K, kd, X, ldx, kw, part, nP);
-  if (nO) syrk_lower_kernel<false><<<dim3((unsigned)nO, (unsigned)so), 256, 0, h->stream>>>(D, K, ko, X, ldx, kw, part, nP);
+  syrk_lower_kernel<true><<<(unsigned)(round_up(sd, 8) * nT), 256, 0, h->stream>>>(D, K, kd, X, ldx, kw, part, nP, nT, sd);
+  if (nO) syrk_lower_kernel<false><<<(unsigned)(round_up(so, 8) * nO), 256, 0, h->stream>>>(D, K, ko, X, ldx, kw, part, nP, nO, so);
   PLDA_LAUNCH_CHECK(h);
   syrk_reduce_kernel<<<(unsigned)(nP * 64), 256, 0, h->stream>>>(part, sd, so, nP, D, alpha, beta, C, ldc);
   PLDA_LAUNCH_CHECK(h);
