@@ -178,6 +178,16 @@ __global__ void splitk_reduce_kernel(const double *__restrict__ part, int splits
   *c = alpha * s + (beta != 0.0 ? beta * *c : 0.0);
 }
 
+// workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), i.e. every register prefetch in flight.  (Measured on the SYRK kernels: no change --
+// the compiler's own counted waits in front of the LDS stores were already the binding ones.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); vmcnt and expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------
 // K2: symmetric rank-K update  S = alpha X^T diag(w) X (+ beta S)  -- the AddSamples scatter
 // (PldaStats::AddSamples reached at pldamodule.cpp:94-98; Kaldi's AddMat2 / ATLAS dsyrk) and the
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_kernel(int D, int64_t K, in
       if (!diag) store(Bs[cur ^ 1], rsb, n0);
       if (t < GK) Ws[cur ^ 1][t] = ws;
     }
-    __syncthreads();
+    lds_barrier();
   };
   for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * GK) {
     stage(k0, 0, ra0, rb0, w0, ra1, rb1, w1);
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
       store(Xs[cur ^ 1], rs);
       if (t < GK) Ws[cur ^ 1][t] = ws;
     }
-    __syncthreads();
+    lds_barrier();
   };
   for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * GK) {
     stage(k0, 0, r0, w0, r1, w1);
