@@ -201,6 +201,7 @@ int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int 
 // *status != 0: not supported / gave up -> use sym_eig_f64.  G is not modified.
 int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vrows, int *status);   // status == nullptr: deferred
 int sym_eig_dc_status(plda_handle *h, int *status);
+int sym_eig_auto_f64(plda_handle *h, double *G, int D, double *s, double *Vrows);   // direct, else block Jacobi
 int simdiag_enqueue(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
                     bool *pending);
 int simdiag_finish(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,

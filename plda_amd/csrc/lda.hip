@@ -263,7 +263,7 @@ int lda_fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uin
     lda_std_kernel<<<blocks(D), 256, 0, h->stream>>>(S, N, D, std);
     lda_whiten_gram_kernel<<<blocks((int64_t)DD), 256, 0, h->stream>>>(S, std, fac, D, G);
     PLDA_LAUNCH_CHECK(h);
-    PLDA_TRY(sym_eig_f64(h, G, D, lam, Vr, nullptr, nullptr));           // singular values^2, right vectors in rows
+    PLDA_TRY(sym_eig_auto_f64(h, G, D, lam, Vr));           // singular values^2, right vectors in rows
     std::vector<double> hl((size_t)D);
     PLDA_HIP(h, hipMemcpyAsync(hl.data(), lam, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
@@ -282,7 +282,7 @@ int lda_fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uin
     PLDA_TRY(gemm_f64(h, K, r1, D, 1.0, Mc, D, 1, scal1, r1, 1, nullptr, 0.0, cen, r1));
     double *G2 = G, *V2 = Vr;                                             // [r1][r1]
     PLDA_TRY(gemm_f64(h, r1, r1, K, 1.0, cen, 1, r1, cen, r1, 1, nullptr, 0.0, G2, r1));
-    PLDA_TRY(sym_eig_f64(h, G2, r1, lam, V2, nullptr, nullptr));
+    PLDA_TRY(sym_eig_auto_f64(h, G2, r1, lam, V2));
     PLDA_HIP(h, hipMemcpyAsync(hl.data(), lam, (size_t)r1 * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
     int r2 = 0;
@@ -338,7 +338,7 @@ int lda_fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uin
       // coef = (Sw^+ means^T)^T, Sw^+ from the eigendecomposition with numpy.linalg.lstsq's default cut-off
       lda_symmetrize_kernel<<<blocks((int64_t)DD), 256, 0, h->stream>>>(Sw, D);
       PLDA_LAUNCH_CHECK(h);
-      PLDA_TRY(sym_eig_f64(h, Sw, D, lam, Vr, nullptr, nullptr));
+      PLDA_TRY(sym_eig_auto_f64(h, Sw, D, lam, Vr));
       double lmax = 0.0;
       PLDA_HIP(h, hipMemcpyAsync(&lmax, lam, 8, hipMemcpyDeviceToHost, h->stream));
       PLDA_HIP(h, hipStreamSynchronize(h->stream));

@@ -1555,6 +1555,15 @@ __global__ void symmetrize_kernel(double *G, int D) {
   }
 }
 
+// direct method where it applies, block Jacobi otherwise (or when it gives up): what the LDA solvers call
+int sym_eig_auto_f64(plda_handle *h, double *G, int D, double *s, double *Vrows) {
+  int status = 1;
+  if (h->eig_variant != 1) PLDA_TRY(sym_eig_dc_f64(h, G, D, s, Vrows, &status));
+  h->eig_last_method = status == 0 ? 2 : 1;
+  if (status != 0) PLDA_TRY(sym_eig_f64(h, G, D, s, Vrows, nullptr, nullptr));
+  return PLDA_OK;
+}
+
 // The work is enqueued in two parts so that GetOutput needs no host round trip of its own:
 //   simdiag_enqueue   Cholesky whitening, congruence, eigensolver, T (and Tinv).  With the direct eigensolver
 //                     nothing is read back; *pending = true and the device flags are left for
