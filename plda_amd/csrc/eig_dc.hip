@@ -1117,7 +1117,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   const size_t DD = (size_t)n * n;
   // workspace: Vh, QtA, QtB, UmatT, deltaT (n^2 each), then vectors and lists
   const size_t vec = (size_t)round_up(n, 32);
-  const size_t need = DD * 8 * 5 + vec * 8 * 10 + 8 * 1024 * 8 + 64 + vec * 4 * 4 + vec * sizeof(DcRot) + 4096;
+  const size_t need = DD * 8 * 5 + vec * 8 * 10 + 8 * 1024 * 8 + 64 + vec * 4 * 4 + vec * sizeof(DcRot) + (8 * vec + 64) * 8 + 4096;
   PLDA_HIP(h, h->eigdc.reserve(need));
   double *Vh = h->eigdc.as<double>();
   double *QtA = Vh + DD, *QtB = QtA + DD, *UmatT = QtB + DD, *deltaT = UmatT + DD;
@@ -1127,6 +1127,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   int *keep = reinterpret_cast<int *>(words + 8 * 1024);
   int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
   DcRot *rots = reinterpret_cast<DcRot *>(flag + vec);
+  double *Tg = reinterpret_cast<double *>(rots + vec);   // compact-WY T blocks: ceil((n - 2) / 8) x 64 doubles
   PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
   TraceScope ts(h, "getoutput.eig.tridiagonalise", 4.0 / 3.0 * (double)n * n * n, 1);
   PLDA_HIP(h, hipMemsetAsync(scale + 2, 0, 8, h->stream));   // running max |g_ij| (as bits)
@@ -1157,7 +1158,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     int nn = n;
     const double *Gp = G;
     const double *scp = scale;
-    int dbg = h->eig_debug;
+    int dbg = n >= 64 ? h->eig_debug : (h->eig_debug & ~2);   // the stamps go to the (then free) deltaT: 1 KiB
     int W = (int)ceil_div(n, TR_ROWS);
     long long *tl = reinterpret_cast<long long *>(deltaT);   // debug stamps (deltaT is free until the merges)
     void *args[] = {&Gp, &nn, &W, &scp, &dd, &ee, &Vh, &tau, &words, &flag, &dbg, &tl};
@@ -1215,7 +1216,6 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     const int E = (int)ceil_div(n, 64);
     const int EE = E <= 1 ? 1 : E <= 2 ? 2 : E <= 4 ? 4 : E <= 8 ? 8 : 16;
     const int ntiles = n >= 3 ? (n - 2 + HB - 1) / HB : 0;
-    double *Tg = deltaT;                                  // free again after the merges; ntiles * 64 <= n^2 / 8 + 64
     if (ntiles) householder_T_kernel<<<ntiles, 256, 0, h->stream>>>(Vh, tau, n, Tg);
     const unsigned grid = (unsigned)ceil_div(n, 8);
     const size_t lds = ((size_t)HB * EE * 64 + HB * HB) * sizeof(double);
