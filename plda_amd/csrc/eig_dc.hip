@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
     int iter = 0;
     while (true) {
       // smallest mm >= l with a negligible e[mm] (mm = m - 1 if none)
-      const double dn = dpp_f64<0x130>(d);   // wave_shl 1: lane i reads lane i + 1
+      const double dn = __shfl_down(d, 1);   // d of lane i + 1
       const bool small = fabs(e) <= DC_EPS * (fabs(d) + fabs(dn));
       const unsigned long long mask = __ballot(small && lane >= l && lane < m - 1);
       const int mm = mask ? __builtin_ctzll(mask) : m - 1;
