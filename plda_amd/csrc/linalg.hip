@@ -829,6 +829,10 @@ int tri_invert_ld(plda_handle *h, const double *L, double *X, int D, int ldx, in
 // pivoting is needed.  The 1024 threads form a 32 x 32 grid; thread (ty, tx) owns the lower-triangle
 // elements (i, j) = (32a + ty, 32b + tx), a >= b, so a sweep is NB(NB+1)/2 FMAs per thread on
 // registers plus one LDS broadcast of column k (double-buffered: one barrier per sweep).
+// (Two pivots per barrier -- both rank-one updates from the two columns as they stand before the pair -- is
+// correct but slower, 3.35 against 2.62 ms for the ten EM iterations at D = 200: the second set of row / column
+// factors does not fit next to the matrix in 128 registers, and the kernel is bound by fp64 issue with four waves
+// per SIMD, not by the barrier.  Removed.)
 // ------------------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(1024) void spd_inverse_sweep_kernel(const double *__restrict__ W,
