@@ -502,6 +502,9 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
       double s = 1.0, c = 1.0, p = 0.0;
       bool underflow = false;
       for (int i = mm - 1; i >= l; --i) {
+        // the eigenvector entries of this rotation are requested first: their LDS latency passes under the scalar chain
+        double z0 = 0.0, z1 = 0.0;
+        if (lane < m) { z0 = Z[lane][i]; z1 = Z[lane][i + 1]; }
         const double ei = gete(i), di = getd(i), di1 = getd(i + 1);
         const double f = s * ei, b = c * ei;
         const double h2 = fma(f, f, g * g);
@@ -521,7 +524,6 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
         if (lane == i + 1) d = g + p;
         g = fma(c, r2, -b);
         if (lane < m) {
-          const double z0 = Z[lane][i], z1 = Z[lane][i + 1];
           Z[lane][i + 1] = fma(s, z0, c * z1);
           Z[lane][i] = fma(c, z0, -s * z1);
         }

@@ -54,9 +54,10 @@ def test_direct_method_against_numpy(n):
         _check(eng, name, G, method=2, expect_method=2)
 
 
-@pytest.mark.parametrize("n", [320, 512, 1000])
+@pytest.mark.parametrize("n", [161, 225, 257, 320, 512, 513, 1000, 1024])
 def test_direct_method_large(n):
-    """n > 160: the tridiagonalisation runs on ceil(n / 8) cooperating workgroups."""
+    """n > 160: the tridiagonalisation runs on ceil(n / 8) cooperating workgroups (register layouts of 7, 8, 16 and 32
+    elements per lane: the sizes straddle their limits; 1024 is the largest supported)."""
     from plda_amd import MPlda
     eng = MPlda(0)
     rng = np.random.default_rng(n)
