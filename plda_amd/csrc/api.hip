@@ -154,6 +154,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EIG_VARIANT")) h->eig_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EIG_DEBUG")) h->eig_debug = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_ZNORM_VARIANT")) h->znorm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
     *out = h;
     return PLDA_OK;
@@ -176,7 +177,7 @@ int plda_destroy(plda_handle *h) {
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
-                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc};
+                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->w) b.release();
     if (h->one_host) (void)hipHostFree(h->one_host);

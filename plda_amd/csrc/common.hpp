@@ -113,6 +113,8 @@ struct plda_handle {
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
   plda::DevBuf eigdc;            // eig_dc.hip workspace
+  plda::DevBuf zn_rows, zn_y, zn_small;   // z-norm statistics by moments (score.hip)
+  int znorm_variant = 0;         // PLDA_ZNORM_VARIANT=1: every LLR on the fused fp32 GEMM (A/B arm)
   const int *eigdc_flag = nullptr;   // device flag of the last direct decomposition (sym_eig_dc_status)
   int eig_variant = 0;           // PLDA_EIG_VARIANT: 0 = direct method where supported, 1 = block Jacobi always
   int eig_debug = 0;             // PLDA_EIG_DEBUG (timing experiments only: results are wrong when set)

@@ -1108,6 +1108,138 @@ int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, cons
 }
 
 // MPlda_norm (pldamodule.cpp:196-256), fused.  dbkg raw [Nb, Din]; dmodels transformed [M, Dout].
+// ------------------------------------------------------------------------------------
+// z-norm statistics by MOMENTS (default).  With the cohort on the train side (n = 1) and the models on the test
+// side the LLR is S_ij = a_i . v_j + r_i + q_j  (a_i = c x_i / var, r_i = -1/2 (L + sum w x_i^2), q_j = -1/2 sum g v_j^2:
+// exactly the operands of the trials GEMM, kept in fp64 here), so over the cohort
+//     mean_j = abar . v_j + rbar + q_j,       var_j = [v_j; 1]^T Cov_i([a_i; r_i]) [v_j; 1]       (population variance)
+// -- the statistics of every model follow from the cohort's first and second moments: one (D + 1)-wide SYRK over the
+// Nb cohort rows and one M x D x D GEMM, O((Nb + M) D^2) instead of the Nb M D of scoring every pair (C5: 2e10
+// against 4e12 flop), all in fp64 and with the covariance taken of CENTRED rows (no E[s^2] - E[s]^2 cancellation).
+// Same numbers as MPlda_norm (pldamodule.cpp:196-256: every LLR, then mean and population std per model), closer
+// to the fp64 oracle than the fused fp32 GEMM below, which stays as the A/B arm (PLDA_ZNORM_VARIANT=1).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void znorm_coef_kernel(const double *__restrict__ psi, int D,
+                                                         double *__restrict__ coef /*[3 D + 1]: ca, w, g, L*/) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    double c, var;
+    const double p = psi[d];
+    llr_coef(1.0, p, c, var);
+    coef[d] = c / var;
+    coef[D + d] = c * c / var;
+    coef[2 * D + d] = 1.0 / var - 1.0 / (1.0 + p);
+    acc += log(var) - log(1.0 + p);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) coef[3 * D] = red[0];
+}
+
+// cohort rows -> At[i] = [ca x_i ; r_i]  (one wave per row)
+__global__ void znorm_rows_kernel(const double *__restrict__ X, const double *__restrict__ coef, int D, int64_t R,
+                                  double *__restrict__ At) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const double *x = X + row * (int64_t)D;
+  double *o = At + row * (int64_t)(D + 1);
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    const double xv = x[d];
+    o[d] = coef[d] * xv;
+    acc = fma(coef[D + d] * xv, xv, acc);
+  }
+  acc = wave_sum_f64(acc);
+  if (lane == 0) o[D] = -0.5 * (acc + coef[3 * D]);
+}
+
+// column sums of a [R, C] matrix, deterministic two stages: grid (ceil(C / 64), ZS) then one block
+constexpr int ZS = 128;
+__global__ __launch_bounds__(256) void znorm_colsum_partial_kernel(const double *__restrict__ A, int64_t R, int C,
+                                                                   double *__restrict__ part /*[ZS][C]*/) {
+  __shared__ double red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int64_t per = (R + ZS - 1) / ZS, r0 = (int64_t)blockIdx.y * per, r1 = r0 + per < R ? r0 + per : R;
+  double acc = 0.0;
+  if (c < C)
+    for (int64_t r = r0 + sub; r < r1; r += 4) acc += A[r * C + c];
+  red[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void znorm_colmean_kernel(const double *__restrict__ part, int C, double invR, double *__restrict__ mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int z = 0; z < ZS; ++z) s += part[(size_t)z * C + c];
+  mean[c] = s * invR;
+}
+__global__ void znorm_centre_kernel(double *__restrict__ A, int64_t total, int C, const double *__restrict__ mean) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) A[idx] -= mean[idx % C];
+}
+
+// models: mean_j = abar . v + rbar + q_j,  var_j = v^T Cvv v + 2 v . cvr + crr  with Y_j = Cvv v_j from the GEMM
+__global__ void znorm_models_kernel(const double *__restrict__ V, const double *__restrict__ Y, const double *__restrict__ coef,
+                                    const double *__restrict__ mom /*[D + 1] means*/, const double *__restrict__ Cov /*[D+1][D+1]*/,
+                                    int D, int64_t M, double *__restrict__ out_mean, double *__restrict__ out_std) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const double *v = V + row * (int64_t)D, *y = Y + row * (int64_t)D;
+  const int D1 = D + 1;
+  double mq = 0.0, var = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    const double vd = v[d];
+    mq += mom[d] * vd - 0.5 * coef[2 * D + d] * vd * vd;
+    var += vd * (y[d] + 2.0 * Cov[(size_t)d * D1 + D]);
+  }
+  mq = wave_sum_f64(mq);
+  var = wave_sum_f64(var);
+  if (lane == 0) {
+    var += Cov[(size_t)D * D1 + D];
+    out_mean[row] = mq + mom[D];
+    out_std[row] = sqrt(var > 0.0 ? var : 0.0);
+  }
+}
+
+static int znorm_stats_moments(plda_handle *h, const double *dT, int64_t Nb, const double *dmodels, int64_t M,
+                               double *dmean, double *dstd) {
+  const int D = h->Dout, D1 = D + 1;
+  PLDA_HIP(h, h->zn_rows.reserve((size_t)Nb * D1 * 8));
+  PLDA_HIP(h, h->zn_y.reserve((size_t)M * D * 8));
+  PLDA_HIP(h, h->zn_small.reserve(((size_t)3 * D + 1 + (size_t)ZS * D1 + D1 + (size_t)D1 * D1) * 8));
+  double *At = h->zn_rows.as<double>(), *Y = h->zn_y.as<double>();
+  double *coef = h->zn_small.as<double>(), *part = coef + 3 * D + 1, *mom = part + (size_t)ZS * D1, *Cov = mom + D1;
+  const int wpb = 4;
+  {
+    TraceScope ts(h, "norm.cohort_moments", 2.0 * (double)Nb * D1 * D1, 1);
+    znorm_coef_kernel<<<1, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, coef);
+    znorm_rows_kernel<<<(unsigned)ceil_div(Nb, wpb), wpb * 64, 0, h->stream>>>(dT, coef, D, Nb, At);
+    znorm_colsum_partial_kernel<<<dim3((unsigned)ceil_div(D1, 64), ZS), 256, 0, h->stream>>>(At, Nb, D1, part);
+    znorm_colmean_kernel<<<(unsigned)ceil_div(D1, 256), 256, 0, h->stream>>>(part, D1, 1.0 / (double)Nb, mom);
+    const int64_t total = Nb * (int64_t)D1;
+    znorm_centre_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, h->stream>>>(At, total, D1, mom);
+    PLDA_LAUNCH_CHECK(h);
+    // population covariance of the centred rows: At^T At / Nb (the SYRK kernels of the fit)
+    PLDA_TRY(gemm_f64(h, D1, D1, Nb, 1.0 / (double)Nb, At, 1, D1, At, D1, 1, nullptr, 0.0, Cov, D1));
+  }
+  {
+    TraceScope ts(h, "norm.model_statistics", 2.0 * (double)M * D * D, 1);
+    // Y = V Cvv  (Cvv = the leading D x D block of Cov, row stride D + 1)
+    PLDA_TRY(gemm_f64(h, M, D, D, 1.0, dmodels, D, 1, Cov, D1, 1, nullptr, 0.0, Y, D));
+    znorm_models_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(dmodels, Y, coef, mom, Cov, D, M, dmean, dstd);
+    PLDA_LAUNCH_CHECK(h);
+  }
+  return PLDA_OK;
+}
+
 int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
                        const double *dmodels, int64_t M, double *dmean, double *dstd) {
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "norm: model not fitted");
@@ -1119,6 +1251,8 @@ int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_e
   if (num_examples <= 0) num_examples = (int)Nb;
   PLDA_TRY(transform_rows_device(h, dbkg, Nb, Din, nullptr, num_examples, dT));
   // cohort = train side with n = 1 (quirk Q7, :235); models = test side
+  if (h->znorm_variant != 1) return znorm_stats_moments(h, dT, Nb, dmodels, M, dmean, dstd);
+  // ---- A/B arm: every LLR on the fp32 MFMA GEMM with the fused (sum, sum of squares) epilogue ----
   TrialOperands op;
   PLDA_TRY(prepare_operands(h, dT, nullptr, 1, Nb, dmodels, M, nullptr, nullptr, op));
   PLDA_HIP(h, h->w[9].reserve((size_t)op.Npad * (8 + 8 + 4)));
