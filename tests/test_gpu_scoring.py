@@ -194,3 +194,34 @@ def test_sharded_scorer_on_device_tensors(engine, oracle):
     assert full is loc and loc.shape == (150, 90)
     assert (np.abs(loc.cpu().numpy() - ref) <= score_tol(ref)).all()
     engine.set_stream(None)
+
+
+@pytest.mark.parametrize("d,nb,nmodels", [(48, 391, 40), (200, 1000, 64), (207, 600, 5), (208, 700, 3), (230, 520, 7), (10, 2, 4),
+                                          (33, 1, 6)])
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant):
+    """MPlda_norm (pldamodule.cpp:196-256).  Arm 0 (default): statistics from the cohort's fp64 moments -- the LLR is
+    bilinear in (cohort row, model) plus a bias on each side -- held to 1e-9 against the oracle's explicit per-pair
+    loop; arm 1: every LLR on the fp32 GEMM with the fused sum / sum-of-squares epilogue, held to the 1e-4 of
+    north_star.  Shapes straddle the (D + 1)-wide SYRK's kernel choice (D + 1 = 208 | 209) and the degenerate cohorts
+    of one and two rows (std = 0 exactly for one row, as the reference's population std)."""
+    monkeypatch.setenv("PLDA_ZNORM_VARIANT", variant)
+    from plda_amd import MPlda
+    m, x, y = _model(oracle, 16, 1500, d, 30, scale_between=0.5)
+    eng = MPlda(0)
+    _load(eng, m)
+    rng = np.random.default_rng(d + nb)
+    bkg = rng.random((nb, d))
+    models = np.stack([oracle.transform_ivector(m, r, 1) for r in rng.random((nmodels, d)) + 0.1])
+    rm, rs = oracle.norm(m, bkg, models)
+    enrol = {int(k): (1, models[k]) for k in range(nmodels)}
+    eng.norm(bkg, enrol)
+    zm, zs = eng.znorm_stats()
+    gm = np.array([zm[k] for k in range(nmodels)]); gs = np.array([zs[k] for k in range(nmodels)])
+    tol = 1e-9 if variant == "0" else 1e-4
+    scale = np.maximum(np.abs(rm), np.abs(rm).mean())
+    assert (np.abs(gm - rm) <= tol * scale).all(), (np.abs(gm - rm) / scale).max()
+    if nb == 1:
+        assert (gs == 0.0).all() if variant == "0" else (np.abs(gs) <= 1e-3 * scale).all()
+    else:
+        assert (np.abs(gs - rs) <= tol * np.maximum(rs, 1e-3 * scale)).all(), (np.abs(gs - rs) / rs).max()
