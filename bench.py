@@ -346,6 +346,24 @@ def main():
         except Exception as e:   # noqa: BLE001
             gather_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- norm(): z-norm statistics of the first 50k enrol models over a 200k-row cohort (the C5 shape at this D),
+    #      outside the timed region: MPlda_norm, pldamodule.cpp:196-256 ----
+    zn = None
+    if rank == 0 and world == 1 and not emu and not args.no_extra and not args.targetdim:
+        zM, zNb = min(M, 50000), 200000
+        gz = torch.Generator(device=dev); gz.manual_seed(5)
+        cohort = torch.rand((zNb, D), dtype=torch.float64, device=dev, generator=gz)
+        zmean = torch.empty(zM, dtype=torch.float64, device=dev); zstd = torch.empty(zM, dtype=torch.float64, device=dev)
+        eng.znorm_stats_dev(cohort.data_ptr(), zNb, zNb, D, dU.data_ptr(), zM, zmean.data_ptr(), zstd.data_ptr())
+        torch.cuda.synchronize(dev)
+        tz = time.perf_counter()
+        eng.znorm_stats_dev(cohort.data_ptr(), zNb, zNb, D, dU.data_ptr(), zM, zmean.data_ptr(), zstd.data_ptr())
+        torch.cuda.synchronize(dev)
+        zn = {"models": zM, "cohort": zNb, "ms": round((time.perf_counter() - tz) * 1e3, 3),
+              "pairs_the_reference_scores": zM * zNb, "finite": bool(torch.isfinite(zmean).all() and torch.isfinite(zstd).all()),
+              "how": "cohort moments in fp64: (D+1)-wide SYRK over the cohort + one M x D x D GEMM (DESIGN.md, row a13)"}
+        del cohort, zmean, zstd
+
     # ---- build extension named by BASELINE configs[1]: targetdim = 150 (top-psi dims), same trials ----
     td = None
     if rank == 0 and world == 1 and args.config == "C2" and not args.targetdim and dout > 150 and not args.no_extra:
@@ -396,6 +414,8 @@ def main():
         }
         if td:
             res["targetdim150"] = td
+        if zn:
+            res["znorm_stats"] = zn
         if gather_info:
             res["gather_inclusive"] = gather_info
         if not args.no_cpu and world == 1:
