@@ -574,8 +574,14 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
                                    dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
                                    (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt,
                                    /*reuse_packed_B=*/r0 > 0));   // the test side is packed once, not per slab
-      PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
-                                   (size_t)m, hipMemcpyDeviceToHost, h->stream));
+      // a contiguous slab goes out as one linear copy.  (What bounds this entry point is the first touch of the
+      // caller's freshly allocated pageable output: 28 GB/s against 52 GB/s into touched pages,
+      // scripts/probe/pcie_probe.hip; 4.1e9 trials/s end to end at 20k x 20k.)
+      if (ld_out == Nt)
+        PLDA_HIP(h, hipMemcpyAsync(out + r0 * ld_out, dO.p, (size_t)m * Nt * 4, hipMemcpyDeviceToHost, h->stream));
+      else
+        PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
+                                     (size_t)m, hipMemcpyDeviceToHost, h->stream));
       PLDA_HIP(h, hipStreamSynchronize(h->stream));
     }
     h->last_M = M;
