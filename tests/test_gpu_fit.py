@@ -307,3 +307,27 @@ def test_fit_alternative_arms_agree(oracle, monkeypatch, env):
     assert _rel(g["transform"].T @ g["transform"], ref["transform"].T @ ref["transform"]) < 1e-8
     it = alt.fit_internals()
     assert _rel(it["W"], ref["W"]) < 1e-8 and _rel(it["B"], ref["B"]) < 1e-8
+
+
+def test_fit_recovers_a_generating_two_covariance_model():
+    """The product against a known answer that is nobody's restatement (see tests/test_oracle.py, same data): the fitted
+    psi approaches the generalised eigenvalues of the generating (B*, W*), the transform whitens the generating W*."""
+    from scipy.linalg import eigh
+    from plda_amd import MPlda
+    rng = np.random.default_rng(11)
+    d, K, n = 5, 3000, 8
+    a = rng.standard_normal((d, d)); Wt = a @ a.T / d + 0.5 * np.eye(d)
+    b = rng.standard_normal((d, d)); Bt = 2.0 * (b @ b.T / d) + 0.2 * np.eye(d)
+    mu = rng.standard_normal(d)
+    yk = rng.multivariate_normal(np.zeros(d), Bt, K)
+    x = mu + np.repeat(yk, n, axis=0) + rng.multivariate_normal(np.zeros(d), Wt, K * n)
+    labels = np.repeat(np.arange(K, dtype=np.uint64), n)
+    eng = MPlda(0)
+    eng.fit(x, labels, 40)
+    m = eng.get_model()
+    ref_psi = np.sort(eigh(Bt, Wt, eigvals_only=True))[::-1]
+    assert np.abs(m["mean"] - mu).max() < 5.0 / np.sqrt(K)
+    assert np.abs(m["psi"] - ref_psi).max() < 0.12 * ref_psi.max()
+    T = m["transform"]
+    assert np.abs(T @ Wt @ T.T - np.eye(d)).max() < 0.1
+    assert np.abs(T @ Bt @ T.T - np.diag(ref_psi)).max() < 0.15 * ref_psi.max()

@@ -160,3 +160,29 @@ def test_eer_restatement_properties():
     thr, far, frr, e = onp.eer(neg, pos)
     n32, p32 = neg.astype(np.float32).astype(np.float64), pos.astype(np.float32).astype(np.float64)
     assert far == (n32 >= thr).mean() and frr == (p32 < thr).mean() and abs(far - frr) < 0.01
+
+
+def test_em_recovers_a_generating_two_covariance_model(oracle):
+    """A known-answer test that does not come from this repository's own restatement: data DRAWN from the
+    two-covariance model  x_ki = mu + y_k + e_ki,  y_k ~ N(0, B*),  e_ki ~ N(0, W*)  with many balanced speakers.
+    The estimator the reference drives (Kaldi PldaEstimator through pldamodule.cpp:94-106; with equal n_k the wrapper's
+    1/n_k class weight is a constant) is maximum likelihood for exactly this model, so its fixed point must approach
+    (mu, W*, B*) at the sampling rate 1/sqrt(K); psi must approach the generalised eigenvalues of (B*, W*)."""
+    from scipy.linalg import eigh
+    rng = np.random.default_rng(11)
+    d, K, n = 5, 3000, 8
+    a = rng.standard_normal((d, d)); Wt = a @ a.T / d + 0.5 * np.eye(d)
+    b = rng.standard_normal((d, d)); Bt = 2.0 * (b @ b.T / d) + 0.2 * np.eye(d)
+    mu = rng.standard_normal(d)
+    yk = rng.multivariate_normal(np.zeros(d), Bt, K)
+    x = mu + np.repeat(yk, n, axis=0) + rng.multivariate_normal(np.zeros(d), Wt, K * n)
+    labels = np.repeat(np.arange(K, dtype=np.uint64), n)
+    m = oracle.fit(x, labels, 40)
+    assert np.abs(m["mean"] - mu).max() < 5.0 / np.sqrt(K)
+    assert np.abs(m["W"] - Wt).max() < 0.06 * np.abs(Wt).max()           # K n = 24 000 samples of the within part
+    assert np.abs(m["B"] - Bt).max() < 0.12 * np.abs(Bt).max()           # K = 3 000 samples of the between part
+    ref_psi = np.sort(eigh(Bt, Wt, eigvals_only=True))[::-1]
+    assert np.abs(m["psi"] - ref_psi).max() < 0.12 * ref_psi.max()
+    # and the transform whitens the TRUE within-class covariance up to the same sampling error
+    T = m["transform"]
+    assert np.abs(T @ Wt @ T.T - np.eye(d)).max() < 0.1
