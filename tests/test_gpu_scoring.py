@@ -225,3 +225,27 @@ def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant
         assert (gs == 0.0).all() if variant == "0" else (np.abs(gs) <= 1e-3 * scale).all()
     else:
         assert (np.abs(gs - rs) <= tol * np.maximum(rs, 1e-3 * scale)).all(), (np.abs(gs - rs) / rs).max()
+
+
+@pytest.mark.parametrize("d,n_enrol", [(1, 1), (1, 4), (7, 3), (200, 1)])
+def test_llr_against_the_closed_form_gaussian_ratio(d, n_enrol):
+    """A known answer that is not the oracle: in the PLDA space (diagonal psi, unit within-class variance) the mean u
+    of n enrolment vectors and a test vector v of the same speaker are jointly Gaussian with covariance
+    [[psi + 1/n, psi], [psi, psi + 1]] per dimension, so  LLR = sum_d log N(v_d | psi u_d / (psi + 1/n),
+    psi + 1 - psi^2 / (psi + 1/n)) - log N(v_d | 0, psi + 1)  (Plda::LogLikelihoodRatio, pldamodule.cpp:266).
+    Both the fp32 GEMM matrix and the fp64 trial-list kernel must give it."""
+    from scipy.stats import norm
+    from plda_amd import MPlda
+    rng = np.random.default_rng(100 + d)
+    psi = np.sort(rng.random(d) * 5.0 + 1e-3)[::-1].copy()
+    eng = MPlda(0)
+    eng.set_model(np.zeros(d), np.eye(d), psi)
+    U, V = rng.standard_normal((33, d)) * 1.5, rng.standard_normal((41, d)) * 1.5
+    cmean = (psi / (psi + 1.0 / n_enrol))[None, None, :] * U[:, None, :]
+    cvar = psi + 1.0 - psi * psi / (psi + 1.0 / n_enrol)
+    ref = (norm.logpdf(V[None, :, :], cmean, np.sqrt(cvar)) - norm.logpdf(V[None, :, :], 0.0, np.sqrt(psi + 1.0))).sum(-1)
+    got = eng.score_matrix((n_enrol, U), (1, V))
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
+    e, t = np.repeat(np.arange(33), 41), np.tile(np.arange(41), 33)
+    lst = eng.score_trials((np.full(33, n_enrol, np.int32), U), (1, V), e, t).reshape(33, 41)
+    assert np.abs(lst - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
