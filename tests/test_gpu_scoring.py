@@ -249,3 +249,29 @@ def test_llr_against_the_closed_form_gaussian_ratio(d, n_enrol):
     e, t = np.repeat(np.arange(33), 41), np.tile(np.arange(41), 33)
     lst = eng.score_trials((np.full(33, n_enrol, np.int32), U), (1, V), e, t).reshape(33, 41)
     assert np.abs(lst - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_znorm_statistics_against_the_closed_form():
+    """norm() against numbers that come from neither the oracle nor the engine's own kernels: with T = I, mean = 0 the
+    cohort rows are only length-normalised (Plda::TransformIvector with num_examples = Nb, pldamodule.cpp:224:
+    x * sqrt(D / sum x^2 / (psi + 1/Nb))), every (cohort row as 1-utterance enrolment, model as test) LLR is the
+    closed-form Gaussian ratio of the test above, and the statistics are their mean and POPULATION std per model."""
+    from scipy.stats import norm
+    from plda_amd import MPlda
+    rng = np.random.default_rng(77)
+    d, nb, nm = 24, 300, 17
+    psi = np.sort(rng.random(d) * 3.0 + 0.05)[::-1].copy()
+    eng = MPlda(0)
+    eng.set_model(np.zeros(d), np.eye(d), psi)
+    bkg = rng.standard_normal((nb, d))
+    models = rng.standard_normal((nm, d)) * 1.3
+    t = bkg * np.sqrt(d / (bkg * bkg / (psi + 1.0 / nb)).sum(1))[:, None]
+    cmean = (psi / (psi + 1.0))[None, None, :] * t[:, None, :]
+    cvar = psi + 1.0 - psi * psi / (psi + 1.0)
+    llr = (norm.logpdf(models[None, :, :], cmean, np.sqrt(cvar)) - norm.logpdf(models[None, :, :], 0.0, np.sqrt(psi + 1.0))).sum(-1)
+    rm, rs = llr.mean(0), llr.std(0)
+    eng.norm(bkg, {int(k): (1, models[k]) for k in range(nm)})
+    zm, zs = eng.znorm_stats()
+    gm = np.array([zm[k] for k in range(nm)]); gs = np.array([zs[k] for k in range(nm)])
+    assert np.abs(gm - rm).max() <= 1e-10 * np.abs(rm).max(), np.abs(gm - rm).max()
+    assert (np.abs(gs - rs) <= 1e-9 * rs).all(), (np.abs(gs - rs) / rs).max()
