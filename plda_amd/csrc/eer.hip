@@ -10,7 +10,7 @@
 // Sort-free: g(k) = FRR - FAR "after score k" is non-decreasing in k, so the minimum of |g|
 // is at the smallest key k1 with g(k1) >= 0 or at its predecessor.  k1 is found EXACTLY by
 // three HBM-bound passes over the fp32 scores that histogram an order-preserving uint32 key
-// 11 + 11 + 10 bits at a time (per-block LDS histograms, float4 loads), with the crossing
+// 11 + 11 + 10 bits at a time (per-block LDS histograms, float4 loads, column strips), with the crossing
 // located in integer arithmetic on the host between passes.  Algorithmic bytes: 3 x 4 B per trial read, nothing written.
 #include "common.hpp"
 
@@ -38,12 +38,8 @@ constexpr int EER_BINS = 2048;
 // key below and the smallest key above the prefix range (needed for neighbours in pass 2).
 typedef float f32x4e __attribute__((ext_vector_type(4)));
 
-// MATRIX: blocks stride over rows, threads over groups of 4 columns (one aligned float4 load
-// per thread when the row base allows it); otherwise a flat list with a fixed class.
-template <bool MATRIX>
-__global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__ scores, int64_t ld, int64_t M,
-                                                       int64_t Nt, const int64_t *__restrict__ espk,
-                                                       const int64_t *__restrict__ tspk, int fixed_class,
+// Flat list of scores of one class (the two-list form of scoring/eer.py).
+__global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__ scores, int64_t Nt, int fixed_class,
                                                        int shift, int nbits, unsigned prefix, int has_prefix,
                                                        unsigned long long *__restrict__ hist /*[2][EER_BINS]*/,
                                                        unsigned *__restrict__ below, unsigned *__restrict__ above) {
@@ -53,8 +49,6 @@ __global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__
   const unsigned mask = (1u << nbits) - 1u;
   const int hi_shift = shift + nbits;
   unsigned lo_max = 0u, hi_min = 0xffffffffu;
-  const int64_t cols4 = (Nt + 3) / 4;
-  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
 
   auto account = [&](bool ok, float sc, int cls) {
     unsigned bin = 0xffffffffu;   // inactive
@@ -66,44 +60,89 @@ __global__ __launch_bounds__(256) void eer_hist_kernel(const float *__restrict__
         bin = ((k >> shift) & mask) | ((unsigned)cls << 11);
       }
     }
-    // plain non-returning LDS atomics: measured 2.8 TB/s over 120 GB, against 1.8 TB/s when lanes
-    // with equal bins were first aggregated with 12 ballots per element
+    // plain non-returning LDS atomics: aggregating lanes with equal bins first (12 ballots per element) was slower
     if (bin != 0xffffffffu) atomicAdd(&lh[bin >> 11][bin & 2047u], 1u);
   };
 
-  if (MATRIX) {
-    for (int64_t row = blockIdx.x; row < M; row += gridDim.x) {
-      const int64_t spk = espk[row];
-      const float *srow = scores + row * ld;
-      for (int64_t c4 = threadIdx.x; c4 - threadIdx.x < cols4; c4 += 256) {
-        const int64_t col = c4 * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        bool ok[4];
-        int cls[4];
-        if (c4 < cols4 && vec && col + 3 < Nt) {
-          const f32x4e x = __builtin_nontemporal_load(reinterpret_cast<const f32x4e *>(srow + col));
-          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (c4 < cols4 && col + e < Nt) v[e] = srow[col + e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ok[e] = c4 < cols4 && col + e < Nt;
-          cls[e] = ok[e] ? (tspk[col + e] == spk ? 1 : 0) : 0;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) account(ok[e], v[e], cls[e]);
-      }
-    }
-  } else {
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx - threadIdx.x < Nt; idx += (int64_t)gridDim.x * 256)
-      account(idx < Nt, idx < Nt ? scores[idx] : 0.f, fixed_class);
-  }
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx - threadIdx.x < Nt; idx += (int64_t)gridDim.x * 256)
+    account(idx < Nt, idx < Nt ? scores[idx] : 0.f, fixed_class);
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * EER_BINS; i += 256) {
     const unsigned v = (&lh[0][0])[i];
     if (v) atomicAdd(hist + i, (unsigned long long)v);
+  }
+  if (has_prefix) {
+    if (lo_max) atomicMax(below, lo_max);
+    if (hi_min != 0xffffffffu) atomicMin(above, hi_min);
+  }
+}
+
+// Matrix pass, strip layout: a workgroup owns EER_STRIP columns -- 4 per thread, whose speaker ids stay in
+// registers -- and walks down a slice of the rows, so that the only per-trial memory traffic is the 4-byte score.
+// (Workgroups walking along rows re-read the 8-byte speaker id of every column for every row: 12 B of cache
+// traffic per trial, 39.4 ms for the three passes over 1e10 trials against 20.4 ms here, identical results:
+// profiles/r02_eer_probe.json.)  Four rows are loaded before they are accounted for.
+constexpr int EER_STRIP = 1024;
+__global__ __launch_bounds__(256) void eer_hist_strip_kernel(const float *__restrict__ scores, int64_t ld, int64_t M,
+                                                             int64_t Nt, const int64_t *__restrict__ espk,
+                                                             const int64_t *__restrict__ tspk, int64_t rows_per_wg,
+                                                             int shift, int nbits, unsigned prefix, int has_prefix,
+                                                             unsigned long long *__restrict__ hist,
+                                                             unsigned *__restrict__ below, unsigned *__restrict__ above) {
+  __shared__ unsigned lh[2][EER_BINS];
+  for (int i = threadIdx.x; i < 2 * EER_BINS; i += 256) (&lh[0][0])[i] = 0;
+  __syncthreads();
+  const unsigned mask = (1u << nbits) - 1u;
+  const int hi_shift = shift + nbits;
+  unsigned lo_max = 0u, hi_min = 0xffffffffu;
+  const int64_t strips = (Nt + EER_STRIP - 1) / EER_STRIP;
+  const int64_t strip = blockIdx.x % strips, slice = blockIdx.x / strips;
+  const int64_t col = strip * EER_STRIP + (int64_t)threadIdx.x * 4;
+  const int64_t r0 = slice * rows_per_wg, r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+  int64_t ts[4];
+  bool ok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ok[e] = col + e < Nt;
+    ts[e] = ok[e] ? tspk[col + e] : 0;
+  }
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && ok[3];
+
+  auto account = [&](float sc, int cls) {
+    const unsigned k = score_key(sc);
+    if (has_prefix && (k >> hi_shift) != prefix) {
+      if ((k >> hi_shift) < prefix) lo_max = k > lo_max ? k : lo_max; else hi_min = k < hi_min ? k : hi_min;
+    } else {
+      atomicAdd(&lh[cls][(k >> shift) & mask], 1u);
+    }
+  };
+
+  for (int64_t row = r0; row < r1; row += 4) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (row + u >= r1) break;
+      const float *src = scores + (row + u) * ld + col;
+      if (vec) {
+        const f32x4e x = __builtin_nontemporal_load(reinterpret_cast<const f32x4e *>(src));
+        v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = ok[e] ? src[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (row + u >= r1) break;
+      const int64_t spk = espk[row + u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (ok[e]) account(v[u][e], ts[e] == spk ? 1 : 0);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * EER_BINS; i += 256) {
+    const unsigned c = (&lh[0][0])[i];
+    if (c) atomicAdd(hist + i, (unsigned long long)c);
   }
   if (has_prefix) {
     if (lo_max) atomicMax(below, lo_max);
@@ -126,16 +165,20 @@ static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, 
   PLDA_HIP(h, hipMemsetAsync(dhist, 0, 2 * EER_BINS * 8, h->stream));
   if (src.scores) {
     const unsigned grid = (unsigned)std::min<int64_t>(src.M, 256 * 16);
-    if (grid)
-      eer_hist_kernel<true><<<grid, 256, 0, h->stream>>>(src.scores, src.ld, src.M, src.Nt, src.espk, src.tspk, 0, shift,
-                                                         nbits, prefix, has_prefix, dhist, dbelow, dabove);
+    if (grid) {
+      const int64_t strips = ceil_div(src.Nt, (int64_t)EER_STRIP);
+      const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(src.M, (256 * 16) / strips));
+      const int64_t rows_per_wg = ceil_div(src.M, slices);
+      eer_hist_strip_kernel<<<(unsigned)(strips * ceil_div(src.M, rows_per_wg)), 256, 0, h->stream>>>(
+          src.scores, src.ld, src.M, src.Nt, src.espk, src.tspk, rows_per_wg, shift, nbits, prefix, has_prefix, dhist,
+          dbelow, dabove);
+    }
   } else {
     for (int c = 0; c < 2; ++c) {
       const float *p = c ? src.pos : src.neg;
       const int64_t n = c ? src.np : src.nn;
       const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 256), 256 * 16);
-      eer_hist_kernel<false><<<grid, 256, 0, h->stream>>>(p, n, 1, n, nullptr, nullptr, c, shift, nbits, prefix,
-                                                          has_prefix, dhist, dbelow, dabove);
+      eer_hist_kernel<<<grid, 256, 0, h->stream>>>(p, n, c, shift, nbits, prefix, has_prefix, dhist, dbelow, dabove);
     }
   }
   PLDA_LAUNCH_CHECK(h);
