@@ -63,6 +63,37 @@ def test_eer_of_a_trials_matrix(eng, oracle):
     assert eer.format_line(out[1], out[2], out[0]).startswith("EER = ")
 
 
+@pytest.mark.parametrize("m,nt,ld,k", [(1, 2, 2, 1), (3, 5, 7, 2), (2, 1023, 1023, 3), (257, 1023, 1023, 9),
+                                       (300, 1025, 1028, 16), (7, 4099, 4100, 5), (5000, 3001, 3001, 40)])
+def test_eer_of_ragged_matrices(eng, m, nt, ld, k):
+    """The matrix passes give each workgroup a strip of 1024 columns and a slice of the rows, four rows at a time:
+    widths that are not a multiple of 4 or of 1024, padded and unaligned leading dimensions, fewer rows than one
+    group of four, quantised scores (ties across the two classes)."""
+    import torch
+    from plda_amd import eer
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(m * 7919 + nt)
+    es = rng.integers(0, k, m); ts = rng.integers(0, k, nt)
+    es[0] = ts[0] = 0                                   # at least one target ...
+    if k > 1:
+        ts[-1] = 1; es[-1] = 0                          # ... and one impostor
+    tgt = es[:, None] == ts[None, :]
+    if k == 1:
+        tgt[0, -1] = False; ts = ts.copy(); ts[-1] = 7  # a speaker nobody enrolled
+        tgt = es[:, None] == ts[None, :]
+    Sh = (rng.standard_normal((m, ld)) * 8).astype(np.float32)
+    Sh[:, :nt] += 12.0 * tgt
+    if m * nt < 1_000_000:
+        Sh = np.round(Sh * 4) / 4
+    S = torch.from_numpy(Sh).to(dev)
+    des, dts = torch.from_numpy(es).to(dev), torch.from_numpy(ts).to(dev)
+    out = eer.eer_from_matrix_dev(eng, S.data_ptr(), ld, m, nt, des.data_ptr(), dts.data_ptr())
+    sub = Sh[:, :nt]
+    ref = onp.eer(sub[~tgt], sub[tgt])
+    assert out[4] == tgt.sum() and out[5] == (~tgt).sum()
+    assert tuple(out[1:4]) == ref[1:] and out[0] == pytest.approx(ref[0], rel=1e-12)
+
+
 def _eer_rank(rank, world, port, q):
     import os
     import sys
