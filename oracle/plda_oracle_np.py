@@ -91,6 +91,58 @@ def fit(X, labels, iters=10, return_wb=False):
     return model
 
 
+def _inv_longdouble(A):
+    """Gauss-Jordan with partial pivoting in np.longdouble (numpy.linalg has no extended-precision path)."""
+    m = A.shape[0]
+    M = np.concatenate([A.astype(np.longdouble), np.eye(m, dtype=np.longdouble)], 1)
+    for p in range(m):
+        q = p + int(np.argmax(np.abs(M[p:, p])))
+        if q != p:
+            M[[p, q]] = M[[q, p]]
+        M[p] /= M[p, p]
+        col = M[:, p].copy()
+        col[p] = 0
+        M -= np.outer(col, M[p])
+    return M[:, m:]
+
+
+def fit_wb_longdouble(X, labels, iters):
+    """stats + em_iter above, step for step, in x87 extended precision (64-bit mantissa, eps 1.1e-19): the
+    yardstick for ill-conditioned fits (fewer samples than dimensions), where two fp64 implementations of the same
+    EM legitimately differ by cond * eps and the question is which one is off.  Returns (W, B) as longdouble;
+    O(iters * groups * D^3) in NumPy row operations -- D of a few hundred at most."""
+    LD = np.longdouble
+    assert np.finfo(LD).eps < 1e-18, "np.longdouble is not extended precision on this platform"
+    X = np.asarray(X, np.float64).astype(LD)
+    labels = np.asarray(labels).astype(np.int64)
+    K = int(labels.max()) + 1
+    D = X.shape[1]
+    counts = np.bincount(labels, minlength=K)
+    means = np.stack([X[labels == c].sum(0) / LD(counts[c]) for c in range(K)])
+    w = LD(1) / counts.astype(LD)
+    scatter = np.zeros((D, D), LD)
+    for c in range(K):
+        xc = X[labels == c] - means[c]
+        scatter += (xc.T @ xc) * w[c]
+    mu = (means * w[:, None]).sum(0) / w.sum()
+    W, B = np.eye(D, dtype=LD), np.eye(D, dtype=LD)
+    for _ in range(iters):
+        Winv, Binv = _inv_longdouble(W), _inv_longdouble(B)
+        Wst, Bst = scatter.copy(), np.zeros((D, D), LD)
+        for n in np.unique(counts):
+            sel = counts == n
+            kg = LD(int(sel.sum()))
+            mixed = _inv_longdouble(Binv + LD(int(n)) * Winv)
+            m = means[sel] - mu
+            ww = (mixed @ (LD(int(n)) * (Winv @ m.T))).T
+            e = m - ww
+            Bst += (kg / LD(int(n))) * mixed + (ww.T @ ww) / LD(int(n))
+            Wst += kg * mixed + e.T @ e
+        W, B = Wst / LD(K), Bst / w.sum()
+        W, B = (W + W.T) / 2, (B + B.T) / 2
+    return W, B
+
+
 def transform_ivector(model, x, n, normalize_length=True, simple_length_norm=False):
     """TransformIvector (A.5); x may be [D] or [R,D] with n scalar or [R]."""
     x = np.atleast_2d(np.asarray(x, np.float64))

@@ -82,7 +82,7 @@ struct plda_handle {
   bool simdiag_has_vr = false;
   bool eig_keep_sign = false;   // LDA: keep negative eigenvalues (PLDA floors them, Kaldi ApplyFloor)
 
-  bool panel_attr_set[4] = {false, false, false, false};
+  bool panel_attr_set[16] = {};
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
@@ -193,6 +193,7 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
 // X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
 int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
                     int *dflag, int batch);
+// [batch] SPD inverses of any size (A^-1 = T^T T, T = blocked whitening); out may be A itself; scr: 3 n^2 doubles each
 int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
                         int64_t so, double *scr, int64_t sscr, int *dflag, int batch);
 // symmetric eigendecomposition of G (row-major, destroyed): eigenvalues sorted

@@ -272,12 +272,15 @@ __global__ void gather_center_kernel(const double *__restrict__ means, const dou
   out[idx] = means[(int64_t)cls[r] * D + d] - mu[d];
 }
 
-// A_g = W + n_g B
+// A_g = W + n_g B (and, for the refinement step of Q, a copy of B per group)
 __global__ void em_group_A_kernel(const double *__restrict__ W, const double *__restrict__ B,
-                                  const double *__restrict__ gn, int64_t DD, double *__restrict__ A) {
+                                  const double *__restrict__ gn, int64_t DD, double *__restrict__ A,
+                                  double *__restrict__ Bcopy) {
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (idx >= DD) return;
-  A[(int64_t)blockIdx.y * DD + idx] = fma(gn[blockIdx.y], B[idx], W[idx]);
+  const double b = B[idx];
+  A[(int64_t)blockIdx.y * DD + idx] = fma(gn[blockIdx.y], b, W[idx]);
+  if (Bcopy) Bcopy[(int64_t)blockIdx.y * DD + idx] = b;
 }
 
 // M-step from the per-group matrices (i <= j computes both (i,j) and (j,i), then symmetrises):
@@ -569,20 +572,35 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     else PLDA_TRY(gemm_f64(h, D, D, K, 1.0, Mg, 1, D, Mg, D, 1, nullptr, 0.0, Csum, D));
     const int64_t sDD = (int64_t)DD;
     for (int it = 0; it < iters; ++it) {
-      // b2 = A^-1 ; b0 = Q = B A^-1 ; b1 = Mx = W Q^T ; b2 = QC = Q C_g ; b3 = QCQ = QC Q^T
+      // inv = A^-1 ; Q = B A^-1 ; b1 = Mx = W Q^T ; QC = Q C_g (over inv) ; b3 = QCQ = QC Q^T
+      double *inv = b2, *Q = b0;
       if (D <= 256) {
-        PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, b2, dflag, G));                     // registers, one CU per group
+        PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, inv, dflag, G));                    // registers, one CU per group
       } else {
-        // block elimination down to <= 256-row sweeps (b1 is free here: scratch)
-        em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0);
+        // A^-1 = T^T T from the blocked whitening; A is dead once T exists, so the inverse replaces it in b0,
+        // and b1 .. b3 (contiguous) are the 3 D^2 doubles of scratch per group
+        inv = b0; Q = b2;
+        em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0, nullptr);
         PLDA_LAUNCH_CHECK(h);
-        PLDA_TRY(spd_inverse_blocked(h, b0, D, D, sDD, b2, D, sDD, b1, sDD, dflag, G));
+        PLDA_TRY(spd_inverse_blocked(h, b0, D, D, sDD, inv, D, sDD, b1, 3 * sDD, dflag, G));
       }
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, B, D, 1, 0, b2, D, 1, sDD, nullptr, 0.0, b0, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, W, D, 1, 0, b0, 1, D, sDD, nullptr, 0.0, b1, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b0, D, 1, sDD, Cg, D, 1, sDD, nullptr, 0.0, b2, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b2, D, 1, sDD, b0, 1, D, sDD, nullptr, 0.0, b3, D, sDD, G));
-      em_group_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, b1, b2, b3, dgn, dgk, G, D, cntW, cntB, W, B);
+      double *QC = inv;
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, B, D, 1, 0, inv, D, 1, sDD, nullptr, 0.0, Q, D, sDD, G));
+      // One step of iterative refinement on Q A = B:  Q += (B - Q A) A^-1  (b1 = A, b3 = residual; both free here).
+      // An explicit inverse is accurate relative to ITS norm: when A has tiny eigenvalues (fewer samples than
+      // dimensions: the directions without data shrink with every iteration) that norm is huge and the O(1) block
+      // of A^-1 that acts on the class means carries an absolute error eps * ||A^-1||.  The residual B - Q A is
+      // made of O(1) numbers, so the step restores that block; what it adds in the tiny directions is multiplied
+      // by the tiny parts of W and B afterwards.  Against a long-double EM (N = 149, D = 200, six iterations,
+      // cond(W) = 3e8): W 3.5e-10 -> 3e-14, B 3.4e-8 -> 2e-13 (the reference's own formulation: 7e-13, 3e-10).
+      em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b1, b3);
+      PLDA_LAUNCH_CHECK(h);
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, -1.0, Q, D, 1, sDD, b1, D, 1, sDD, nullptr, 1.0, b3, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b3, D, 1, sDD, inv, D, 1, sDD, nullptr, 1.0, Q, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, W, D, 1, 0, Q, 1, D, sDD, nullptr, 0.0, b1, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, Q, D, 1, sDD, Cg, D, 1, sDD, nullptr, 0.0, QC, D, sDD, G));
+      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, QC, D, 1, sDD, Q, 1, D, sDD, nullptr, 0.0, b3, D, sDD, G));
+      em_group_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, b1, QC, b3, dgn, dgk, G, D, cntW, cntB, W, B);
       PLDA_LAUNCH_CHECK(h);
     }
     int hflag = 0;

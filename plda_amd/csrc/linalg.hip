@@ -7,8 +7,8 @@
 //                 optional per-k weights (weighted SYRK X^T diag(w) X), deterministic split-K, batching;
 //                 a panel-resident 32x32 kernel for the small K <= 256 products of the EM
 //   chol_small / spd_inverse_small   Cholesky factor / SPD inverse with the matrix resident in the
-//                 registers of one workgroup (D <= 256); whiten_blocked / spd_inverse_blocked extend
-//                 them to any size by block elimination (GEMMs on the panel kernel)
+//                 registers of one workgroup (D <= 256); whiten_blocked extends the Cholesky to any size by
+//                 block elimination (GEMMs on the panel kernel), spd_inverse_blocked = T^T T from it
 //   tri_invert    forward substitution, one wave per column, solution held in registers
 //   sym_eig_f64   one-sided (Hestenes) block Jacobi: one workgroup per pair of 4-row blocks and outer
 //                 round (Gram matrix on the MFMA pipe, 8x8 two-sided sweep in one wave, one apply pass);
@@ -580,55 +580,68 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
 // workgroups on the chip and walk K in 13 dependent load -> LDS -> MFMA rounds.  Here a workgroup owns a
 // 32 x 32 tile, pulls the WHOLE K extent of both operand panels into LDS with every load in flight at
 // once (one memory latency), then runs the MFMAs back to back.
-template <bool AKC, bool BKC>
+// Panel kernel for the small products of the EM, the whitening and GetOutput (M, N <= 1024, few tiles): a workgroup
+// owns a 32 x 32 tile of C and stages 32 rows of each operand over a K chunk of 64 NB values in LDS, every load of
+// the chunk in flight at once (8 NB per operand and thread, no integer division in the index math: with batches of
+// 8 + 8 loads and idx / K the 200^3 products of the EM took 14 us, four memory round trips and ~100 divisions per
+// thread).  K > 256 runs in chunks of 256 with the accumulators kept.
+template <bool KC, int NB>
+__device__ __forceinline__ void panel_fetch(double (&v)[8 * NB], const double *__restrict__ P, int64_t s_row, int64_t s_k,
+                                            int r0, int R, int kn, int t) {
+#pragma unroll
+  for (int u = 0; u < 8 * NB; ++u) {
+    int r, k;
+    if (KC) { r = (t >> 4) + 16 * (u & 1); k = (t & 15) + 16 * (u >> 1); }   // 16 lanes along k: 128-byte segments
+    else { r = t & 31; k = (t >> 5) + 8 * u; }                              // 32 lanes along the rows
+    const int gr = r0 + r;
+    v[u] = (k < kn && gr < R) ? P[(int64_t)gr * s_row + (int64_t)k * s_k] : 0.0;
+  }
+}
+template <bool KC, int NB>
+__device__ __forceinline__ void panel_stage(const double (&v)[8 * NB], double *__restrict__ S, int t) {
+  constexpr int ld = 64 * NB + 1;
+#pragma unroll
+  for (int u = 0; u < 8 * NB; ++u) {
+    int r, k;
+    if (KC) { r = (t >> 4) + 16 * (u & 1); k = (t & 15) + 16 * (u >> 1); }
+    else { r = t & 31; k = (t >> 5) + 8 * u; }
+    S[r * ld + k] = v[u];
+  }
+}
+
+template <bool AKC, bool BKC, int NB>
 __global__ __launch_bounds__(256) void gemm_f64_panel_kernel(int M, int N, int K, double alpha,
                                                              const double *__restrict__ A, int64_t sam, int64_t sak,
                                                              const double *__restrict__ B, int64_t sbk, int64_t sbn,
                                                              double beta, double *__restrict__ C, int64_t ldc,
                                                              int64_t strideA, int64_t strideB, int64_t strideC) {
   extern __shared__ __attribute__((aligned(16))) double panel[];   // As[32][ld], Bs[32][ld]
-  const int Kp = (K + 3) & ~3, ld = Kp + 1;
+  constexpr int kc = 64 * NB, ld = kc + 1;
   double *As = panel, *Bs = panel + 32 * ld;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   A += (int64_t)blockIdx.z * strideA;
   B += (int64_t)blockIdx.z * strideB;
   C += (int64_t)blockIdx.z * strideC;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int total = 32 * Kp;
-  // batches of 8 + 8 independent loads per thread are issued before any of them is consumed
-  for (int base = 0; base < total; base += 8 * 256) {
-    double ra[8], rb[8];
-    int la[8], lb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256 + t;
-      int m, k;
-      if (AKC) { m = idx / Kp; k = idx - m * Kp; } else { k = idx >> 5; m = idx & 31; }
-      const int gm = m0 + m;
-      la[u] = idx < total ? m * ld + k : -1;
-      ra[u] = (idx < total && gm < M && k < K) ? A[gm * sam + k * sak] : 0.0;
-      int n, kb;
-      if (BKC) { n = idx / Kp; kb = idx - n * Kp; } else { kb = idx >> 5; n = idx & 31; }
-      const int gn = n0 + n;
-      lb[u] = idx < total ? n * ld + kb : -1;
-      rb[u] = (idx < total && gn < N && kb < K) ? B[gn * sbn + kb * sbk] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (la[u] >= 0) As[la[u]] = ra[u];
-      if (lb[u] >= 0) Bs[lb[u]] = rb[u];
-    }
-  }
-  __syncthreads();
   const int wm = wave >> 1, wn = wave & 1, fi = lane & 15, fk = lane >> 4;
   const double *ap = As + (wm * 16 + fi) * ld + fk, *bp = Bs + (wn * 16 + fi) * ld + fk;
   f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  int kk = 0;
-  for (; kk + 8 <= Kp; kk += 8) {
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk + 4], bp[kk + 4], acc1, 0, 0, 0);
+  for (int k0 = 0; k0 < K; k0 += kc) {
+    const int kn = min(kc, K - k0), Kp = (kn + 3) & ~3;
+    double va[8 * NB], vb[8 * NB];
+    panel_fetch<AKC, NB>(va, A + (int64_t)k0 * sak, sam, sak, m0, M, kn, t);
+    panel_fetch<BKC, NB>(vb, B + (int64_t)k0 * sbk, sbn, sbk, n0, N, kn, t);
+    if (k0) __syncthreads();        // the previous chunk has been consumed
+    panel_stage<AKC, NB>(va, As, t);
+    panel_stage<BKC, NB>(vb, Bs, t);
+    __syncthreads();
+    int kk = 0;
+    for (; kk + 8 <= Kp; kk += 8) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk + 4], bp[kk + 4], acc1, 0, 0, 0);
+    }
+    if (kk < Kp) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc0, 0, 0, 0);
   }
-  if (kk < Kp) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk], bp[kk], acc0, 0, 0, 0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + wm * 16 + fk + 4 * r, col = n0 + wn * 16 + fi;
@@ -651,30 +664,40 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
     return fail(h, PLDA_E_INVAL, "gemm_f64: operands need one unit stride");
   // X^T diag(w) X with both operands the same rows: the symmetric kernel (PLDA_GEMM64_VARIANT=2 keeps the
   // general one, for A/B measurements)
-  if (batch == 1 && A == B && M == N && !akc && !bkc && sak == sbk && sam == 1 && sbn == 1 && K >= 512 && M >= 32 &&
+  if (batch == 1 && A == B && M == N && !akc && !bkc && sak == sbk && sam == 1 && sbn == 1 && K >= 2048 && M >= 32 &&
       M <= 1024 && h->gemm64_variant != 2)
     return syrk_f64(h, (int)M, K, alpha, A, sak, kw, beta, C, ldc);
   const int64_t tiles = ceil_div(M, GB) * ceil_div(N, GB);
-  if (K <= 256 && M <= 1024 && N <= 1024 && !kw) {
-    const size_t lds = (size_t)2 * 32 * (((K + 3) & ~3) + 1) * 8;
+  // the panel kernel: every K <= 256, and deeper products whose 64 x 64 tiles would leave most of the chip idle
+  if (M <= 1024 && N <= 1024 && !kw && (K <= 256 || (K <= 2048 && tiles * batch < 256)) && h->gemm64_variant != 4) {
+    const int nb = (int)std::min<int64_t>(4, ceil_div(K, 64));
+    const size_t lds = (size_t)2 * 32 * (64 * nb + 1) * 8;
     const dim3 pgrid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), (unsigned)batch);
     if (batch > 65535) return fail(h, PLDA_E_INVAL, "gemm_f64: batch %d too large", batch);
-#define PANEL_LAUNCH(AK, BK)                                                                                  \
+#define PANEL_LAUNCH(AK, BK, NBB)                                                                             \
   do {                                                                                                        \
-    bool &attr_done = h->panel_attr_set[(AK ? 2 : 0) + (BK ? 1 : 0)];                                         \
+    bool &attr_done = h->panel_attr_set[((AK ? 2 : 0) + (BK ? 1 : 0)) * 4 + NBB - 1];                         \
     if (!attr_done) {                                                                                         \
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f64_panel_kernel<AK, BK>),         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 257 * 8));          \
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f64_panel_kernel<AK, BK, NBB>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * (64 * NBB + 1) * 8)); \
       attr_done = true;                                                                                       \
     }                                                                                                         \
-    gemm_f64_panel_kernel<AK, BK><<<pgrid, 256, lds, h->stream>>>((int)M, (int)N, (int)K, alpha, A, sam, sak, \
-                                                                  B, sbk, sbn, beta, C, ldc, strideA, strideB, \
-                                                                  strideC);                                   \
+    gemm_f64_panel_kernel<AK, BK, NBB><<<pgrid, 256, lds, h->stream>>>((int)M, (int)N, (int)K, alpha, A, sam, \
+                                                                       sak, B, sbk, sbn, beta, C, ldc,        \
+                                                                       strideA, strideB, strideC);            \
   } while (0)
-    if (akc && bkc) PANEL_LAUNCH(true, true);
-    else if (akc && !bkc) PANEL_LAUNCH(true, false);
-    else if (!akc && bkc) PANEL_LAUNCH(false, true);
-    else PANEL_LAUNCH(false, false);
+#define PANEL_NB(AK, BK)                                                                                      \
+  do {                                                                                                        \
+    if (nb == 1) PANEL_LAUNCH(AK, BK, 1);                                                                     \
+    else if (nb == 2) PANEL_LAUNCH(AK, BK, 2);                                                                \
+    else if (nb == 3) PANEL_LAUNCH(AK, BK, 3);                                                                \
+    else PANEL_LAUNCH(AK, BK, 4);                                                                             \
+  } while (0)
+    if (akc && bkc) PANEL_NB(true, true);
+    else if (akc && !bkc) PANEL_NB(true, false);
+    else if (!akc && bkc) PANEL_NB(false, true);
+    else PANEL_NB(false, false);
+#undef PANEL_NB
 #undef PANEL_LAUNCH
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
@@ -752,10 +775,10 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // ------------------------------------------------------------------------------------
 template <int E>
 __global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict__ L, double *__restrict__ X, int D,
-                                                        int ldx, int64_t stride_x) {
+                                                        int ldx, int64_t stride_x, int64_t stride_l) {
   const int j = blockIdx.x;
   const int lane = threadIdx.x;
-  L += (size_t)blockIdx.y * D * D;
+  L += (int64_t)blockIdx.y * stride_l;
   X += (int64_t)blockIdx.y * stride_x;
   double x[E], r0[E], r1[E], r2[E], r3[E];
 #pragma unroll
@@ -807,9 +830,10 @@ __global__ __launch_bounds__(64) void tri_invert_kernel(const double *__restrict
   }
 }
 
-int tri_invert_ld(plda_handle *h, const double *L, double *X, int D, int ldx, int64_t stride_x, int batch) {
+// L: [batch] D x D factors, leading dimension D, batch stride stride_l
+int tri_invert_ld(plda_handle *h, const double *L, int64_t stride_l, double *X, int D, int ldx, int64_t stride_x, int batch) {
   const int E = (int)ceil_div(D, 64);
-#define TI(EE) tri_invert_kernel<EE><<<dim3(D, batch), 64, 0, h->stream>>>(L, X, D, ldx, stride_x)
+#define TI(EE) tri_invert_kernel<EE><<<dim3(D, batch), 64, 0, h->stream>>>(L, X, D, ldx, stride_x, stride_l)
   if (E <= 1) TI(1);
   else if (E <= 2) TI(2);
   else if (E <= 4) TI(4);
@@ -1049,63 +1073,55 @@ __global__ void copy_block_kernel(const double *__restrict__ src, int lds, int64
   else d[(int64_t)r * ldd + c] = v;
 }
 
-// SPD inverse of any size by block elimination on top of the register-resident sweep:
-//   A = [A11 A12; A12^T A22],  X11 = A11^-1,  Y = X11 A12,  S = A22 - A12^T Y,
-//   A^-1 = [X11 + Y S^-1 Y^T,  -Y S^-1;  (.)^T,  S^-1].
-// A11 and the Schur complement S are SPD, so the recursion bottoms out in sweeps of <= 256 rows; everything
-// else is GEMMs with K <= n/2 (the panel-resident kernel).  A: [batch] matrices, leading dimension lda, batch
-// stride sa; out likewise; `scr`: n * n doubles of scratch per batch entry (stride sscr) cover all levels
-// (a level uses n2 * n <= n^2 / 2 of it, the next level starts behind that).
-int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
-                        int64_t so, double *scr, int64_t sscr, int *dflag, int batch) {
-  if (n <= 256) return spd_inverse_small(h, A, nullptr, nullptr, n, lda, sa, out, ldo, so, dflag, batch);
-  const int n1 = (int)round_up((int64_t)ceil_div(n, 2), 32), n2 = n - n1;
-  const double *A12 = A + n1, *A22 = A + (int64_t)n1 * lda + n1;
-  double *O11 = out, *O12 = out + n1, *O21 = out + (int64_t)n1 * ldo, *O22 = out + (int64_t)n1 * ldo + n1;
-  double *Y = scr;                                 // [n1][n2]
-  double *S = scr + (int64_t)n1 * n2;              // [n2][n2]
-  double *sub = scr + (int64_t)n2 * n;             // scratch of the next level
-  const dim3 g22((unsigned)ceil_div((int64_t)n2 * n2, 256), (unsigned)batch);
-  const dim3 g12((unsigned)ceil_div((int64_t)n1 * n2, 256), (unsigned)batch);
-  PLDA_TRY(spd_inverse_blocked(h, A, n1, lda, sa, O11, ldo, so, sub, sscr, dflag, batch));           // O11 = X11
-  PLDA_TRY(gemm_f64_batched(h, n1, n2, n1, 1.0, O11, ldo, 1, so, A12, lda, 1, sa, nullptr, 0.0, Y, n2, sscr, batch));
-  copy_block_kernel<<<g22, 256, 0, h->stream>>>(A22, lda, sa, S, n2, sscr, n2, n2, false);
-  PLDA_LAUNCH_CHECK(h);
-  // S -= A12^T Y : (m, k) of A12^T = A12[k][m]
-  PLDA_TRY(gemm_f64_batched(h, n2, n2, n1, -1.0, A12, 1, lda, sa, Y, n2, 1, sscr, nullptr, 1.0, S, n2, sscr, batch));
-  PLDA_TRY(spd_inverse_blocked(h, S, n2, n2, sscr, O22, ldo, so, sub, sscr, dflag, batch));           // O22 = S^-1
-  PLDA_TRY(gemm_f64_batched(h, n1, n2, n2, -1.0, Y, n2, 1, sscr, O22, ldo, 1, so, nullptr, 0.0, O12, ldo, so, batch));
-  // O11 = X11 - O12 Y^T : (k, n) of Y^T = Y[n][k]
-  PLDA_TRY(gemm_f64_batched(h, n1, n1, n2, -1.0, O12, ldo, 1, so, Y, 1, n2, sscr, nullptr, 1.0, O11, ldo, so, batch));
-  copy_block_kernel<<<g12, 256, 0, h->stream>>>(O12, ldo, so, O21, ldo, so, n1, n2, true);
-  PLDA_LAUNCH_CHECK(h);
-  return PLDA_OK;
+__global__ void zero_block_kernel(double *__restrict__ dst, int ldd, int64_t strided, int rows, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  dst[(int64_t)blockIdx.y * strided + (int64_t)(idx / cols) * ldd + idx % cols] = 0.0;
 }
 
-// Whitening factor T (lower triangular, T A T^T = I, i.e. T = chol(A)^-1) of an SPD matrix of any size by
+// Whitening factor T (lower triangular, T A T^T = I, i.e. T = chol(A)^-1) of [batch] SPD matrices of any size by
 // block elimination over the register-resident Cholesky:
 //   T11 = whiten(A11),  Y = T11 A12,  S = A22 - Y^T Y,  T22 = whiten(S),  T21 = -T22 Y^T T11.
-// `scr`: 2 n^2 doubles.
-int whiten_blocked(plda_handle *h, const double *A, int n, int lda, double *T, int ldt, double *scr, int *dflag) {
+// A: leading dimension lda, batch stride sa; T: ldt, st; `scr`: 2 n^2 doubles per matrix, batch stride sscr.
+// The Schur complement is formed from the Cholesky factor of A11 (Y^T Y), as a blocked Cholesky does.  Block
+// elimination with the explicit INVERSE of A11 instead (S = A22 - A12^T A11^-1 A12, the first version of the EM's
+// D > 256 inverse) loses the small eigen-directions when A11 is itself ill conditioned: with fewer samples than
+// dimensions (N - K < n1) the EM's W came out with 1000 x the error in psi of this form or of the unblocked sweep
+// (scripts/stress_case.py shape 150 257 4 6 0.2: 6.5e-4 against 6e-7 at cond(W) = 1.4e9).
+int whiten_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *T, int ldt, int64_t st,
+                   double *scr, int64_t sscr, int *dflag, int batch) {
   if (n <= 256) {
-    PLDA_TRY(chol_small(h, A, n, lda, 0, scr, n, 0, dflag, 1));
-    return tri_invert_ld(h, scr, T, n, ldt, 0, 1);
+    PLDA_TRY(chol_small(h, A, n, lda, sa, scr, n, sscr, dflag, batch));
+    return tri_invert_ld(h, scr, sscr, T, n, ldt, st, batch);
   }
   const int n1 = (int)round_up((int64_t)ceil_div(n, 2), 32), n2 = n - n1;
   const double *A12 = A + n1, *A22 = A + (int64_t)n1 * lda + n1;
   double *T11 = T, *T12 = T + n1, *T21 = T + (int64_t)n1 * ldt, *T22 = T + (int64_t)n1 * ldt + n1;
   double *Y = scr, *S = Y + (int64_t)n1 * n2, *tmp = S + (int64_t)n2 * n2, *sub = tmp + (int64_t)n2 * n1;
-  PLDA_TRY(whiten_blocked(h, A, n1, lda, T11, ldt, sub, dflag));
-  PLDA_TRY(gemm_f64(h, n1, n2, n1, 1.0, T11, ldt, 1, A12, lda, 1, nullptr, 0.0, Y, n2));
-  copy_block_kernel<<<dim3((unsigned)ceil_div((int64_t)n2 * n2, 256), 1), 256, 0, h->stream>>>(A22, lda, 0, S, n2, 0,
-                                                                                           n2, n2, false);
+  const unsigned ub = (unsigned)batch;
+  PLDA_TRY(whiten_blocked(h, A, n1, lda, sa, T11, ldt, st, sub, sscr, dflag, batch));
+  PLDA_TRY(gemm_f64_batched(h, n1, n2, n1, 1.0, T11, ldt, 1, st, A12, lda, 1, sa, nullptr, 0.0, Y, n2, sscr, batch));
+  copy_block_kernel<<<dim3((unsigned)ceil_div((int64_t)n2 * n2, 256), ub), 256, 0, h->stream>>>(A22, lda, sa, S, n2, sscr,
+                                                                                            n2, n2, false);
   PLDA_LAUNCH_CHECK(h);
-  PLDA_TRY(gemm_f64(h, n2, n2, n1, -1.0, Y, 1, n2, Y, n2, 1, nullptr, 1.0, S, n2));
-  PLDA_TRY(whiten_blocked(h, S, n2, n2, T22, ldt, sub, dflag));
-  PLDA_TRY(gemm_f64(h, n2, n1, n1, 1.0, Y, 1, n2, T11, ldt, 1, nullptr, 0.0, tmp, n1));
-  PLDA_TRY(gemm_f64(h, n2, n1, n2, -1.0, T22, ldt, 1, tmp, n1, 1, nullptr, 0.0, T21, ldt));
-  PLDA_HIP(h, hipMemset2DAsync(T12, (size_t)ldt * 8, 0, (size_t)n2 * 8, (size_t)n1, h->stream));
+  PLDA_TRY(gemm_f64_batched(h, n2, n2, n1, -1.0, Y, 1, n2, sscr, Y, n2, 1, sscr, nullptr, 1.0, S, n2, sscr, batch));
+  PLDA_TRY(whiten_blocked(h, S, n2, n2, sscr, T22, ldt, st, sub, sscr, dflag, batch));
+  PLDA_TRY(gemm_f64_batched(h, n2, n1, n1, 1.0, Y, 1, n2, sscr, T11, ldt, 1, st, nullptr, 0.0, tmp, n1, sscr, batch));
+  PLDA_TRY(gemm_f64_batched(h, n2, n1, n2, -1.0, T22, ldt, 1, st, tmp, n1, 1, sscr, nullptr, 0.0, T21, ldt, st, batch));
+  zero_block_kernel<<<dim3((unsigned)ceil_div((int64_t)n1 * n2, 256), ub), 256, 0, h->stream>>>(T12, ldt, st, n1, n2);
+  PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
+}
+
+// SPD inverse of [batch] matrices of any size: A^-1 = T^T T with T = whiten(A).  out may be A (dead once T exists), not scr;
+// `scr`: 3 n^2 doubles per matrix (T + the whitening's scratch), batch stride sscr.
+int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
+                        int64_t so, double *scr, int64_t sscr, int *dflag, int batch) {
+  if (n <= 256) return spd_inverse_small(h, A, nullptr, nullptr, n, lda, sa, out, ldo, so, dflag, batch);
+  double *T = scr;
+  PLDA_TRY(whiten_blocked(h, A, n, lda, sa, T, n, sscr, scr + (int64_t)n * n, sscr, dflag, batch));
+  // (m, k) of T^T = T[k][m]
+  return gemm_f64_batched(h, n, n, n, 1.0, T, 1, n, sscr, T, n, 1, sscr, nullptr, 0.0, out, ldo, so, batch);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1592,7 +1608,7 @@ static int simdiag_run(plda_handle *h, const double *W, const double *B, int D, 
   // the Cholesky one, as in the reference's GetOutput.)
   {
     TraceScope ts(h, "getoutput.whiten (chol + inverse)");
-    PLDA_TRY(whiten_blocked(h, W, D, D, T1, D, scr, dflag));
+    PLDA_TRY(whiten_blocked(h, W, D, D, 0, T1, D, 0, scr, 0, dflag, 1));
   }
   if (!direct) {
     // checked HERE for the Jacobi solver: with a W that is not positive definite T1 is full of NaNs, and it would

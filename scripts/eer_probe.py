@@ -17,7 +17,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 
 
 eng = MPlda(0)
-eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 res = {"N": N, "ragged": []}
 g = torch.Generator(device=dev); g.manual_seed(3)
 for (m, nt, ld, k) in [(1, 1, 1, 1), (3, 5, 7, 2), (257, 1023, 1023, 9), (300, 1025, 1028, 16), (1000, 4099, 4100, 50), (5000, 3001, 3001, 40)]:

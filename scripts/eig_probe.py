@@ -14,7 +14,7 @@ for spec in sys.argv[1:] or ["200:0", "200:1", "512:0", "512:1"]:
     os.environ["PLDA_EIG_VARIANT"] = variant
     N, K = (100000, 5000) if D <= 256 else (200000, 5000)
     eng = MPlda(0)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     g = torch.Generator(device=dev); g.manual_seed(1)
     X = torch.rand((N, D), dtype=torch.float64, device=dev, generator=g)
     y = (torch.arange(N, device=dev) % K).to(torch.int64)

@@ -14,7 +14,7 @@ rng = np.random.default_rng(0)
 q, _ = np.linalg.qr(rng.standard_normal((D, D)))
 e = MPlda(0)
 e.set_model(rng.random(D), q * (1.0 + rng.random(D))[:, None], np.sort(rng.random(D) * 4.0)[::-1].copy())
-e.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+e.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 e.profile_enable(True)
 U = torch.from_numpy(rng.standard_normal((N, D))).to(dev)
 out = torch.empty((N, N), dtype=torch.float32, device=dev)

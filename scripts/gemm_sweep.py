@@ -23,7 +23,7 @@ for v in variants:
     os.environ["PLDA_GEMM_VARIANT"] = str(v)
     e = MPlda(0)
     e.set_model(mean, T, psi)
-    e.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    e.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     e.profile_enable(True)
     engines[v] = e
 X = torch.from_numpy(rng.random((N, D))).to(dev)

@@ -45,7 +45,7 @@ def c3():
     """1M x-vectors, D=512, 10k speakers; fit; 10k speaker models (n=100) x 1M tests."""
     N, D, K = 1_000_000, 512, 10_000
     rng = np.random.default_rng(3)
-    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     X = torch.from_numpy(rng.random((N, D))).to(dev)
     y = torch.from_numpy((np.arange(N) % K).astype(np.int64)).to(dev)
     eng.fit_dev(X.data_ptr(), N, D, y.data_ptr(), K, 10)
@@ -89,7 +89,7 @@ def c4_shard():
     D, M, Nt = 256, 5000, 1_200_000
     rng = np.random.default_rng(4)
     q, _ = np.linalg.qr(rng.standard_normal((D, D)))
-    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     eng.set_model(rng.random(D), q * (1 + rng.random(D))[:, None], np.sort(rng.random(D) * 5)[::-1].copy())
     counts = rng.integers(1, 6, M).astype(np.int32)
     dn = torch.from_numpy(counts).to(dev)
@@ -109,7 +109,7 @@ def c5():
     D, M, Nb = 200, 50_000, 200_000
     rng = np.random.default_rng(5)
     q, _ = np.linalg.qr(rng.standard_normal((D, D)))
-    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     eng.set_model(rng.random(D), q * (1 + rng.random(D))[:, None], np.sort(rng.random(D) * 5)[::-1].copy())
     E = torch.from_numpy(rng.random((M, D))).to(dev)
     dU = torch.empty((M, D), dtype=torch.float64, device=dev)
@@ -145,7 +145,7 @@ def c2_skew():
     sizes = rng.integers(5, 61, K)
     sizes = np.floor(sizes * (N / sizes.sum())).astype(np.int64); sizes[-1] += N - sizes.sum()
     y = np.repeat(np.arange(K), sizes); rng.shuffle(y)
-    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     X = torch.from_numpy(rng.random((N, D)) + 0.3 * rng.standard_normal((K, D))[y]).to(dev)
     yy = torch.from_numpy(y.astype(np.int64)).to(dev)
     eng.fit_dev(X.data_ptr(), N, D, yy.data_ptr(), K, 10)
@@ -179,7 +179,7 @@ def eer_full():
     from plda_amd import eer
     D, N, K = 200, 100_000, 5000
     rng = np.random.default_rng(8)
-    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     y = (np.arange(N) % K)
     X = rng.random((N, D)) + 0.25 * rng.standard_normal((K, D))[y]
     dX = torch.from_numpy(X).to(dev); dy = torch.from_numpy(y.astype(np.int64)).to(dev)
@@ -207,7 +207,7 @@ def frontend():
     """d-vector pooling: 200k utterances x 100 frames x 64 dims, float32 -> HBM GB/s."""
     import ctypes as C
     U, F, D = 200_000, 100, 64
-    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng = MPlda(0); eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     frames = torch.randn((U * F, D), dtype=torch.float32, device=dev)
     off = torch.arange(0, (U + 1) * F, F, dtype=torch.int64, device=dev)
     out = torch.empty((U, D), dtype=torch.float64, device=dev)

@@ -16,6 +16,7 @@ from plda_amd.lda import LDA                        # noqa: E402
 
 ob.build()
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # second argument: offset of every seed (fresh cases)
 fails = []
 
 
@@ -24,7 +25,7 @@ def rel(a, b):
 
 
 for case in range(ncases):
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(1000 + case + seed0)
     d = int(rng.choice([1, 2, 3, 5, 8, 17, 31, 32, 33, 64, 100, 129, 200, 257, 300]))
     k = int(rng.integers(2, 40))
     n = int(max(k * 2, rng.integers(k + 1, 40 * k)))
@@ -33,7 +34,7 @@ for case in range(ncases):
     between = float(rng.choice([0.0, 0.2, 1.0]))
     tag = "case %d: N=%d D=%d K=%d skew=%s iters=%d between=%.1f" % (case, n, d, k, skew, iters, between)
     try:
-        x, y = make_data(5000 + case, n, d, k, skew=skew, scale_between=between)
+        x, y = make_data(5000 + case + seed0, n, d, k, skew=skew, scale_between=between)
         eng = MPlda(0)
         eng.fit(x, y, iters)
         ref = ob.fit(x, y, iters)

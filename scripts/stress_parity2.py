@@ -19,19 +19,20 @@ import torch                                        # noqa: E402
 
 ob.build()
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # second argument: offset of every seed (fresh cases)
 fails = []
 dev = torch.device("cuda", 0)
 tmp = tempfile.mkdtemp()
 
 for case in range(ncases):
-    rng = np.random.default_rng(7000 + case)
+    rng = np.random.default_rng(7000 + case + seed0)
     tag = "case %d" % case
     try:
         # ---- z-norm ----
         d = int(rng.choice([2, 5, 16, 40, 64, 150, 200, 256]))
         k = int(rng.integers(3, 30))
         n = int(rng.integers(4 * k, 30 * k))
-        x, y = make_data(9000 + case, n, d, k, skew=True, scale_between=float(rng.choice([0.1, 0.5, 1.0])))
+        x, y = make_data(9000 + case + seed0, n, d, k, skew=True, scale_between=float(rng.choice([0.1, 0.5, 1.0])))
         eng = MPlda(0)
         eng.fit(x, y, 3)
         m = eng.get_model()

@@ -14,14 +14,15 @@ from plda_amd import MPlda              # noqa: E402
 
 ob.build()
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # second argument: offset of every seed (fresh cases)
 fails = []
 for case in range(ncases):
-    rng = np.random.default_rng(300 + case)
+    rng = np.random.default_rng(300 + case + seed0)
     d = int(rng.choice([48, 64, 100, 128, 200, 260]))
     k = int(rng.integers(50, 700))
     n = int(rng.integers(3 * k, 40 * k))
     iters = int(rng.integers(1, 6))
-    x, y = make_data(400 + case, n, d, k, skew=True, scale_between=float(rng.choice([0.0, 0.3, 1.0])))
+    x, y = make_data(400 + case + seed0, n, d, k, skew=True, scale_between=float(rng.choice([0.0, 0.3, 1.0])))
     eng = MPlda(0)
     t0 = time.perf_counter(); eng.fit(x, y, iters); tg = time.perf_counter() - t0
     t0 = time.perf_counter(); ref = ob.fit(x, y, iters); tc = time.perf_counter() - t0

@@ -121,7 +121,7 @@ def _default_case(monkeypatch, d, n_enrol, znorm, seed):
     from oracle import plda_oracle_np as onp
     dev = torch.device("cuda", 0)
     eng, psi = _engine(monkeypatch, None, d, seed)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     eng.profile_enable(True)
     m = nt = 8192
     rng = np.random.default_rng(seed)
@@ -181,7 +181,7 @@ def test_operand_over_4gib(monkeypatch):
     dev = torch.device("cuda", 0)
     d, m, nt = 512, 256, 1_017_000
     eng, psi = _engine(monkeypatch, None, d, 31)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     g = torch.Generator(device=dev); g.manual_seed(5)
     dV = torch.randn((nt, d), dtype=torch.float64, device=dev, generator=g)
     dU = torch.randn((m, d), dtype=torch.float64, device=dev, generator=g)

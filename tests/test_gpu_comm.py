@@ -31,7 +31,7 @@ def test_block_cyclic_shards_tile_the_matrix(world, block, mixed):
     dV = torch.from_numpy(rng.standard_normal((nt, d))).to(dev)
     n = torch.from_numpy(rng.integers(1, 6, m).astype(np.int32)).to(dev) if mixed else None
     eng = _engine(d)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     full = torch.empty((m, nt), dtype=torch.float32, device=dev)
     eng.score_matrix_dev(dU.data_ptr(), n.data_ptr() if mixed else None, 0 if mixed else 3, m, dV.data_ptr(), nt,
                          full.data_ptr(), nt)
@@ -63,7 +63,7 @@ def test_real_communicator_world_1():
     d, m, nt = 40, 700, 900
     rng = np.random.default_rng(6)
     eng = _engine(d)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     uid = MPlda.comm_unique_id()
     assert len(uid) == 128
     eng.comm_init(1, 0, uid)

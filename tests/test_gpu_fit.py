@@ -274,8 +274,8 @@ def test_fit_em_dev_rejects_bad_statistics():
 
 @pytest.mark.parametrize("d,k", [(288, 40), (512, 30), (700, 24)])
 def test_fit_large_dim_blocked_inverse(oracle, d, k):
-    """D > 256: (W + nB)^-1 by block elimination over the register-resident sweep (one and two levels);
-    skewed counts give several groups in the batch."""
+    """D > 256: (W + nB)^-1 = T^T T from the blocked whitening (one and two levels of block elimination over the
+    register-resident Cholesky); skewed counts give several groups in the batch."""
     from plda_amd import MPlda
     x, y = make_data(40 + d, 3 * d, d, k, skew=True, scale_between=0.3)
     eng = MPlda(0)
@@ -286,6 +286,51 @@ def test_fit_large_dim_blocked_inverse(oracle, d, k):
     assert _rel(it["B"], ref["B"]) < 1e-8, _rel(it["B"], ref["B"])
     g = eng.get_model()
     assert np.abs(g["psi"] - ref["psi"]).max() <= 1e-8 * max(ref["psi"].max(), 1e-12)
+
+
+@pytest.mark.parametrize("n,d,k", [(150, 200, 4), (150, 257, 4), (150, 300, 4), (300, 512, 8)])
+def test_fit_with_fewer_samples_than_dimensions(oracle, n, d, k):
+    """N - K < D: the within-class scatter is singular and every EM iteration multiplies cond(W) by ~40 (1e9 after
+    six).  Any two fp64 implementations then differ by about cond * eps -- the C and NumPy oracles by 5e-7 in psi --
+    and the engine has to stay at that level.  (Regression: block elimination with the explicit inverse of the
+    leading block gave 6.5e-4 at D = 257 and 300, where that block is itself ill conditioned.)"""
+    from plda_amd import MPlda
+    x, y = make_data(5000, n, d, k, scale_between=0.2)
+    eng = MPlda(0)
+    eng.fit(x, y, 6)
+    ref = oracle.fit(x, y, 6)
+    assert np.linalg.cond(ref["W"]) > 1e8
+    it = eng.fit_internals()
+    assert _rel(it["W"], ref["W"]) < 2e-9, _rel(it["W"], ref["W"])
+    g = eng.get_model()
+    e_psi = np.abs(g["psi"] - ref["psi"]).max() / ref["psi"].max()
+    assert e_psi < 2e-5, e_psi
+
+
+@pytest.mark.parametrize("n,d,k,skew", [(48, 64, 4, False), (90, 128, 6, True), (149, 200, 5, True)])
+def test_em_against_extended_precision_when_ill_conditioned(oracle, n, d, k, skew):
+    """Fewer samples than dimensions, six iterations: W and B against the same EM run in x87 extended precision
+    (oracle/plda_oracle_np.py:fit_wb_longdouble).  The grouped EM with its refinement step of Q has to be at least
+    as close to it as the reference's formulation (the fp64 oracle) is -- without the step it was 500 x (W) and
+    100 x (B) further away."""
+    from oracle import plda_oracle_np as onp
+    from plda_amd import MPlda
+    x, y = make_data(777 + d, n, d, k, skew=skew, scale_between=0.5)
+    _, dense = np.unique(y, return_inverse=True)
+    Wt, Bt = onp.fit_wb_longdouble(x, dense, 6)
+    ref = oracle.fit(x, y, 6)
+    assert np.linalg.cond(ref["W"]) > 1e6
+
+    def err(a, t):
+        return float(np.abs(a.astype(np.longdouble) - t).max() / np.abs(t).max())
+
+    eng = MPlda(0)
+    eng.fit(x, y, 6)
+    it = eng.fit_internals()
+    e_w, e_b = err(it["W"], Wt), err(it["B"], Bt)
+    o_w, o_b = err(ref["W"], Wt), err(ref["B"], Bt)
+    assert e_w <= max(2 * o_w, 1e-13), (e_w, o_w)
+    assert e_b <= max(2 * o_b, 1e-12), (e_b, o_b)
 
 
 @pytest.mark.parametrize("env", [{"PLDA_EM_VARIANT": "1"}, {"PLDA_JACOBI_VARIANT": "1"}, {"PLDA_GEMM64_VARIANT": "1"}])

@@ -25,7 +25,7 @@ def test_c2_full_size_properties():
     psi = np.sort(rng.random(D) * 4.0)[::-1].copy()
     eng = MPlda(0)
     eng.set_model(rng.random(D), T, psi)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     X = torch.from_numpy(rng.random((N, D))).to(dev)
     Ut = torch.empty((N, D), dtype=torch.float64, device=dev)
     eng.transform_rows_dev(X.data_ptr(), N, D, None, 1, Ut.data_ptr())
@@ -80,7 +80,7 @@ def test_c5_full_size_fused_znorm_statistics():
     mean, T, psi = _model(D, 51)
     eng = MPlda(0)
     eng.set_model(mean, T, psi)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     g = torch.Generator(device=dev); g.manual_seed(9)
     bkg = torch.rand((Nb, D), dtype=torch.float64, device=dev, generator=g)
     models = torch.randn((M, D), dtype=torch.float64, device=dev, generator=g)
@@ -119,7 +119,7 @@ def test_c3_and_c4_shard_full_size():
         mean, T, psi = _model(D, seed)
         eng = MPlda(0)
         eng.set_model(mean, T, psi)
-        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream or None)
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         g = torch.Generator(device=dev); g.manual_seed(seed)
         dU = torch.randn((M, D), dtype=torch.float64, device=dev, generator=g)
         dV = torch.randn((Nt, D), dtype=torch.float64, device=dev, generator=g)

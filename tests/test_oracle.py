@@ -186,3 +186,14 @@ def test_em_recovers_a_generating_two_covariance_model(oracle):
     # and the transform whitens the TRUE within-class covariance up to the same sampling error
     T = m["transform"]
     assert np.abs(T @ Wt @ T.T - np.eye(d)).max() < 0.1
+
+
+def test_extended_precision_em_agrees_with_the_fp64_oracles():
+    """oracle/plda_oracle_np.py:fit_wb_longdouble is the yardstick of the ill-conditioned GPU tests: on a
+    well-conditioned problem it has to reproduce the fp64 restatements to rounding."""
+    x, y = make_data(3, 300, 12, 20, skew=True, scale_between=0.5)
+    _, dense = np.unique(y, return_inverse=True)
+    W, B = onp.fit_wb_longdouble(x, dense, 4)
+    m = onp.fit(x, dense, 4, return_wb=True)
+    assert float(np.abs(W - m["W"]).max() / np.abs(m["W"]).max()) < 1e-13
+    assert float(np.abs(B - m["B"]).max() / np.abs(m["B"]).max()) < 1e-13
