@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 flop/clk
+PEAK_FP64_MFMA_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: half of that
 
 CONFIGS = {
     # name: fit rows, featdim, speakers, enrol models, enrol counts, test vectors
@@ -364,6 +365,26 @@ def main():
               "how": "cohort moments in fp64: (D+1)-wide SYRK over the cohort + one M x D x D GEMM (DESIGN.md, row a13)"}
         del cohort, zmean, zstd
 
+    # ---- transform (K4: rows -> PLDA space -> length norm, pldamodule.cpp:111-194) of the test side's rows, outside
+    #      the timed region: 2 N D^2 flop on the fp64 MFMA pipe + a length-norm pass over the output ----
+    tf = None
+    if rank == 0 and world == 1 and not emu and not args.no_extra and not args.targetdim:
+        gx = torch.Generator(device=dev); gx.manual_seed(6)
+        Xt = torch.rand((Nt, D), dtype=torch.float64, device=dev, generator=gx)
+        Yt = torch.empty((Nt, dout), dtype=torch.float64, device=dev)
+        eng.transform_rows_dev(Xt.data_ptr(), Nt, D, None, 1, Yt.data_ptr())
+        torch.cuda.synchronize(dev)
+        tt0 = time.perf_counter()
+        for _ in range(5):
+            eng.transform_rows_dev(Xt.data_ptr(), Nt, D, None, 1, Yt.data_ptr())
+        torch.cuda.synchronize(dev)
+        tsec = (time.perf_counter() - tt0) / 5
+        tf = {"rows": Nt, "D": D, "ms": round(tsec * 1e3, 3), "rows_per_s": round(Nt / tsec, 1),
+              "TFLOPps": round(2.0 * Nt * D * dout / tsec / 1e12, 2),
+              "frac_fp64_mfma_78.6": round(2.0 * Nt * D * dout / tsec / (PEAK_FP64_MFMA_TFLOPS * 1e12), 4),
+              "GBps_in_plus_out": round(8.0 * Nt * (D + dout) / tsec / 1e9, 1)}
+        del Xt, Yt
+
     # ---- build extension named by BASELINE configs[1]: targetdim = 150 (top-psi dims), same trials ----
     td = None
     if rank == 0 and world == 1 and args.config == "C2" and not args.targetdim and dout > 150 and not args.no_extra:
@@ -416,6 +437,8 @@ def main():
             res["targetdim150"] = td
         if zn:
             res["znorm_stats"] = zn
+        if tf:
+            res["transform"] = tf
         if gather_info:
             res["gather_inclusive"] = gather_info
         if not args.no_cpu and world == 1:
