@@ -83,6 +83,8 @@ struct plda_handle {
   bool eig_keep_sign = false;   // LDA: keep negative eigenvalues (PLDA floors them, Kaldi ApplyFloor)
 
   bool panel_attr_set[16] = {};
+  bool tf_attr_set[5] = {};
+  int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass (A/B arm)
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament

@@ -876,6 +876,161 @@ __global__ void length_norm_kernel(double *__restrict__ out, int64_t R, int Dout
   for (int d = lane; d < Dout; d += 64) t[d] = f * (t[d] + offset[d]);
 }
 
+// ------------------------------------------------------------------------------------
+// K4 in one pass (Dout <= 512): out[r][:] = f_r (offset + T x_r).  A workgroup of 8 waves owns 16 * 8 / CH rows and
+// ALL columns: wave (rg, ch) accumulates 16 rows x NT 16-column tiles in v_mfma_f64_16x16x4_f64 accumulators
+// (CH = 2: two column halves per row group), so the row's sum of t_d^2 / (psi_d + 1/n) is there when the
+// contraction ends and the normalised row is written once.  (The general GEMM + length_norm_kernel pair writes
+// T x, reads it back and writes it again: 24 N D bytes moved for 16, and 17-25 % of the time.)  Operand stages
+// of 16 k: T's rows for all columns + the workgroup's rows of X, k-contiguous with a row pitch of 17 doubles
+// (conflict-free fragment reads), fetched global -> registers under the MFMAs of the previous stage and written
+// to the other buffer behind them; one barrier per stage.  Same k order and accumulator layout as gemm_f64_kernel.
+// ------------------------------------------------------------------------------------
+typedef double f64x4s __attribute__((ext_vector_type(4)));
+constexpr int TF_LD = 17;
+
+__device__ __forceinline__ double tf_rcp(double x) {   // hardware estimate + two Newton steps: full precision
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+template <int NT, int CH>
+__global__ __launch_bounds__(512) void transform_fused_kernel(const double *__restrict__ X, int64_t R, int Din,
+                                                              const double *__restrict__ T, int Dout,
+                                                              const double *__restrict__ offset,
+                                                              const double *__restrict__ psi,
+                                                              const int32_t *__restrict__ n_arr, int n_uniform,
+                                                              double *__restrict__ out) {
+  constexpr int RG = 8 / CH;              // row groups of 16
+  constexpr int ROWS = 16 * RG;
+  constexpr int COLS = 16 * NT * CH;
+  constexpr int TP = (COLS + 31) / 32;    // fetch passes over T's rows (32 rows x 16 k per pass)
+  constexpr int XP = ROWS / 32;
+  constexpr int STAGE = (COLS + ROWS) * TF_LD;
+  extern __shared__ __attribute__((aligned(16))) double tf_lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rg = wave % RG, ch = wave / RG;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+  const int lk = t & 15, lr = t >> 4;     // this thread's k and first row inside a fetch pass
+
+  f64x4s acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f64x4s{0.0, 0.0, 0.0, 0.0};
+  double rt[TP], rx[XP];
+
+  auto fetch = [&](int k0) {              // unconditional loads on clamped indices; zeroed at the LDS write
+    const int gk = min(k0 + lk, Din - 1);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) rt[p] = T[(int64_t)min(lr + 32 * p, Dout - 1) * Din + gk];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) rx[p] = X[min(r0 + lr + 32 * p, R - 1) * (int64_t)Din + gk];
+  };
+  auto stage = [&](double *buf, int k0) {
+    const bool kok = k0 + lk < Din;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+      const int n = lr + 32 * p;
+      if (n < COLS) buf[n * TF_LD + lk] = (kok && n < Dout) ? rt[p] : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) buf[(COLS + lr + 32 * p) * TF_LD + lk] = kok ? rx[p] : 0.0;
+  };
+
+  fetch(0);
+  stage(tf_lds, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < Din; k0 += 16) {
+    const bool more = k0 + 16 < Din;
+    if (more) fetch(k0 + 16);
+    const double *Ts = tf_lds + cur * STAGE, *Xs = Ts + COLS * TF_LD;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double a = Xs[(rg * 16 + fi) * TF_LD + kk * 4 + fk];
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const double b = Ts[((ch * NT + tn) * 16 + fi) * TF_LD + kk * 4 + fk];
+        acc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tn], 0, 0, 0);
+      }
+      // fragment reads stay inside their k-step (all four steps' reads hoisted to the top of the stage need
+      // 4 x (1 + NT) register pairs next to the accumulators and spill at NT = 16); the SIMD's other wave covers them
+      asm volatile("" ::: "memory");
+    }
+    if (more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row group
+  double inv_n[4], part[4] = {0.0, 0.0, 0.0, 0.0};
+  int64_t grow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    grow[r] = r0 + rg * 16 + fk + 4 * r;
+    inv_n[r] = 1.0 / (n_arr ? (double)n_arr[min(grow[r], R - 1)] : (double)n_uniform);
+  }
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    const int col = (ch * NT + tn) * 16 + fi;
+    const bool cok = col < Dout;
+    const double off = cok ? offset[col] : 0.0, ps = cok ? psi[col] : 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = cok ? acc[tn][r] + off : 0.0;
+      acc[tn][r] = v;
+      part[r] = fma(v * v, tf_rcp(ps + inv_n[r]), part[r]);
+    }
+    asm volatile("" ::: "memory");   // keep the next tile's offset / psi loads behind this tile: hoisted together they spill
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) part[r] += __shfl_xor(part[r], o);
+  }
+  if (CH == 2) {     // the other column half of the same rows lives in wave (rg, 1 - ch): exchange through LDS
+    double *red = tf_lds;                   // the stage buffers are dead behind the loop's last barrier
+    if (fi == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 + fk + 4 * r] = part[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[r] = red[rg * 16 + fk + 4 * r] + red[ROWS + rg * 16 + fk + 4 * r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double f = sqrt((double)Dout / part[r]);
+    if (grow[r] < R) {
+      double *o = out + grow[r] * (int64_t)Dout;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int col = (ch * NT + tn) * 16 + fi;
+        if (col < Dout) o[col] = f * acc[tn][r];
+      }
+    }
+  }
+}
+
+template <int NT, int CH>
+static int launch_transform_fused(plda_handle *h, int slot, const double *dX, int64_t R, int Din, const int32_t *dn,
+                                  int n_uniform, double *dout) {
+  constexpr int ROWS = 16 * (8 / CH), COLS = 16 * NT * CH;
+  constexpr size_t lds = (size_t)2 * (COLS + ROWS) * TF_LD * 8;
+  if (!h->tf_attr_set[slot]) {
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->tf_attr_set[slot] = true;
+  }
+  transform_fused_kernel<NT, CH><<<(unsigned)ceil_div(R, (int64_t)ROWS), 512, lds, h->stream>>>(
+      dX, R, Din, h->d_transform.as<double>(), h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
+      n_uniform, dout);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
                           int n_uniform, double *dout) {
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
@@ -883,6 +1038,14 @@ int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, 
   if (R <= 0) return PLDA_OK;
   // out[r][o] = sum_k X[r][k] T[o][k]
   TraceScope ts(h, "transform.gemm + length_norm (K4)", 2.0 * (double)R * h->Dout * Din, 1);
+  if (h->Dout <= 512 && h->transform_variant != 1 && R < ((int64_t)1 << 31) * 64) {
+    const int D = h->Dout;
+    if (D <= 128) return launch_transform_fused<8, 1>(h, 0, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 208) return launch_transform_fused<13, 1>(h, 1, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 256) return launch_transform_fused<16, 1>(h, 2, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 384) return launch_transform_fused<12, 2>(h, 3, dX, R, Din, dn, n_uniform, dout);
+    return launch_transform_fused<16, 2>(h, 4, dX, R, Din, dn, n_uniform, dout);
+  }
   PLDA_TRY(gemm_f64(h, R, h->Dout, Din, 1.0, dX, Din, 1, h->d_transform.as<double>(), 1, Din,
                     nullptr, 0.0, dout, h->Dout));
   const int wpb = 4;

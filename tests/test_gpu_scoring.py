@@ -275,3 +275,32 @@ def test_znorm_statistics_against_the_closed_form():
     gm = np.array([zm[k] for k in range(nm)]); gs = np.array([zs[k] for k in range(nm)])
     assert np.abs(gm - rm).max() <= 1e-10 * np.abs(rm).max(), np.abs(gm - rm).max()
     assert (np.abs(gs - rs) <= 1e-9 * rs).all(), (np.abs(gs - rs) / rs).max()
+
+
+@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("din,dout", [(7, 7), (77, 77), (128, 128), (129, 129), (200, 200), (200, 150), (209, 209),
+                                      (256, 256), (257, 257), (300, 300), (385, 385), (512, 512), (512, 200),
+                                      (520, 520)])
+def test_transform_rows_all_dimension_classes(din, dout, variant, monkeypatch):
+    """K4 through every instantiation of the one-pass kernel (column tiles of 8 / 13 / 16 x 16 per wave, one or two
+    column halves, Dout <= 512) and the GEMM + length-norm pair behind it (Dout > 512, or PLDA_TRANSFORM_VARIANT=1):
+    ragged row counts, K not a multiple of 16, truncated models (Dout < Din), per-row and uniform counts, against the
+    NumPy restatement of TransformIvector (pldamodule.cpp:171 -> Plda::TransformIvector)."""
+    from oracle import plda_oracle_np as onp
+    from plda_amd import MPlda
+    monkeypatch.setenv("PLDA_TRANSFORM_VARIANT", variant)
+    rng = np.random.default_rng(din * 1000 + dout)
+    q, _ = np.linalg.qr(rng.standard_normal((din, din)))
+    T = (q * (0.5 + rng.random(din))[:, None])[:dout]
+    mean = rng.random(din)
+    psi = np.sort(rng.random(dout) * 3.0 + 0.01)[::-1].copy()
+    eng = MPlda(0)
+    eng.set_model(mean, T, psi)
+    model = dict(mean=mean, transform=T, psi=psi, offset=-T @ mean)
+    for r in (1, 63, 64, 129, 1000):
+        x = rng.standard_normal((r, din))
+        n = rng.integers(1, 9, r).astype(np.int32)
+        for ne in (3, n):
+            got = eng.transform_array(x, ne)
+            ref = onp.transform_ivector(model, x, ne)
+            np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12)
