@@ -885,6 +885,11 @@ __global__ void length_norm_kernel(double *__restrict__ out, int64_t R, int Dout
 // of 16 k: T's rows for all columns + the workgroup's rows of X, k-contiguous with a row pitch of 17 doubles
 // (conflict-free fragment reads), fetched global -> registers under the MFMAs of the previous stage and written
 // to the other buffer behind them; one barrier per stage.  Same k order and accumulator layout as gemm_f64_kernel.
+// Tried and dropped: 4-wave workgroups of 64 rows (T re-read twice as often: 25-50 % slower at D = 200 and 256, also
+// where two of them fit a CU); a second fragment register set filled one k-step ahead (3-5 % slower, spills at
+// (16, 2)).  Time follows the number of 16-column tiles, not the row pitch (D = 248 and 256: the same 3.06 ms for
+// 1.2M rows): the kernel is bound by its own issue rhythm -- 12.5k cycles per stage against 8.2k of MFMA work per
+// SIMD -- not by memory.
 // ------------------------------------------------------------------------------------
 typedef double f64x4s __attribute__((ext_vector_type(4)));
 constexpr int TF_LD = 17;
