@@ -944,13 +944,25 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
     for (int p = 0; p < XP; ++p) buf[(COLS + lr + 32 * p) * TF_LD + lk] = kok ? rx[p] : 0.0;
   };
 
+  // The two waves of a SIMD (w and w + 4) take their non-MFMA work at opposite ends of a stage: the first fetches
+  // the next stage, runs its MFMAs and writes the fetched registers to the other buffer at the END; the second
+  // writes them at the START (they were fetched one stage earlier), fetches the stage after next and then runs its
+  // MFMAs -- so one of the two is feeding the matrix pipe while the other moves data.  (Both in the same order:
+  // they reach the barrier, the fragment reads and the LDS writes together, and the pipe idles a third of the time.)
+  const bool early = wave >= 4;
   fetch(0);
   stage(tf_lds, 0);
+  if (early && Din > 16) fetch(16);
   __syncthreads();
   int cur = 0;
   for (int k0 = 0; k0 < Din; k0 += 16) {
     const bool more = k0 + 16 < Din;
-    if (more) fetch(k0 + 16);
+    if (early) {
+      if (more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
+      if (k0 + 32 < Din) fetch(k0 + 32);
+    } else if (more) {
+      fetch(k0 + 16);
+    }
     const double *Ts = tf_lds + cur * STAGE, *Xs = Ts + COLS * TF_LD;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -964,7 +976,7 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
       // 4 x (1 + NT) register pairs next to the accumulators and spill at NT = 16); the SIMD's other wave covers them
       asm volatile("" ::: "memory");
     }
-    if (more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
+    if (!early && more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
     __syncthreads();
     cur ^= 1;
   }
