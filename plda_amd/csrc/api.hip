@@ -177,7 +177,7 @@ int plda_destroy(plda_handle *h) {
     (void)comm_destroy(h);
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
-                      &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
+                      &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
                       &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->w) b.release();

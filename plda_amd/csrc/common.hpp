@@ -70,6 +70,7 @@ struct plda_handle {
 
   // ---- scoring workspace ----
   plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias, s_rpair, s_cpair;
+  plda::DevBuf tf_pad;   // zero-padded copy of the transform for the one-pass K4 kernel
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 

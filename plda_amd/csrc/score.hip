@@ -901,9 +901,14 @@ __device__ __forceinline__ double tf_rcp(double x) {   // hardware estimate + tw
   return r;
 }
 
+// T arrives zero-padded ([TP * 32 rows][Dinp = Din rounded up to 16], pad_transform_kernel), so its loads need no
+// clamps and its LDS writes no predicates; X's row pointers are clamped once, before the loop.  (With clamped
+// indices and zero-selects at every load and store the stage loop carried 2.3 vector-ALU instructions per MFMA --
+// 64-bit address arithmetic, compares, selects -- each costing the SIMD's matrix pipe an issue slot: PMC, MFMA busy
+// 70 % of the cycles at D = 256.)
 template <int NT, int CH>
 __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__restrict__ X, int64_t R, int Din,
-                                                              const double *__restrict__ T, int Dout,
+                                                              const double *__restrict__ Tpad, int Dinp, int Dout,
                                                               const double *__restrict__ offset,
                                                               const double *__restrict__ psi,
                                                               const int32_t *__restrict__ n_arr, int n_uniform,
@@ -912,8 +917,9 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   constexpr int ROWS = 16 * RG;
   constexpr int COLS = 16 * NT * CH;
   constexpr int TP = (COLS + 31) / 32;    // fetch passes over T's rows (32 rows x 16 k per pass)
+  constexpr int CP = TP * 32;             // rows of the padded T and of its LDS stage
   constexpr int XP = ROWS / 32;
-  constexpr int STAGE = (COLS + ROWS) * TF_LD;
+  constexpr int STAGE = (CP + ROWS) * TF_LD;
   extern __shared__ __attribute__((aligned(16))) double tf_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rg = wave % RG, ch = wave / RG;
@@ -925,35 +931,43 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = f64x4s{0.0, 0.0, 0.0, 0.0};
   double rt[TP], rx[XP];
+  const double *tptr = Tpad + (int64_t)lr * Dinp + lk;
+  const double *xptr[XP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) xptr[p] = X + min(r0 + lr + 32 * p, R - 1) * (int64_t)Din + lk;
+  const int64_t tstep = (int64_t)32 * Dinp;
 
-  auto fetch = [&](int k0) {              // unconditional loads on clamped indices; zeroed at the LDS write
-    const int gk = min(k0 + lk, Din - 1);
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < TP; ++p) rt[p] = T[(int64_t)min(lr + 32 * p, Dout - 1) * Din + gk];
+    for (int p = 0; p < TP; ++p) rt[p] = tptr[p * tstep + k0];
+    // the last stage of a Din that is not a multiple of 16 must not read past a row's end (zeroed at the LDS write)
+    const int ko = (k0 + 16 <= Din) ? k0 : min(k0 + lk, Din - 1) - lk;
 #pragma unroll
-    for (int p = 0; p < XP; ++p) rx[p] = X[min(r0 + lr + 32 * p, R - 1) * (int64_t)Din + gk];
+    for (int p = 0; p < XP; ++p) rx[p] = xptr[p][ko];
   };
   auto stage = [&](double *buf, int k0) {
-    const bool kok = k0 + lk < Din;
 #pragma unroll
-    for (int p = 0; p < TP; ++p) {
-      const int n = lr + 32 * p;
-      if (n < COLS) buf[n * TF_LD + lk] = (kok && n < Dout) ? rt[p] : 0.0;
+    for (int p = 0; p < TP; ++p) buf[(lr + 32 * p) * TF_LD + lk] = rt[p];
+    if (k0 + 16 <= Din) {
+#pragma unroll
+      for (int p = 0; p < XP; ++p) buf[(CP + lr + 32 * p) * TF_LD + lk] = rx[p];
+    } else {
+      const bool kok = k0 + lk < Din;
+#pragma unroll
+      for (int p = 0; p < XP; ++p) buf[(CP + lr + 32 * p) * TF_LD + lk] = kok ? rx[p] : 0.0;
     }
-#pragma unroll
-    for (int p = 0; p < XP; ++p) buf[(COLS + lr + 32 * p) * TF_LD + lk] = kok ? rx[p] : 0.0;
   };
 
   // The two waves of a SIMD (w and w + 4) take their non-MFMA work at opposite ends of a stage: the first fetches
   // the next stage, runs its MFMAs and writes the fetched registers to the other buffer at the END; the second
   // writes them at the START (they were fetched one stage earlier), fetches the stage after next and then runs its
-  // MFMAs -- so one of the two is feeding the matrix pipe while the other moves data.  (Both in the same order:
-  // they reach the barrier, the fragment reads and the LDS writes together, and the pipe idles a third of the time.)
+  // MFMAs -- so one of the two is feeding the matrix pipe while the other moves data.
   const bool early = wave >= 4;
   fetch(0);
   stage(tf_lds, 0);
   if (early && Din > 16) fetch(16);
   __syncthreads();
+  const int tfrag = (ch * NT * 16 + fi) * TF_LD + fk, xfrag = (CP + rg * 16 + fi) * TF_LD + fk;
   int cur = 0;
   for (int k0 = 0; k0 < Din; k0 += 16) {
     const bool more = k0 + 16 < Din;
@@ -963,13 +977,13 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
     } else if (more) {
       fetch(k0 + 16);
     }
-    const double *Ts = tf_lds + cur * STAGE, *Xs = Ts + COLS * TF_LD;
+    const double *Ts = tf_lds + cur * STAGE + tfrag, *Xs = tf_lds + cur * STAGE + xfrag;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const double a = Xs[(rg * 16 + fi) * TF_LD + kk * 4 + fk];
+      const double a = Xs[kk * 4];
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) {
-        const double b = Ts[((ch * NT + tn) * 16 + fi) * TF_LD + kk * 4 + fk];
+        const double b = Ts[tn * 16 * TF_LD + kk * 4];
         acc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tn], 0, 0, 0);
       }
       // fragment reads stay inside their k-step (all four steps' reads hoisted to the top of the stage need
@@ -1031,18 +1045,32 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   }
 }
 
+__global__ void pad_transform_kernel(const double *__restrict__ T, int Dout, int Din, double *__restrict__ Tpad, int rows,
+                                     int Dinp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * Dinp) return;
+  const int r = idx / Dinp, c = idx % Dinp;
+  Tpad[idx] = (r < Dout && c < Din) ? T[(int64_t)r * Din + c] : 0.0;
+}
+
 template <int NT, int CH>
 static int launch_transform_fused(plda_handle *h, int slot, const double *dX, int64_t R, int Din, const int32_t *dn,
                                   int n_uniform, double *dout) {
-  constexpr int ROWS = 16 * (8 / CH), COLS = 16 * NT * CH;
-  constexpr size_t lds = (size_t)2 * (COLS + ROWS) * TF_LD * 8;
+  constexpr int ROWS = 16 * (8 / CH), COLS = 16 * NT * CH, CP = (COLS + 31) / 32 * 32;
+  constexpr size_t lds = (size_t)2 * (CP + ROWS) * TF_LD * 8;
   if (!h->tf_attr_set[slot]) {
     PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->tf_attr_set[slot] = true;
   }
+  // the model may have changed since the last call (fit, set_model, truncate, smoothing, load): the padded copy of T
+  // is rebuilt every time -- 2 MB at most, a few microseconds
+  const int Dinp = (int)round_up(Din, 16);
+  PLDA_HIP(h, h->tf_pad.reserve((size_t)CP * Dinp * 8));
+  pad_transform_kernel<<<(unsigned)ceil_div((int64_t)CP * Dinp, 256), 256, 0, h->stream>>>(
+      h->d_transform.as<double>(), h->Dout, Din, h->tf_pad.as<double>(), CP, Dinp);
   transform_fused_kernel<NT, CH><<<(unsigned)ceil_div(R, (int64_t)ROWS), 512, lds, h->stream>>>(
-      dX, R, Din, h->d_transform.as<double>(), h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
+      dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
       n_uniform, dout);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
