@@ -886,8 +886,9 @@ __global__ void length_norm_kernel(double *__restrict__ out, int64_t R, int Dout
 // (conflict-free fragment reads), fetched global -> registers under the MFMAs of the previous stage and written
 // to the other buffer behind them; one barrier per stage.  Same k order and accumulator layout as gemm_f64_kernel.
 // Tried and dropped: 4-wave workgroups of 64 rows (T re-read twice as often: 25-50 % slower at D = 200 and 256, also
-// where two of them fit a CU); a second fragment register set filled one k-step ahead (3-5 % slower, spills at
-// (16, 2)).  Time follows the number of 16-column tiles, not the row pitch (D = 248 and 256: the same 3.06 ms for
+// where two of them fit a CU); a second fragment register set filled one k-step ahead, with and without
+// sched_group_barrier forcing one LDS read between every two MFMAs (3-10 % slower, spills at (16, 2)) -- so the idle
+// 30 % of the matrix pipe is not LDS latency the schedule could hide.  Time follows the number of 16-column tiles, not the row pitch (D = 248 and 256: the same 3.06 ms for
 // 1.2M rows): the kernel is bound by its own issue rhythm -- 12.5k cycles per stage against 8.2k of MFMA work per
 // SIMD -- not by memory.
 // ------------------------------------------------------------------------------------
