@@ -146,6 +146,10 @@ int plda_create(int device, plda_handle **out) {
     h->device = device;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) h->num_cus = n;
+    }
     if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
     if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);

@@ -85,6 +85,7 @@ struct plda_handle {
 
   bool panel_attr_set[16] = {};
   bool tf_attr_set[5] = {};
+  int num_cus = 256;           // hipDeviceAttributeMultiprocessorCount (persistent grids)
   int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass (A/B arm)
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)

@@ -925,26 +925,39 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rg = wave % RG, ch = wave / RG;
   const int fi = lane & 15, fk = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.x * ROWS;
   const int lk = t & 15, lr = t >> 4;     // this thread's k and first row inside a fetch pass
+  const double *tptr = Tpad + (int64_t)lr * Dinp + lk;
+  const int64_t tstep = (int64_t)32 * Dinp;
+  const int tfrag = (ch * NT * 16 + fi) * TF_LD + fk, xfrag = (CP + rg * 16 + fi) * TF_LD + fk;
+  const bool early = wave >= 4;
+  // Persistent: one workgroup per CU walks over the row blocks.  (One workgroup fills a CU -- registers -- so between
+  // two of them the CU stood idle for the whole turnaround, ~17k cycles per 128-row block: wave launch, LDS
+  // allocation, the first loads.)
+  const int64_t nblocks = (R + ROWS - 1) / ROWS;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  const int64_t r0 = blk * ROWS;
 
   f64x4s acc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) acc[i] = f64x4s{0.0, 0.0, 0.0, 0.0};
   double rt[TP], rx[XP];
-  const double *tptr = Tpad + (int64_t)lr * Dinp + lk;
   const double *xptr[XP];
 #pragma unroll
   for (int p = 0; p < XP; ++p) xptr[p] = X + min(r0 + lr + 32 * p, R - 1) * (int64_t)Din + lk;
-  const int64_t tstep = (int64_t)32 * Dinp;
 
-  auto fetch = [&](int k0) {
+  // fetch half q (q = 4: everything): the loads of a stage are issued in two halves, behind the MFMAs of the first
+  // two k-steps (later ones arrive too late for the wave's LDS write and it waits for them).  All at once at the top of a stage they are 48 KB per workgroup through the CU's 64 B/clk vector
+  // memory path: ~750 cycles in which both waves of every SIMD stand in load issue and nobody feeds the matrix pipe
+  // (phase timing, scripts/probe/transform_tl.hip: stage time = 8 192 MFMA cycles + exactly that).
+  auto fetch = [&](int k0, int q) {
 #pragma unroll
-    for (int p = 0; p < TP; ++p) rt[p] = tptr[p * tstep + k0];
+    for (int p = 0; p < TP; ++p)
+      if (q == 4 || (p & 1) == q) rt[p] = tptr[p * tstep + k0];
     // the last stage of a Din that is not a multiple of 16 must not read past a row's end (zeroed at the LDS write)
     const int ko = (k0 + 16 <= Din) ? k0 : min(k0 + lk, Din - 1) - lk;
 #pragma unroll
-    for (int p = 0; p < XP; ++p) rx[p] = xptr[p][ko];
+    for (int p = 0; p < XP; ++p)
+      if (q == 4 || (p & 1) == q) rx[p] = xptr[p][ko];
   };
   auto stage = [&](double *buf, int k0) {
 #pragma unroll
@@ -963,21 +976,16 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   // the next stage, runs its MFMAs and writes the fetched registers to the other buffer at the END; the second
   // writes them at the START (they were fetched one stage earlier), fetches the stage after next and then runs its
   // MFMAs -- so one of the two is feeding the matrix pipe while the other moves data.
-  const bool early = wave >= 4;
-  fetch(0);
+  fetch(0, 4);
   stage(tf_lds, 0);
-  if (early && Din > 16) fetch(16);
+  if (early && Din > 16) fetch(16, 4);
   __syncthreads();
-  const int tfrag = (ch * NT * 16 + fi) * TF_LD + fk, xfrag = (CP + rg * 16 + fi) * TF_LD + fk;
   int cur = 0;
   for (int k0 = 0; k0 < Din; k0 += 16) {
     const bool more = k0 + 16 < Din;
-    if (early) {
-      if (more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
-      if (k0 + 32 < Din) fetch(k0 + 32);
-    } else if (more) {
-      fetch(k0 + 16);
-    }
+    if (early && more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
+    const int kf = early ? k0 + 32 : k0 + 16;     // the stage this wave fetches during this one
+    const bool dofetch = kf < Din;
     const double *Ts = tf_lds + cur * STAGE + tfrag, *Xs = tf_lds + cur * STAGE + xfrag;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -987,6 +995,7 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
         const double b = Ts[tn * 16 * TF_LD + kk * 4];
         acc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tn], 0, 0, 0);
       }
+      if (dofetch && kk < 2) fetch(kf, kk);
       // fragment reads stay inside their k-step (all four steps' reads hoisted to the top of the stage need
       // 4 x (1 + NT) register pairs next to the accumulators and spill at NT = 16); the SIMD's other wave covers them
       asm volatile("" ::: "memory");
@@ -996,6 +1005,15 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
     cur ^= 1;
   }
 
+  // offset and psi of every column go through LDS (the stage buffers are dead behind the loop's last barrier): read
+  // from global tile by tile -- the only order that does not spill -- they were 16 dependent L2 round trips, half of
+  // the 19k-cycle epilogue of a workgroup that has the CU to itself.
+  double *eo = tf_lds, *ep = tf_lds + COLS;
+  for (int c = t; c < COLS; c += 512) {
+    eo[c] = c < Dout ? offset[c] : 0.0;
+    ep[c] = c < Dout ? psi[c] : 1.0;
+  }
+  __syncthreads();
   // accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row group
   double inv_n[4], part[4] = {0.0, 0.0, 0.0, 0.0};
   int64_t grow[4];
@@ -1008,14 +1026,13 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   for (int tn = 0; tn < NT; ++tn) {
     const int col = (ch * NT + tn) * 16 + fi;
     const bool cok = col < Dout;
-    const double off = cok ? offset[col] : 0.0, ps = cok ? psi[col] : 1.0;
+    const double off = eo[col], ps = ep[col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double v = cok ? acc[tn][r] + off : 0.0;
       acc[tn][r] = v;
       part[r] = fma(v * v, tf_rcp(ps + inv_n[r]), part[r]);
     }
-    asm volatile("" ::: "memory");   // keep the next tile's offset / psi loads behind this tile: hoisted together they spill
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1023,7 +1040,7 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
     for (int o = 1; o < 16; o <<= 1) part[r] += __shfl_xor(part[r], o);
   }
   if (CH == 2) {     // the other column half of the same rows lives in wave (rg, 1 - ch): exchange through LDS
-    double *red = tf_lds;                   // the stage buffers are dead behind the loop's last barrier
+    double *red = tf_lds + 2 * COLS;        // behind the offset / psi copies
     if (fi == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 + fk + 4 * r] = part[r];
@@ -1043,6 +1060,8 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
         if (col < Dout) o[col] = f * acc[tn][r];
       }
     }
+  }
+  __syncthreads();   // the epilogue's LDS copies are read; the next block stages over them
   }
 }
 
@@ -1070,7 +1089,7 @@ static int launch_transform_fused(plda_handle *h, int slot, const double *dX, in
   PLDA_HIP(h, h->tf_pad.reserve((size_t)CP * Dinp * 8));
   pad_transform_kernel<<<(unsigned)ceil_div((int64_t)CP * Dinp, 256), 256, 0, h->stream>>>(
       h->d_transform.as<double>(), h->Dout, Din, h->tf_pad.as<double>(), CP, Dinp);
-  transform_fused_kernel<NT, CH><<<(unsigned)ceil_div(R, (int64_t)ROWS), 512, lds, h->stream>>>(
+  transform_fused_kernel<NT, CH><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)ROWS), h->num_cus), 512, lds, h->stream>>>(
       dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
       n_uniform, dout);
   PLDA_LAUNCH_CHECK(h);
