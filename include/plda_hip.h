@@ -252,40 +252,99 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
                                 const int64_t *denrol_spk, const int64_t *dtest_spk,
                                 plda_eer_reduce_fn reduce, void *ctx, double *out);
 
-/* ---- several GPUs of one node: one process per GPU, one handle per process, RCCL over
- * xGMI inside the library.  The reference has no counterpart (one process, one thread; its native object
- * libplda.MPlda, pldamodule.cpp:280-295, is the only thing callers bind, so the sharded path lives behind the same
- * object).  Rank 0 calls plda_comm_unique_id and distributes the 128 bytes by any means (MPI, a file,
- * torch.distributed's store); every rank then calls plda_comm_init (collective).
+/* ---- several GPUs of one node: one process per GPU, one handle per process.  The reference
+ * has no counterpart (one process, one thread; its native object libplda.MPlda, pldamodule.cpp:280-295, is the only
+ * thing callers bind, so the sharded path lives behind the same object).
  *
+ * Every collective the library issues goes through ONE table of three operations on DEVICE pointers
+ * (plda_collectives); three providers fill it:
+ *   plda_comm_init         RCCL over xGMI (the default and the production transport).  librccl is opened lazily by
+ *                          this call -- a single-GPU user never needs it.  Rank 0 calls plda_comm_unique_id and
+ *                          distributes the 128 bytes by any means (MPI, a file, torch.distributed's store); every rank
+ *                          then calls plda_comm_init (collective).
+ *   plda_comm_init_host    any HOST transport (MPI, gloo, shared memory): the caller supplies the two operations on
+ *                          host buffers, the library stages device data through a pinned bounce buffer in bounded
+ *                          chunks.  This is also how the sharded entry points are tested with several processes on
+ *                          ONE GPU (RCCL refuses two ranks on one device): tests/test_gpu_comm_procs.py.
+ *   plda_comm_init_custom  the device-level table itself (e.g. HIP-IPC peer copies).
+ * All callbacks return 0 on success.  Buffers are byte-addressed; `hip_stream` is the hipStream_t the operation must
+ * be ordered on (enqueue, or synchronise it and work on the host).
+ *
+ *   plda_shard_plan                 the row partition of the trials matrix, as a pure function (no handle, no GPU):
+ *       block b of `block_rows` rows (rounded up to a multiple of 256; <= 0: 4096) belongs to rank b mod R; the rows
+ *       left over after the last full round of R blocks are dealt out once more in R equal smaller blocks, so the
+ *       tail does not land on rank 0.  Writes this rank's blocks (first row, row count) in ascending order; a rank's
+ *       COMPACT slab holds them back to back, *local_rows rows in all.
  *   plda_score_matrix_sharded_dev   every rank passes the SAME replicated inputs (all M enrol rows, all Nt tests,
- *       a replicated model).  Enrol rows are dealt out block-cyclically -- block b of `block_rows` rows (a multiple
- *       of 256; <= 0: 4096) belongs to rank b mod R; the rows left over after the last full round of R blocks
- *       are dealt out once more in R equal smaller blocks -- and each rank writes its blocks straight into their
- *       final rows of the full matrix dout[M, ld_out].  gather == 0: that is all (scores stay sharded: what
- *       thresholding, counting, EER want; no collective).  gather != 0: every R consecutive blocks are
+ *       a replicated model) and scores the blocks plda_shard_plan gives it, straight into their final rows of the
+ *       full matrix dout[M, ld_out] (which must hold M * ld_out floats).  gather == 0: that is all (scores stay
+ *       sharded: what thresholding, counting, EER want; no collective).  gather != 0: every R consecutive blocks are
  *       assembled on every rank by one IN-PLACE all-gather on a side stream while the next blocks are being
- *       scored (no staging copy; ragged tail: a group of broadcasts); the handle's stream is ordered
- *       behind the last one.
+ *       scored (no staging copy; ragged tail: all_gather_v); whole ld_out-wide rows travel, so the padding columns
+ *       [Nt, ld_out) of dout are overwritten with unspecified values; the handle's stream is ordered behind the
+ *       last one.
+ *   plda_score_matrix_sharded_local_dev   the same partition with COMPACT output: this rank's blocks back to back in
+ *       dlocal[local_rows, ld_local] -- a rank holds M/R rows of scores, not M (C4 on 8 GPUs: 24 GB instead of
+ *       192 GB).  dfull == NULL: scores stay sharded.  dfull != NULL (needs ld_full == ld_local): the full
+ *       [M, ld_full] matrix is assembled there on every rank as well, super-block by super-block, overlapped as above.
  *   plda_znorm_stats_sharded_dev    MPlda_norm (pldamodule.cpp:196-256) with the M models split contiguously
  *       over the ranks (every rank scans the whole cohort); full mean / std arrays on every rank.
  *   plda_fit_sharded_dev            MPlda_fit with the statistics pass (pldamodule.cpp:76-100) over THIS rank's
  *       speakers (local dense labels 0..K-1; a speaker's rows must all be on one rank); the D x D offset
  *       scatter is all-reduced, centroids and counts are all-gathered in rank order, and EM + GetOutput
  *       (:102-106) run as replicas on every rank from identical inputs.
- *   plda_eer_matrix_comm_dev        plda_eer_matrix_sharded_dev with the library's own reduction.
- * Without plda_comm_init all of them run as a single rank. ---- */
+ *   plda_eer_matrix_comm_dev        plda_eer_matrix_sharded_dev with the handle's collectives; the compact slab of
+ *       plda_score_matrix_sharded_local_dev (with the speaker ids of ITS rows) is what it takes.
+ * Without a communicator all of them run as a single rank. ---- */
+#define PLDA_DT_F64 0
+#define PLDA_DT_U64 1
+#define PLDA_DT_U32 2
+#define PLDA_OP_SUM 0
+#define PLDA_OP_MAX 1
+#define PLDA_OP_MIN 2
+typedef struct plda_collectives {
+  void *ctx;
+  /* every rank contributes `bytes` at dsend; drecv receives nranks * bytes in rank order.  dsend may be
+   * drecv + rank * bytes (in place). */
+  int (*all_gather)(void *ctx, const void *dsend, void *drecv, int64_t bytes, void *hip_stream);
+  /* ragged, in place: rank q owns bytes [offs[q], offs[q] + counts[q]) of the same dbuf on every rank (counts may be
+   * 0); afterwards every rank holds every piece.  offs / counts: nranks host int64 each, identical on all ranks. */
+  int (*all_gather_v)(void *ctx, void *dbuf, const int64_t *offs, const int64_t *counts, void *hip_stream);
+  /* element-wise, in place: dtype PLDA_DT_*, op PLDA_OP_* */
+  int (*all_reduce)(void *ctx, void *dbuf, int64_t count, int32_t dtype, int32_t op, void *hip_stream);
+  /* called once by plda_comm_destroy / plda_destroy; may be NULL */
+  void (*destroy)(void *ctx);
+} plda_collectives;
+typedef struct plda_host_collectives {
+  void *ctx;
+  /* the same two operations on HOST memory (the library's pinned bounce buffer), blocking */
+  int (*all_gather_v)(void *ctx, void *hbuf, const int64_t *offs, const int64_t *counts);
+  int (*all_reduce)(void *ctx, void *hbuf, int64_t count, int32_t dtype, int32_t op);
+  void (*destroy)(void *ctx);
+} plda_host_collectives;
 int plda_comm_unique_id(void *out, int64_t cap_bytes /* >= 128 */);
 int plda_comm_init(plda_handle *h, int32_t nranks, int32_t rank, const void *unique_id);
+int plda_comm_init_custom(plda_handle *h, int32_t nranks, int32_t rank, const plda_collectives *table);
+int plda_comm_init_host(plda_handle *h, int32_t nranks, int32_t rank, const plda_host_collectives *table);
 int plda_comm_destroy(plda_handle *h);
 int plda_comm_info(plda_handle *h, int32_t *nranks, int32_t *rank);
+/* who takes part, as the TRANSPORT reports it, written as a JSON object into json[cap]: {"transport": "rccl" | "host"
+ * | "custom" | "none" | "emulated", "nranks", "rank", "device", "pci_bus_id"}; for RCCL nranks / rank / device come
+ * from ncclCommCount / ncclCommUserRank / ncclCommCuDevice (plus "rccl_version"), not from what the caller passed in */
+int plda_comm_describe(plda_handle *h, char *json, int64_t cap);
 /* test hook: act as rank `rank` of `nranks` WITHOUT a communicator (no collective runs, gather is ignored):
  * lets one GPU play every rank in turn and check that the shards tile the whole problem */
 int plda_comm_emulate(plda_handle *h, int32_t nranks, int32_t rank);
+int plda_shard_plan(int64_t M, int32_t nranks, int32_t rank, int64_t block_rows, int64_t *row_start,
+                    int64_t *row_count, int64_t cap, int64_t *nblocks, int64_t *local_rows);
 int plda_score_matrix_sharded_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform,
                                   int64_t M, const double *dV, int64_t Nt, const double *dzmean,
                                   const double *dzstd, float *dout, int64_t ld_out, int64_t block_rows,
                                   int32_t gather);
+int plda_score_matrix_sharded_local_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform,
+                                        int64_t M, const double *dV, int64_t Nt, const double *dzmean,
+                                        const double *dzstd, float *dlocal, int64_t ld_local, int64_t block_rows,
+                                        float *dfull, int64_t ld_full);
 int plda_znorm_stats_sharded_dev(plda_handle *h, const double *dbkg, int64_t Nb, int32_t num_examples,
                                  int32_t Din, const double *dmodels, int64_t M, double *dout_mean,
                                  double *dout_std);

@@ -76,7 +76,12 @@ SIGNATURES = {
     "plda_eer_matrix_sharded_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "plda_comm_unique_id": (C.c_int, [_vp, _i64]),
     "plda_comm_init": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "plda_comm_init_custom": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "plda_comm_init_host": (C.c_int, [_vp, _i32, _i32, _vp]),
     "plda_comm_destroy": (C.c_int, [_vp]),
+    "plda_comm_describe": (C.c_int, [_vp, _vp, _i64]),
+    "plda_shard_plan": (C.c_int, [_i64, _i32, _i32, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "plda_score_matrix_sharded_local_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64]),
     "plda_comm_emulate": (C.c_int, [_vp, _i32, _i32]),
     "plda_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "plda_score_matrix_sharded_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32]),
@@ -86,6 +91,26 @@ SIGNATURES = {
     "plda_znorm_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "plda_znorm_stats_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
 }
+
+# plda_collectives / plda_host_collectives (include/plda_hip.h): callback tables of the multi-GPU entry points
+PLDA_DT_F64, PLDA_DT_U64, PLDA_DT_U32 = 0, 1, 2
+PLDA_OP_SUM, PLDA_OP_MAX, PLDA_OP_MIN = 0, 1, 2
+HOST_ALL_GATHER_V = C.CFUNCTYPE(C.c_int, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64))
+HOST_ALL_REDUCE = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _i32)
+DESTROY_FN = C.CFUNCTYPE(None, _vp)
+DEV_ALL_GATHER = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, _i64, _vp)
+DEV_ALL_GATHER_V = C.CFUNCTYPE(C.c_int, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp)
+DEV_ALL_REDUCE = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _i32, _vp)
+
+
+class HostCollectives(C.Structure):
+    _fields_ = [("ctx", _vp), ("all_gather_v", HOST_ALL_GATHER_V), ("all_reduce", HOST_ALL_REDUCE), ("destroy", DESTROY_FN)]
+
+
+class Collectives(C.Structure):
+    _fields_ = [("ctx", _vp), ("all_gather", DEV_ALL_GATHER), ("all_gather_v", DEV_ALL_GATHER_V),
+                ("all_reduce", DEV_ALL_REDUCE), ("destroy", DESTROY_FN)]
+
 
 _lib = None
 

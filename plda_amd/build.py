@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc compilation failed")
     if force or procs or _stale(SO, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]   # librccl is opened lazily by plda_comm_init (csrc/comm.hip)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

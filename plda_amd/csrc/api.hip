@@ -68,10 +68,13 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out);
 // comm.hip
 int comm_init(plda_handle *h, int nranks, int rank, const void *uid);
+int comm_init_custom(plda_handle *h, int nranks, int rank, const plda_collectives *t);
+int comm_init_host(plda_handle *h, int nranks, int rank, const plda_host_collectives *t);
 int comm_destroy(plda_handle *h);
+int comm_describe(plda_handle *h, std::string &js);
 int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
-                                const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
-                                int64_t ld, int64_t block_rows, int gather);
+                                const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dlocal,
+                                int64_t ld_local, float *dfull, int64_t ld_full, int64_t block_rows, int gather);
 int znorm_stats_sharded_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
                                const double *dmodels, int64_t M, double *dmean, double *dstd);
 int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K, int iters);
@@ -124,7 +127,7 @@ template <typename F> int guarded(plda_handle *h, const char *fn, F &&body) noex
 
 extern "C" {
 
-int plda_abi_version(void) { return 1; }
+int plda_abi_version(void) { return 2; }
 
 int plda_create(int device, plda_handle **out) {
   return guarded(nullptr, "plda_create", [&]() -> int {
@@ -1081,12 +1084,44 @@ int plda_comm_init(plda_handle *h, int32_t nranks, int32_t rank, const void *uni
   });
 }
 
+int plda_comm_init_custom(plda_handle *h, int32_t nranks, int32_t rank, const plda_collectives *table) {
+  return guarded(h, "plda_comm_init_custom", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return comm_init_custom(h, nranks, rank, table);
+  });
+}
+
+int plda_comm_init_host(plda_handle *h, int32_t nranks, int32_t rank, const plda_host_collectives *table) {
+  return guarded(h, "plda_comm_init_host", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return comm_init_host(h, nranks, rank, table);
+  });
+}
+
 int plda_comm_destroy(plda_handle *h) {
   return guarded(h, "plda_comm_destroy", [&]() -> int {
     if (!h) return PLDA_E_INVAL;
     PLDA_LOCK(h);
     PLDA_TRY(set_device(h));
     return comm_destroy(h);
+  });
+}
+
+int plda_comm_describe(plda_handle *h, char *json, int64_t cap) {
+  return guarded(h, "plda_comm_describe", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!json || cap <= 0) return fail(h, PLDA_E_INVAL, "comm_describe: bad argument");
+    PLDA_TRY(set_device(h));
+    std::string js;
+    PLDA_TRY(comm_describe(h, js));
+    if ((int64_t)js.size() + 1 > cap) return fail(h, PLDA_E_CAPACITY, "comm_describe: need %zu bytes", js.size() + 1);
+    std::memcpy(json, js.c_str(), js.size() + 1);
+    return PLDA_OK;
   });
 }
 
@@ -1119,7 +1154,22 @@ int plda_score_matrix_sharded_dev(plda_handle *h, const double *dU, const int32_
     PLDA_LOCK(h);
     if (!dn_enrol && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: n_uniform must be > 0 when n_enrol is NULL");
     PLDA_TRY(set_device(h));
-    return score_matrix_sharded_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out, block_rows, gather);
+    return score_matrix_sharded_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, nullptr, 0, dout, ld_out,
+                                       block_rows, gather);
+  });
+}
+
+int plda_score_matrix_sharded_local_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform,
+                                        int64_t M, const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
+                                        float *dlocal, int64_t ld_local, int64_t block_rows, float *dfull, int64_t ld_full) {
+  return guarded(h, "plda_score_matrix_sharded_local_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!dn_enrol && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: n_uniform must be > 0 when n_enrol is NULL");
+    if (!dlocal) return fail(h, PLDA_E_INVAL, "score_matrix_sharded_local: dlocal is NULL");
+    PLDA_TRY(set_device(h));
+    return score_matrix_sharded_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dlocal, ld_local, dfull, ld_full,
+                                       block_rows, dfull ? 1 : 0);
   });
 }
 

@@ -1,15 +1,15 @@
 // plda_amd/csrc/comm.hip -- the path sharded across the GPUs of one node, behind
-// the C ABI: one process per GPU, one handle per process, RCCL (xGMI) inside the library.
+// the C ABI: one process per GPU, one handle per process.
 //
 // The reference has no parallelism of any kind (one process, one thread, GIL held: SURVEY.md
 // section 2c); what shards is the build's own batched path:
 //   * trials matrix  -- trial (i, j) needs only enrol row i, the replicated test set and the
-//     replicated model: enrol rows are dealt out BLOCK-CYCLICALLY (blocks of `block_rows`), every
-//     rank writes its blocks straight into their final place of the full [M, Nt] matrix (ld_out),
-//     and -- only if the caller wants every rank to hold everything -- super-block s (R consecutive
-//     blocks, one per rank) is assembled by ONE in-place all-gather on a side stream while
-//     super-block s+1 is being scored.  No staging copies: the kernel's output buffer is the
-//     collective's send AND receive buffer.
+//     replicated model: enrol rows are dealt out BLOCK-CYCLICALLY (blocks of `block_rows`); a rank
+//     writes its blocks either back to back into a compact slab [M/R, Nt] or straight into their
+//     final place of the full [M, Nt] matrix, and -- only if the caller wants every rank to hold
+//     everything -- super-block s (R consecutive blocks, one per rank) is assembled by ONE all-gather
+//     on a side stream while super-block s+1 is being scored.  No staging copies: the kernel's output
+//     buffer is the collective's send buffer (and, in place, its receive buffer).
 //   * z-norm statistics -- by model: every rank scans the whole cohort for its slab of models; one
 //     exchange of [M] means and stds.
 //   * fit statistics -- by speaker: AddSamples' accumulators are sums over speakers, so the D x D
@@ -17,12 +17,22 @@
 //     replicas ("replicas only", section 8e) from bit-identical inputs.
 //   * EER of a sharded trials matrix -- the three histogram passes of eer.hip with the counters
 //     summed over the ranks.
+//
+// Every collective goes through the handle's `plda_collectives` table (include/plda_hip.h).  Providers:
+// RCCL over xGMI (production; librccl is dlopen'ed by plda_comm_init, so the .so does not depend on it),
+// a host-staged adapter over two caller-supplied host operations (MPI / gloo / anything; also what lets
+// several PROCESSES ON ONE GPU drive these very loops, events and offsets in the tests -- RCCL refuses two
+// ranks on one device), or a caller-supplied device-level table.
 #include "common.hpp"
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only; the functions are resolved with dlsym
+
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace plda {
@@ -36,16 +46,306 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
                       const int64_t *dtspk, double *out,
                       int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *), void *ctx);
 
-static int nccl_fail(plda_handle *h, ncclResult_t r, const char *what, int line) {
-  return fail(h, PLDA_E_HIP, "RCCL error %d (%s) at comm.hip:%d: %s", (int)r, ncclGetErrorString(r), line, what);
-}
-#define PLDA_NCCL(h, expr)                                              \
-  do {                                                                  \
-    ncclResult_t _r = (expr);                                           \
-    if (_r != ncclSuccess) return nccl_fail((h), _r, #expr, __LINE__);  \
-  } while (0)
+// ------------------------------------------------------------------------------------ RCCL, resolved lazily
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  std::string err;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
 
-static inline ncclComm_t comm_of(plda_handle *h) { return static_cast<ncclComm_t>(h->comm); }
+// librccl of the process if one is already loaded (torch ships its own), else the ROCm installation's
+const Rccl *rccl_api(std::string *why) {
+  std::lock_guard<std::mutex> g(g_rccl_mu);
+  if (g_rccl.lib) return &g_rccl;
+  std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
+  if (const char *rp = std::getenv("ROCM_PATH")) {
+    names.push_back(std::string(rp) + "/lib/librccl.so.1");
+    names.push_back(std::string(rp) + "/lib/librccl.so");
+  }
+  names.push_back("/opt/rocm/lib/librccl.so.1");
+  names.push_back("/opt/rocm/lib/librccl.so");
+  void *lib = nullptr;
+  std::string tried;
+  for (const auto &n : names) {
+    lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+    tried += (tried.empty() ? "" : ", ") + n;
+  }
+  if (!lib) {
+    if (why) *why = "librccl not found (tried " + tried + "): " + (dlerror() ? dlerror() : "");
+    return nullptr;
+  }
+  bool ok = true;
+  auto sym = [&](auto &fp, const char *name) {
+    fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(lib, name));
+    if (!fp) { ok = false; if (why) *why = std::string("librccl lacks ") + name; }
+  };
+  sym(g_rccl.GetUniqueId, "ncclGetUniqueId");
+  sym(g_rccl.CommInitRank, "ncclCommInitRank");
+  sym(g_rccl.CommDestroy, "ncclCommDestroy");
+  sym(g_rccl.AllGather, "ncclAllGather");
+  sym(g_rccl.Broadcast, "ncclBroadcast");
+  sym(g_rccl.AllReduce, "ncclAllReduce");
+  sym(g_rccl.GroupStart, "ncclGroupStart");
+  sym(g_rccl.GroupEnd, "ncclGroupEnd");
+  sym(g_rccl.GetErrorString, "ncclGetErrorString");
+  sym(g_rccl.CommCount, "ncclCommCount");
+  sym(g_rccl.CommUserRank, "ncclCommUserRank");
+  sym(g_rccl.CommCuDevice, "ncclCommCuDevice");
+  sym(g_rccl.GetVersion, "ncclGetVersion");
+  if (!ok) { dlclose(lib); return nullptr; }
+  g_rccl.lib = lib;
+  return &g_rccl;
+}
+
+struct RcclCtx {
+  const Rccl *api;
+  ncclComm_t comm;
+  int nranks;
+  plda_handle *h;
+};
+
+int rccl_err(RcclCtx *c, ncclResult_t r, const char *what) {
+  fail(c->h, PLDA_E_HIP, "RCCL error %d (%s): %s", (int)r, c->api->GetErrorString(r), what);
+  return 1;
+}
+
+int rccl_all_gather(void *vc, const void *dsend, void *drecv, int64_t bytes, void *st) {
+  auto *c = static_cast<RcclCtx *>(vc);
+  const ncclResult_t r = c->api->AllGather(dsend, drecv, (size_t)bytes, ncclChar, c->comm, static_cast<hipStream_t>(st));
+  return r == ncclSuccess ? 0 : rccl_err(c, r, "ncclAllGather");
+}
+
+// ragged all-gather in place, as one group of broadcasts
+int rccl_all_gather_v(void *vc, void *dbuf, const int64_t *offs, const int64_t *counts, void *st) {
+  auto *c = static_cast<RcclCtx *>(vc);
+  ncclResult_t r = c->api->GroupStart();
+  if (r != ncclSuccess) return rccl_err(c, r, "ncclGroupStart");
+  for (int q = 0; q < c->nranks; ++q) {
+    if (counts[q] <= 0) continue;
+    char *p = static_cast<char *>(dbuf) + offs[q];
+    r = c->api->Broadcast(p, p, (size_t)counts[q], ncclChar, q, c->comm, static_cast<hipStream_t>(st));
+    if (r != ncclSuccess) { (void)c->api->GroupEnd(); return rccl_err(c, r, "ncclBroadcast"); }
+  }
+  r = c->api->GroupEnd();
+  return r == ncclSuccess ? 0 : rccl_err(c, r, "ncclGroupEnd");
+}
+
+int rccl_all_reduce(void *vc, void *dbuf, int64_t count, int32_t dtype, int32_t op, void *st) {
+  auto *c = static_cast<RcclCtx *>(vc);
+  const ncclDataType_t dt = dtype == PLDA_DT_F64 ? ncclDouble : dtype == PLDA_DT_U64 ? ncclUint64 : ncclUint32;
+  const ncclRedOp_t ro = op == PLDA_OP_SUM ? ncclSum : op == PLDA_OP_MAX ? ncclMax : ncclMin;
+  const ncclResult_t r = c->api->AllReduce(dbuf, dbuf, (size_t)count, dt, ro, c->comm, static_cast<hipStream_t>(st));
+  return r == ncclSuccess ? 0 : rccl_err(c, r, "ncclAllReduce");
+}
+
+void rccl_destroy(void *vc) {
+  auto *c = static_cast<RcclCtx *>(vc);
+  if (c->comm) (void)c->api->CommDestroy(c->comm);
+  delete c;
+}
+
+// ------------------------------------------------------------------------------------ host-staged adapter
+// device-level table over two host operations: device data crosses a pinned bounce buffer in chunks of at most
+// HS_CHUNK bytes per rank, so the staging memory is bounded whatever the size of a super-block
+constexpr int64_t HS_CHUNK = (int64_t)32 << 20;
+
+struct HostStage {
+  plda_handle *h;
+  plda_host_collectives t;
+  int nranks, rank;
+  void *pinned = nullptr;
+  size_t cap = 0;
+  std::vector<int64_t> hoff, hcnt;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr; cap = 0;
+    if (hipHostMalloc(&pinned, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    cap = bytes;
+    return 0;
+  }
+};
+
+int hs_fail(HostStage *c, const char *what) {
+  fail(c->h, PLDA_E_HIP, "host-staged collective failed: %s", what);
+  return 1;
+}
+
+int hs_all_gather_v(void *vc, void *dbuf, const int64_t *offs, const int64_t *counts, void *vst) {
+  auto *c = static_cast<HostStage *>(vc);
+  hipStream_t st = static_cast<hipStream_t>(vst);
+  const int R = c->nranks, me = c->rank;
+  int64_t maxc = 0;
+  for (int q = 0; q < R; ++q) maxc = std::max(maxc, counts[q]);
+  if (maxc <= 0) return 0;
+  if (c->reserve((size_t)std::min(maxc, HS_CHUNK) * R)) return hs_fail(c, "pinned staging buffer");
+  char *hb = static_cast<char *>(c->pinned);
+  char *db = static_cast<char *>(dbuf);
+  c->hoff.resize(R); c->hcnt.resize(R);
+  for (int64_t c0 = 0; c0 < maxc; c0 += HS_CHUNK) {
+    int64_t run = 0;
+    for (int q = 0; q < R; ++q) {
+      c->hcnt[q] = std::max<int64_t>(0, std::min(HS_CHUNK, counts[q] - c0));
+      c->hoff[q] = run;
+      run += c->hcnt[q];
+    }
+    if (c->hcnt[me] > 0 &&
+        hipMemcpyAsync(hb + c->hoff[me], db + offs[me] + c0, (size_t)c->hcnt[me], hipMemcpyDeviceToHost, st) != hipSuccess)
+      return hs_fail(c, "device -> host copy");
+    if (hipStreamSynchronize(st) != hipSuccess) return hs_fail(c, "stream synchronisation");
+    if (c->t.all_gather_v(c->t.ctx, hb, c->hoff.data(), c->hcnt.data()) != 0) return hs_fail(c, "all_gather_v callback");
+    for (int q = 0; q < R; ++q) {
+      if (q == me || c->hcnt[q] <= 0) continue;
+      if (hipMemcpyAsync(db + offs[q] + c0, hb + c->hoff[q], (size_t)c->hcnt[q], hipMemcpyHostToDevice, st) != hipSuccess)
+        return hs_fail(c, "host -> device copy");
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return hs_fail(c, "stream synchronisation");   // the buffer is reused
+  }
+  return 0;
+}
+
+int hs_all_gather(void *vc, const void *dsend, void *drecv, int64_t bytes, void *vst) {
+  auto *c = static_cast<HostStage *>(vc);
+  char *mine = static_cast<char *>(drecv) + (int64_t)c->rank * bytes;
+  if (dsend != mine &&
+      hipMemcpyAsync(mine, dsend, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(vst)) != hipSuccess)
+    return hs_fail(c, "device -> device copy");
+  std::vector<int64_t> offs(c->nranks), counts(c->nranks, bytes);
+  for (int q = 0; q < c->nranks; ++q) offs[q] = (int64_t)q * bytes;
+  return hs_all_gather_v(vc, drecv, offs.data(), counts.data(), vst);
+}
+
+int hs_all_reduce(void *vc, void *dbuf, int64_t count, int32_t dtype, int32_t op, void *vst) {
+  auto *c = static_cast<HostStage *>(vc);
+  hipStream_t st = static_cast<hipStream_t>(vst);
+  const int64_t es = dtype == PLDA_DT_U32 ? 4 : 8;
+  const int64_t per = HS_CHUNK / es;
+  if (count <= 0) return 0;
+  if (c->reserve((size_t)std::min(count, per) * es)) return hs_fail(c, "pinned staging buffer");
+  char *db = static_cast<char *>(dbuf);
+  for (int64_t e0 = 0; e0 < count; e0 += per) {
+    const int64_t n = std::min(per, count - e0);
+    if (hipMemcpyAsync(c->pinned, db + e0 * es, (size_t)(n * es), hipMemcpyDeviceToHost, st) != hipSuccess)
+      return hs_fail(c, "device -> host copy");
+    if (hipStreamSynchronize(st) != hipSuccess) return hs_fail(c, "stream synchronisation");
+    if (c->t.all_reduce(c->t.ctx, c->pinned, n, dtype, op) != 0) return hs_fail(c, "all_reduce callback");
+    if (hipMemcpyAsync(db + e0 * es, c->pinned, (size_t)(n * es), hipMemcpyHostToDevice, st) != hipSuccess)
+      return hs_fail(c, "host -> device copy");
+    if (hipStreamSynchronize(st) != hipSuccess) return hs_fail(c, "stream synchronisation");
+  }
+  return 0;
+}
+
+void hs_destroy(void *vc) {
+  auto *c = static_cast<HostStage *>(vc);
+  if (c->t.destroy) c->t.destroy(c->t.ctx);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  delete c;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------ installing a table
+static int install(plda_handle *h, int nranks, int rank, const plda_collectives &t, int kind) {
+  h->coll = t; h->comm_kind = kind; h->comm = true; h->comm_nranks = nranks; h->comm_rank = rank;
+  PLDA_HIP(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  for (auto &e : h->comm_ev) PLDA_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return PLDA_OK;
+}
+
+static int check_new(plda_handle *h, int nranks, int rank, const void *p, const char *fn) {
+  if (h->comm) return fail(h, PLDA_E_INVAL, "%s: this handle already has a communicator", fn);
+  if (nranks <= 0 || rank < 0 || rank >= nranks || !p) return fail(h, PLDA_E_INVAL, "%s: bad argument", fn);
+  return PLDA_OK;
+}
+
+int comm_init(plda_handle *h, int nranks, int rank, const void *uid) {
+  PLDA_TRY(check_new(h, nranks, rank, uid, "comm_init"));
+  std::string why;
+  const Rccl *api = rccl_api(&why);
+  if (!api) return fail(h, PLDA_E_HIP, "comm_init: %s", why.c_str());
+  ncclUniqueId id;
+  std::memcpy(&id, uid, sizeof(id));
+  ncclComm_t c = nullptr;
+  const ncclResult_t r = api->CommInitRank(&c, nranks, id, rank);
+  if (r != ncclSuccess) return fail(h, PLDA_E_HIP, "comm_init: ncclCommInitRank: %s", api->GetErrorString(r));
+  auto *ctx = new RcclCtx{api, c, nranks, h};
+  const plda_collectives t = {ctx, rccl_all_gather, rccl_all_gather_v, rccl_all_reduce, rccl_destroy};
+  return install(h, nranks, rank, t, 1);
+}
+
+int comm_init_custom(plda_handle *h, int nranks, int rank, const plda_collectives *t) {
+  PLDA_TRY(check_new(h, nranks, rank, t, "comm_init_custom"));
+  if (!t->all_gather || !t->all_gather_v || !t->all_reduce) return fail(h, PLDA_E_INVAL, "comm_init_custom: the table lacks an operation");
+  return install(h, nranks, rank, *t, 3);
+}
+
+int comm_init_host(plda_handle *h, int nranks, int rank, const plda_host_collectives *t) {
+  PLDA_TRY(check_new(h, nranks, rank, t, "comm_init_host"));
+  if (!t->all_gather_v || !t->all_reduce) return fail(h, PLDA_E_INVAL, "comm_init_host: the table lacks an operation");
+  auto *ctx = new HostStage{h, *t, nranks, rank};
+  const plda_collectives dt = {ctx, hs_all_gather, hs_all_gather_v, hs_all_reduce, hs_destroy};
+  return install(h, nranks, rank, dt, 2);
+}
+
+int comm_destroy(plda_handle *h) {
+  if (!h->comm) { h->comm_nranks = 1; h->comm_rank = 0; return PLDA_OK; }
+  (void)hipStreamSynchronize(h->stream);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->coll.destroy) h->coll.destroy(h->coll.ctx);
+  h->coll = plda_collectives{nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (auto &e : h->comm_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  h->comm = false; h->comm_kind = 0; h->comm_stream = nullptr; h->comm_nranks = 1; h->comm_rank = 0;
+  return PLDA_OK;
+}
+
+int comm_describe(plda_handle *h, std::string &js) {
+  int nranks = h->comm_nranks, rank = h->comm_rank, device = h->device, version = 0;
+  const char *transport = !h->comm ? (h->comm_nranks > 1 ? "emulated" : "none")
+                                   : h->comm_kind == 1 ? "rccl" : h->comm_kind == 2 ? "host" : "custom";
+  if (h->comm && h->comm_kind == 1) {
+    auto *c = static_cast<RcclCtx *>(h->coll.ctx);
+    if (c->api->CommCount(c->comm, &nranks) != ncclSuccess || c->api->CommUserRank(c->comm, &rank) != ncclSuccess ||
+        c->api->CommCuDevice(c->comm, &device) != ncclSuccess)
+      return fail(h, PLDA_E_HIP, "comm_describe: the communicator does not answer");
+    (void)c->api->GetVersion(&version);
+  }
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, sizeof bus, h->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+  char buf[384];
+  std::snprintf(buf, sizeof buf,
+                "{\"transport\": \"%s\", \"nranks\": %d, \"rank\": %d, \"device\": %d, \"pci_bus_id\": \"%s\", \"rccl_version\": %d}",
+                transport, nranks, rank, device, bus, version);
+  js = buf;
+  return PLDA_OK;
+}
+
+// a failed collective: the built-in providers have written their own message, a caller-supplied table has not
+static int coll_failed(plda_handle *h, const char *what) {
+  if (h->err.empty()) return fail(h, PLDA_E_HIP, "collective %s failed (the transport's callback returned non-zero)", what);
+  return PLDA_E_HIP;
+}
+#define PLDA_COLL(h, expr, what)                      \
+  do {                                                \
+    (h)->err.clear();                                 \
+    if ((expr) != 0) return coll_failed((h), what);   \
+  } while (0)
 
 // contiguous balanced partition of m items over `world` ranks
 static inline void shard_range(int64_t m, int world, int rank, int64_t &b, int64_t &e) {
@@ -54,96 +354,104 @@ static inline void shard_range(int64_t m, int world, int rank, int64_t &b, int64
   e = b + base + (rank < extra ? 1 : 0);
 }
 
-// all ranks contribute `counts[q]` elements at offset `offs[q]` of the same (replicated-layout) buffer:
-// an all-gather with ragged pieces, as one group of broadcasts (in place)
-static int allgatherv_inplace(plda_handle *h, void *buf, const std::vector<int64_t> &offs, const std::vector<int64_t> &counts,
-                              size_t elem, hipStream_t st) {
-  PLDA_NCCL(h, ncclGroupStart());
-  for (int q = 0; q < h->comm_nranks; ++q) {
-    if (counts[q] <= 0) continue;
-    char *p = static_cast<char *>(buf) + (size_t)offs[q] * elem;
-    const ncclResult_t r = ncclBroadcast(p, p, (size_t)counts[q] * elem, ncclChar, q, comm_of(h), st);
-    if (r != ncclSuccess) { (void)ncclGroupEnd(); return nccl_fail(h, r, "ncclBroadcast", __LINE__); }
-  }
-  PLDA_NCCL(h, ncclGroupEnd());
-  return PLDA_OK;
-}
-
-int comm_init(plda_handle *h, int nranks, int rank, const void *uid) {
-  if (h->comm) return fail(h, PLDA_E_INVAL, "comm_init: this handle already has a communicator");
-  if (nranks <= 0 || rank < 0 || rank >= nranks || !uid) return fail(h, PLDA_E_INVAL, "comm_init: bad argument");
-  ncclUniqueId id;
-  std::memcpy(&id, uid, sizeof(id));
-  ncclComm_t c = nullptr;
-  PLDA_NCCL(h, ncclCommInitRank(&c, nranks, id, rank));
-  h->comm = c; h->comm_nranks = nranks; h->comm_rank = rank;
-  PLDA_HIP(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-  for (auto &e : h->comm_ev) PLDA_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return PLDA_OK;
-}
-
-int comm_destroy(plda_handle *h) {
-  if (!h->comm) return PLDA_OK;
-  (void)hipStreamSynchronize(h->stream);
-  (void)hipStreamSynchronize(h->comm_stream);
-  (void)ncclCommDestroy(comm_of(h));
-  for (auto &e : h->comm_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-  h->comm = nullptr; h->comm_stream = nullptr; h->comm_nranks = 1; h->comm_rank = 0;
-  return PLDA_OK;
-}
-
 // ------------------------------------------------------------------------------------ trials matrix
+// The partition (also exported as plda_shard_plan): super-block s = R consecutive blocks, block q of it -> rank q.
+struct ShardPlan {
+  int64_t block, super, nfull, rem, tail_block, nsuper;
+  ShardPlan(int64_t M, int R, int64_t block_rows) {
+    if (block_rows <= 0) block_rows = 4096;
+    block = round_up(block_rows, 256);
+    super = block * R;
+    nfull = M / super;                                          // full super-blocks; the remainder is dealt out
+    rem = M - nfull * super;                                    // again in (smaller) equal blocks, so that the
+    tail_block = rem ? round_up(ceil_div(rem, R), 256) : 0;     // last rows do not all land on rank 0
+    nsuper = nfull + (rem ? 1 : 0);
+  }
+  int64_t blk(int64_t s) const { return s < nfull ? block : tail_block; }
+  // rows [r0, r0 + cnt) of rank q in super-block s (cnt may be 0 in the tail)
+  void rows(int64_t s, int q, int64_t M, int64_t &r0, int64_t &cnt) const {
+    r0 = s * super + (int64_t)q * blk(s);
+    cnt = std::max<int64_t>(0, std::min(blk(s), M - r0));
+  }
+};
+
+int shard_plan(int64_t M, int R, int rank, int64_t block_rows, int64_t *row_start, int64_t *row_count, int64_t cap,
+               int64_t *nblocks, int64_t *local_rows) {
+  if (M < 0 || R <= 0 || rank < 0 || rank >= R) return PLDA_E_INVAL;
+  const ShardPlan p(M, R, block_rows);
+  int64_t nb = 0, rows = 0;
+  for (int64_t s = 0; s < p.nsuper; ++s) {
+    int64_t r0, cnt;
+    p.rows(s, rank, M, r0, cnt);
+    if (cnt <= 0) continue;
+    if (nb < cap) {
+      if (row_start) row_start[nb] = r0;
+      if (row_count) row_count[nb] = cnt;
+    }
+    ++nb; rows += cnt;
+  }
+  if (nblocks) *nblocks = nb;
+  if (local_rows) *local_rows = rows;
+  return (row_start || row_count) && nb > cap ? PLDA_E_CAPACITY : PLDA_OK;
+}
+
+// dlocal != nullptr: compact slab (this rank's blocks back to back); else this rank's rows of dfull.
+// gather: assemble dfull on every rank (needs a communicator; ignored without one).
 int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
-                                const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dout,
-                                int64_t ld, int64_t block_rows, int gather) {
+                                const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dlocal,
+                                int64_t ld_local, float *dfull, int64_t ld_full, int64_t block_rows, int gather) {
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix_sharded: model not fitted");
   if (M <= 0 || Nt <= 0) return PLDA_OK;
-  if (!dU || !dV || !dout || ld < Nt) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: bad argument");
+  if (!dU || !dV || (!dlocal && !dfull)) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: bad argument");
+  if ((dlocal && ld_local < Nt) || (dfull && ld_full < Nt)) return fail(h, PLDA_E_INVAL, "score_matrix_sharded: ld < Nt");
   const int R = h->comm_nranks, me = h->comm_rank;   // (without a communicator: 1 / 0, or plda_comm_emulate's)
-  if (block_rows <= 0) block_rows = 4096;
-  block_rows = round_up(block_rows, 256);
+  const ShardPlan p(M, R, block_rows);
   const int D = h->Dout;
   const bool zn = dzmean && dzstd;
-  const int64_t super = block_rows * R;                       // rows of one super-block
-  const int64_t nfull = M / super;                            // full super-blocks; the remainder is dealt out
-  const int64_t rem = M - nfull * super;                      // again in (smaller) equal blocks, so that the
-  const int64_t tail_block = rem ? round_up(ceil_div(rem, R), 256) : 0;   // last rows do not all land on rank 0
-  const int64_t nsuper = nfull + (rem ? 1 : 0);
-  const bool do_gather = gather && R > 1 && h->comm;
+  const bool do_gather = gather && dfull && R > 1 && h->comm;
+  if (do_gather && dlocal && ld_local != ld_full)
+    return fail(h, PLDA_E_INVAL, "score_matrix_sharded: gathering a compact slab needs ld_local == ld_full");
   bool packedB = false;
-  for (int64_t s = 0; s < nsuper; ++s) {
-    const int64_t s0 = s * super;
-    const int64_t blk = s < nfull ? block_rows : tail_block;
-    const int64_t r0 = s0 + (int64_t)me * blk;
-    const int64_t cnt = std::max<int64_t>(0, std::min(blk, M - r0));
+  int64_t lo = 0;                                               // rows of the compact slab written so far
+  for (int64_t s = 0; s < p.nsuper; ++s) {
+    int64_t r0, cnt;
+    p.rows(s, me, M, r0, cnt);
+    float *mine = dlocal ? dlocal + lo * ld_local : dfull + r0 * ld_full;
+    const int64_t ldm = dlocal ? ld_local : ld_full;
     if (cnt > 0) {
       PLDA_TRY(score_matrix_device(h, dU + r0 * D, dn ? dn + r0 : nullptr, n_uniform, cnt, dV, Nt, zn ? dzmean + r0 : nullptr,
-                                   zn ? dzstd + r0 : nullptr, dout + r0 * ld, ld, packedB));
+                                   zn ? dzstd + r0 : nullptr, mine, ldm, packedB));
       packedB = true;                                          // the test side is packed once
+      lo += cnt;
     }
     if (!do_gather) continue;
     hipEvent_t ev = h->comm_ev[s & 3];
     PLDA_HIP(h, hipEventRecord(ev, h->stream));
     PLDA_HIP(h, hipStreamWaitEvent(h->comm_stream, ev, 0));
-    if (s < nfull) {
-      // full super-block: equal pieces, contiguous -> in-place all-gather
-      PLDA_NCCL(h, ncclAllGather(dout + r0 * ld, dout + s0 * ld, (size_t)(block_rows * ld), ncclFloat, comm_of(h),
-                                 h->comm_stream));
+    const int64_t s0 = s * p.super;
+    if (s < p.nfull) {
+      // full super-block: R equal pieces, contiguous in dfull -> one all-gather (in place when `mine` lives there)
+      PLDA_COLL(h, h->coll.all_gather(h->coll.ctx, mine, dfull + s0 * ld_full, p.block * ld_full * 4, h->comm_stream), "all_gather");
     } else {
       std::vector<int64_t> offs(R), counts(R);
       for (int q = 0; q < R; ++q) {
-        const int64_t q0 = s0 + (int64_t)q * blk;
-        offs[q] = q0 * ld;
-        counts[q] = std::max<int64_t>(0, std::min(blk, M - q0)) * ld;
+        int64_t q0, qc;
+        p.rows(s, q, M, q0, qc);
+        offs[q] = q0 * ld_full * 4;
+        counts[q] = qc * ld_full * 4;
       }
-      PLDA_TRY(allgatherv_inplace(h, dout, offs, counts, 4, h->comm_stream));
+      if (dlocal && cnt > 0)
+        PLDA_HIP(h, hipMemcpyAsync(dfull + r0 * ld_full, mine, (size_t)(cnt * ld_full * 4), hipMemcpyDeviceToDevice, h->comm_stream));
+      PLDA_COLL(h, h->coll.all_gather_v(h->coll.ctx, dfull, offs.data(), counts.data(), h->comm_stream), "all_gather_v");
     }
   }
   if (do_gather) {
     // later work on the handle's stream sees the assembled matrix
     PLDA_HIP(h, hipEventRecord(h->comm_ev[4], h->comm_stream));
     PLDA_HIP(h, hipStreamWaitEvent(h->stream, h->comm_ev[4], 0));
+  } else if (gather && dfull && dlocal && R == 1) {
+    PLDA_HIP(h, hipMemcpy2DAsync(dfull, (size_t)ld_full * 4, dlocal, (size_t)ld_local * 4, (size_t)Nt * 4, (size_t)M,
+                                 hipMemcpyDeviceToDevice, h->stream));
   }
   h->last_M = M;
   return PLDA_OK;
@@ -159,9 +467,9 @@ int znorm_stats_sharded_device(plda_handle *h, const double *dbkg, int64_t Nb, i
     PLDA_TRY(znorm_stats_device(h, dbkg, Nb, num_examples, Din, dmodels + b * h->Dout, e - b, dmean + b, dstd + b));
   if (R == 1 || !h->comm) return PLDA_OK;
   std::vector<int64_t> offs(R), counts(R);
-  for (int q = 0; q < R; ++q) { int64_t qb, qe; shard_range(M, R, q, qb, qe); offs[q] = qb; counts[q] = qe - qb; }
-  PLDA_TRY(allgatherv_inplace(h, dmean, offs, counts, 8, h->stream));
-  PLDA_TRY(allgatherv_inplace(h, dstd, offs, counts, 8, h->stream));
+  for (int q = 0; q < R; ++q) { int64_t qb, qe; shard_range(M, R, q, qb, qe); offs[q] = qb * 8; counts[q] = (qe - qb) * 8; }
+  PLDA_COLL(h, h->coll.all_gather_v(h->coll.ctx, dmean, offs.data(), counts.data(), h->stream), "all_gather_v");
+  PLDA_COLL(h, h->coll.all_gather_v(h->coll.ctx, dstd, offs.data(), counts.data(), h->stream), "all_gather_v");
   return PLDA_OK;
 }
 
@@ -178,23 +486,27 @@ int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const
   PLDA_HIP(h, h->w[6].reserve((size_t)R * 8));
   int64_t *dK = h->w[6].as<int64_t>();
   PLDA_HIP(h, hipMemcpyAsync(dK + me, &K, 8, hipMemcpyHostToDevice, h->stream));
-  PLDA_NCCL(h, ncclAllGather(dK + me, dK, 1, ncclInt64, comm_of(h), h->stream));
+  PLDA_COLL(h, h->coll.all_gather(h->coll.ctx, dK + me, dK, 8, h->stream), "all_gather");
   std::vector<int64_t> hK(R);
   PLDA_HIP(h, hipMemcpyAsync(hK.data(), dK, (size_t)R * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  std::vector<int64_t> off(R), cntM(R), offM(R);
+  std::vector<int64_t> offC(R), cntC(R), offM(R), cntM(R);
   int64_t Kt = 0;
-  for (int q = 0; q < R; ++q) { off[q] = Kt; Kt += hK[q]; }
-  for (int q = 0; q < R; ++q) { offM[q] = off[q] * D; cntM[q] = hK[q] * D; }
+  for (int q = 0; q < R; ++q) {
+    if (hK[q] <= 0) return fail(h, PLDA_E_INVAL, "fit_sharded: rank %d reports %lld speakers", q, (long long)hK[q]);
+    offC[q] = Kt * 8; cntC[q] = hK[q] * 8;
+    offM[q] = Kt * D * 8; cntM[q] = hK[q] * D * 8;
+    Kt += hK[q];
+  }
   // merged statistics in rank order: means / counts gathered, scatter summed
   Tmp mm, mc;
   PLDA_HIP(h, mm.alloc((size_t)Kt * D * 8));
   PLDA_HIP(h, mc.alloc((size_t)Kt * 8));
-  PLDA_HIP(h, hipMemcpyAsync(static_cast<double *>(mm.p) + offM[me], h->f_means.p, (size_t)K * D * 8, hipMemcpyDeviceToDevice, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(static_cast<int64_t *>(mc.p) + off[me], h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToDevice, h->stream));
-  PLDA_TRY(allgatherv_inplace(h, mm.p, offM, cntM, 8, h->stream));
-  PLDA_TRY(allgatherv_inplace(h, mc.p, off, hK, 8, h->stream));
-  PLDA_NCCL(h, ncclAllReduce(h->f_scatter.p, h->f_scatter.p, DD, ncclDouble, ncclSum, comm_of(h), h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(static_cast<char *>(mm.p) + offM[me], h->f_means.p, (size_t)K * D * 8, hipMemcpyDeviceToDevice, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(static_cast<char *>(mc.p) + offC[me], h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToDevice, h->stream));
+  PLDA_COLL(h, h->coll.all_gather_v(h->coll.ctx, mm.p, offM.data(), cntM.data(), h->stream), "all_gather_v");
+  PLDA_COLL(h, h->coll.all_gather_v(h->coll.ctx, mc.p, offC.data(), cntC.data(), h->stream), "all_gather_v");
+  PLDA_COLL(h, h->coll.all_reduce(h->coll.ctx, h->f_scatter.p, (int64_t)DD, PLDA_DT_F64, PLDA_OP_SUM, h->stream), "all_reduce");
   PLDA_HIP(h, h->f_means.reserve((size_t)Kt * D * 8));
   PLDA_HIP(h, h->f_counts.reserve((size_t)Kt * 8));
   PLDA_HIP(h, hipMemcpyAsync(h->f_means.p, mm.p, (size_t)Kt * D * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -214,15 +526,15 @@ static int eer_comm_reduce(void *vctx, unsigned long long *hist, unsigned *below
   unsigned long long *d = h->w[7].as<unsigned long long>();
   if (hist) {
     if (hipMemcpyAsync(d, hist, NB * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
-    if (ncclAllReduce(d, d, NB, ncclUint64, ncclSum, comm_of(h), h->stream) != ncclSuccess) return 1;
+    if (h->coll.all_reduce(h->coll.ctx, d, (int64_t)NB, PLDA_DT_U64, PLDA_OP_SUM, h->stream) != 0) return 1;
     if (hipMemcpyAsync(hist, d, NB * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 1;
     return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 1;
   }
   unsigned *du = reinterpret_cast<unsigned *>(d);
   if (hipMemcpyAsync(du, below, 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
   if (hipMemcpyAsync(du + 1, above, 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
-  if (ncclAllReduce(du, du, 1, ncclUint32, ncclMax, comm_of(h), h->stream) != ncclSuccess) return 1;
-  if (ncclAllReduce(du + 1, du + 1, 1, ncclUint32, ncclMin, comm_of(h), h->stream) != ncclSuccess) return 1;
+  if (h->coll.all_reduce(h->coll.ctx, du, 1, PLDA_DT_U32, PLDA_OP_MAX, h->stream) != 0) return 1;
+  if (h->coll.all_reduce(h->coll.ctx, du + 1, 1, PLDA_DT_U32, PLDA_OP_MIN, h->stream) != 0) return 1;
   if (hipMemcpyAsync(below, du, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 1;
   if (hipMemcpyAsync(above, du + 1, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 1;
   return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 1;
@@ -240,8 +552,15 @@ using namespace plda;
 
 extern "C" int plda_comm_unique_id(void *out, int64_t cap_bytes) {
   if (!out || cap_bytes < (int64_t)sizeof(ncclUniqueId)) return PLDA_E_CAPACITY;
+  const Rccl *api = rccl_api(nullptr);
+  if (!api) return PLDA_E_HIP;
   ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return PLDA_E_HIP;
+  if (api->GetUniqueId(&id) != ncclSuccess) return PLDA_E_HIP;
   std::memcpy(out, &id, sizeof(id));
   return PLDA_OK;
+}
+
+extern "C" int plda_shard_plan(int64_t M, int32_t nranks, int32_t rank, int64_t block_rows, int64_t *row_start,
+                               int64_t *row_count, int64_t cap, int64_t *nblocks, int64_t *local_rows) {
+  return shard_plan(M, nranks, rank, block_rows, row_start, row_count, cap, nblocks, local_rows);
 }

@@ -108,8 +108,11 @@ struct plda_handle {
   std::vector<TraceSpan> trace_spans;
   size_t trace_used = 0;
 
-  // ---- multi-GPU (comm.hip): RCCL communicator, side stream for the gather, ordering events ----
-  void *comm = nullptr;          // ncclComm_t
+  // ---- multi-GPU (comm.hip): the collective table (RCCL, host-staged or caller-supplied), side stream for the
+  // gather, ordering events.  comm_kind: 0 none / emulated, 1 RCCL, 2 host-staged, 3 custom ----
+  plda_collectives coll = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int comm_kind = 0;
+  bool comm = false;             // a communicator is installed (collectives run)
   int comm_nranks = 1, comm_rank = 0;
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -643,6 +643,9 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   PLDA_HIP(h, h->d_transform.reserve(DD * 8));
   PLDA_HIP(h, h->d_psi.reserve((size_t)D * 8));
   PLDA_HIP(h, h->d_offset.reserve((size_t)D * 8));
+  // from here on the model buffers are overwritten: the handle counts as fitted again only once the
+  // factorisation flags have been read back (a failed GetOutput must not leave a NaN model behind a true flag)
+  h->fitted = false;
   // enqueue only: with the direct eigensolver GetOutput reads nothing back before the model copies below
   bool pending = false;
   if (iters > 0 && h->simdiag_has_vr)   // the per-iteration EM arm ran: warm start from its last eigenvectors

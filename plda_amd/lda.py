@@ -148,7 +148,7 @@ class LDA(object):
 
     def load(self, path):
         from .libplda import _npz_path
-        z = np.load(_npz_path(path), allow_pickle=False)
+        z = np.load(_npz_path(path, for_load=True), allow_pickle=False)
         self.solver = str(z["solver"])
         self._classes = z["classes"]
         coef = np.ascontiguousarray(z["coef"], np.float64)

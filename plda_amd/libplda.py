@@ -50,14 +50,17 @@ def _labels(y, n, allow_strings_msg=False):
     return np.ascontiguousarray(y)
 
 
-def _npz_path(path):
-    """np.savez appends '.npz' to a path without that suffix and np.load does not: normalise both ways,
-    so that save('model') / load('model') round-trip.  File objects pass through."""
+def _npz_path(path, for_load=False):
+    """np.savez appends '.npz' to a path without that suffix and np.load does not: normalise, so that
+    save('model') / load('model') round-trip.  On load an existing file of exactly that name wins (a model
+    written through a file object may have any name).  File objects pass through."""
     if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__"):
         import os
         p = os.fspath(path)
         if isinstance(p, bytes):
             p = p.decode()
+        if for_load and os.path.exists(p):
+            return p
         return p if p.endswith(".npz") else p + ".npz"
     return path
 
@@ -157,7 +160,7 @@ class MPlda(object):
                  zn_std=np.array([self._stdvz[i] for i in ids], dtype=np.float64))
 
     def load(self, path):
-        z = np.load(_npz_path(path))
+        z = np.load(_npz_path(path, for_load=True))
         self.set_model(z["mean"], z["transform"], z["psi"])
         self._meanz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_mean"])}
         self._stdvz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_std"])}
@@ -460,8 +463,21 @@ class MPlda(object):
         uid = C.create_string_buffer(bytes(unique_id), 128)
         self._ck(self._lib.plda_comm_init(self._h, int(nranks), int(rank), uid))
 
+    def comm_init_host(self, nranks, rank, table):
+        """Collectives over a HOST transport: `table` is a _native.HostCollectives (two callbacks on host buffers,
+        e.g. plda_amd.sharding.TorchHostTransport over gloo); the library stages device data through a pinned
+        bounce buffer.  The callbacks must stay alive as long as the communicator: they are kept on this object."""
+        self._comm_table = table
+        self._ck(self._lib.plda_comm_init_host(self._h, int(nranks), int(rank), C.byref(table)))
+
+    def comm_init_custom(self, nranks, rank, table):
+        """Collectives through a caller-supplied device-level table (_native.Collectives)."""
+        self._comm_table = table
+        self._ck(self._lib.plda_comm_init_custom(self._h, int(nranks), int(rank), C.byref(table)))
+
     def comm_destroy(self):
         self._ck(self._lib.plda_comm_destroy(self._h))
+        self._comm_table = None
 
     def comm_emulate(self, nranks, rank):
         self._ck(self._lib.plda_comm_emulate(self._h, int(nranks), int(rank)))
@@ -470,6 +486,31 @@ class MPlda(object):
         a, b = C.c_int32(), C.c_int32()
         self._ck(self._lib.plda_comm_info(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def comm_describe(self):
+        """dict(transport, nranks, rank, device, pci_bus_id, rccl_version) as the transport itself reports it
+        (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice)."""
+        import json
+        buf = C.create_string_buffer(512)
+        self._ck(self._lib.plda_comm_describe(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    @staticmethod
+    def shard_plan(m, nranks, rank, block_rows=4096):
+        """This rank's blocks [(first row, stop row), ...] of the row partition of the trials matrix
+        (plda_shard_plan: a pure function of the library, no GPU needed) -- their order is also the order of
+        the rows in the rank's compact slab."""
+        lib = N.load()
+        nb, rows = C.c_int64(), C.c_int64()
+        rc = lib.plda_shard_plan(int(m), int(nranks), int(rank), int(block_rows), None, None, 0, C.byref(nb), C.byref(rows))
+        if rc != N.PLDA_OK:
+            raise N.PldaError(rc, "plda_shard_plan: bad argument")
+        st, ct = np.zeros(max(nb.value, 1), np.int64), np.zeros(max(nb.value, 1), np.int64)
+        rc = lib.plda_shard_plan(int(m), int(nranks), int(rank), int(block_rows), _ptr(st), _ptr(ct), nb.value,
+                                 C.byref(nb), C.byref(rows))
+        if rc != N.PLDA_OK:
+            raise N.PldaError(rc, "plda_shard_plan failed")
+        return [(int(a), int(a + c)) for a, c in zip(st[:nb.value], ct[:nb.value])]
 
     def score_matrix_sharded_dev(self, dU, dn, n_uniform, m, dV, nt, dout, ld, block_rows=4096, gather=False,
                                  dzmean=None, dzstd=None):
@@ -480,6 +521,26 @@ class MPlda(object):
             C.c_void_p(int(dV)), int(nt), C.c_void_p(int(dzmean)) if dzmean else None,
             C.c_void_p(int(dzstd)) if dzstd else None, C.c_void_p(int(dout)), int(ld), int(block_rows),
             1 if gather else 0))
+
+    def score_matrix_sharded_local_dev(self, dU, dn, n_uniform, m, dV, nt, dlocal, ld_local, block_rows=4096,
+                                       dfull=None, ld_full=0, dzmean=None, dzstd=None):
+        """The same partition with COMPACT output: this rank's blocks back to back in dlocal[local_rows, ld_local]
+        (row map: shard_plan); dfull, if given, additionally receives the assembled [M, ld_full] matrix."""
+        self._ck(self._lib.plda_score_matrix_sharded_local_dev(
+            self._h, C.c_void_p(int(dU)), C.c_void_p(int(dn)) if dn else None, int(n_uniform), int(m),
+            C.c_void_p(int(dV)), int(nt), C.c_void_p(int(dzmean)) if dzmean else None,
+            C.c_void_p(int(dzstd)) if dzstd else None, C.c_void_p(int(dlocal)), int(ld_local), int(block_rows),
+            C.c_void_p(int(dfull)) if dfull else None, int(ld_full)))
+
+    def eer_matrix_comm_dev(self, dscores, ld, m, nt, denrol_spk, dtest_spk):
+        """EER of a row-sharded trials matrix (this rank's slab [m, ld] with the speaker ids of ITS rows, all test
+        speaker ids), the histogram counters summed over the ranks through the handle's collectives.  Returns
+        the 6-vector (threshold, FAR, FRR, EER, #targets, #impostors), identical on every rank."""
+        out = np.zeros(6)
+        self._ck(self._lib.plda_eer_matrix_comm_dev(self._h, C.c_void_p(int(dscores)) if dscores else None, int(ld), int(m),
+                                                    int(nt), C.c_void_p(int(denrol_spk)) if denrol_spk else None,
+                                                    C.c_void_p(int(dtest_spk)), _ptr(out)))
+        return out
 
     def znorm_stats_sharded_dev(self, dbkg, nb, num_examples, d, dmodels, m, dmean, dstd):
         self._ck(self._lib.plda_znorm_stats_sharded_dev(self._h, C.c_void_p(int(dbkg)), int(nb), int(num_examples), int(d),

@@ -1,31 +1,109 @@
-"""plda_amd/sharding.py -- the path sharded across ranks (one process per GPU): trials by enrol row,
-z-norm statistics by model, fit statistics by speaker.
+"""plda_amd/sharding.py -- host-side glue of the multi-GPU path (one process per GPU).
 
-The trials matrix partitions by enrol row: trial (i, j) needs only enrol row i, the
-replicated test set and the replicated model, so every rank scores its contiguous row
-slab with no data-path collective.  Assembling the full [M, Nt] score
-matrix on every rank is ONE all-gather of the row slabs (RCCL over xGMI when the
-process group is "nccl"); it is optional (`gather=False` keeps scores sharded, which is
-what shard-local consumers -- thresholding, EER counting, z-norm -- want) because its
-volume, not the GEMM, bounds scaling: each rank must receive (R-1)/R of M*Nt*4 bytes
-over its xGMI links.  When requested, the gather is issued slab by slab on a side
-stream so that slab c travels while slab c+1 is being scored.
+The sharding itself -- trials by enrol row, z-norm statistics by model, fit statistics by speaker, EER
+counters summed -- lives behind the C ABI (csrc/comm.hip: plda_score_matrix_sharded[_local]_dev,
+plda_znorm_stats_sharded_dev, plda_fit_sharded_dev, plda_eer_matrix_comm_dev); this module only
 
-`score_block` is any callable (U_rows, n_rows, V) -> scores tensor [rows, Nt]; on the
-GPU it wraps MPlda.score_matrix_dev, in the gloo/CPU tests it wraps the oracle.
+  * gives an engine its communicator (`init_comm`): RCCL over xGMI (production), or any
+    torch.distributed backend as a HOST transport (`TorchHostTransport`: the two host operations of
+    `plda_host_collectives` over e.g. gloo -- what the multi-process tests on ONE GPU use, and what
+    runs on CPU in the world-size-2 tests of the transport itself);
+  * wraps the entry points for torch tensors (allocation of the compact slab, the row map).
+
+The reference has no counterpart (one process, one thread: SURVEY.md section 2c).
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _native as N
 
-def init_comm(engine, group=None, device=None):
-    """Give `engine` (an MPlda) its RCCL communicator: rank 0 draws the unique id, torch.distributed
-    (any backend -- it only carries 128 bytes) hands it round, every rank calls plda_comm_init.  After
-    this the library's own sharded entry points (score_matrix_sharded_dev, fit_sharded_dev,
-    znorm_stats_sharded_dev, plda_eer_matrix_comm_dev) run over RCCL without torch in the data path."""
+
+# ------------------------------------------------------------------------------------ transports
+class TorchHostTransport(object):
+    """`plda_host_collectives` over a torch.distributed process group (any backend that moves CPU tensors,
+    e.g. gloo).  all_gather_v = one broadcast per non-empty piece, in place on the library's pinned
+    buffer; all_reduce = dist.all_reduce on a view of it.  Exceptions never cross the C boundary: a
+    callback that fails returns 1 and keeps the exception in `last_error`."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.last_error = None
+        self.calls = {"all_gather_v": 0, "all_reduce": 0, "bytes": 0}
+        self._agv = N.HOST_ALL_GATHER_V(self._all_gather_v)
+        self._ar = N.HOST_ALL_REDUCE(self._all_reduce)
+        self.table = N.HostCollectives(None, self._agv, self._ar, N.DESTROY_FN())
+
+    def _src(self, q):
+        return dist.get_global_rank(self.group, q) if self.group is not None else q
+
+    def _all_gather_v(self, ctx, hbuf, offs, counts):
+        try:
+            world = self.world
+            o = [int(offs[q]) for q in range(world)]
+            c = [int(counts[q]) for q in range(world)]
+            total = max(a + b for a, b in zip(o, c))
+            if total <= 0:
+                return 0
+            buf = np.ctypeslib.as_array(C.cast(hbuf, C.POINTER(C.c_uint8)), shape=(total,))
+            for q in range(world):
+                if c[q] > 0:
+                    dist.broadcast(torch.from_numpy(buf[o[q]:o[q] + c[q]]), src=self._src(q), group=self.group)
+                    self.calls["bytes"] += c[q]
+            self.calls["all_gather_v"] += 1
+            return 0
+        except Exception as e:       # noqa: BLE001 -- never let an exception cross the C boundary
+            self.last_error = e
+            return 1
+
+    def _all_reduce(self, ctx, hbuf, count, dtype, op):
+        try:
+            count = int(count)
+            if count <= 0:
+                return 0
+            rop = {N.PLDA_OP_SUM: dist.ReduceOp.SUM, N.PLDA_OP_MAX: dist.ReduceOp.MAX, N.PLDA_OP_MIN: dist.ReduceOp.MIN}[int(op)]
+            if dtype == N.PLDA_DT_F64:
+                a = np.ctypeslib.as_array(C.cast(hbuf, C.POINTER(C.c_double)), shape=(count,))
+                dist.all_reduce(torch.from_numpy(a), op=rop, group=self.group)
+            elif dtype == N.PLDA_DT_U64:
+                # two's-complement sums wrap identically; counters stay far below 2^63, so max / min order too
+                a = np.ctypeslib.as_array(C.cast(hbuf, C.POINTER(C.c_int64)), shape=(count,))
+                dist.all_reduce(torch.from_numpy(a), op=rop, group=self.group)
+            elif dtype == N.PLDA_DT_U32:
+                a = np.ctypeslib.as_array(C.cast(hbuf, C.POINTER(C.c_uint32)), shape=(count,))
+                t = torch.from_numpy(a.astype(np.int64))
+                dist.all_reduce(t, op=rop, group=self.group)
+                a[:] = t.numpy().astype(np.uint32)
+            else:
+                raise ValueError("unknown dtype %d" % dtype)
+            self.calls["all_reduce"] += 1
+            return 0
+        except Exception as e:       # noqa: BLE001
+            self.last_error = e
+            return 1
+
+
+def init_comm(engine, group=None, device=None, transport="rccl"):
+    """Give `engine` (an MPlda) its communicator; returns (world, rank).
+
+    transport "rccl": rank 0 draws the unique id, torch.distributed (any backend -- it only carries 128 bytes)
+    hands it round, every rank calls plda_comm_init; afterwards the library's sharded entry points run over
+    RCCL without torch in the data path.  transport "host": the collectives travel through `group` itself
+    (TorchHostTransport) -- no RCCL, works with several processes on one GPU."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 1, 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if transport == "host":
+        tr = TorchHostTransport(group)
+        engine.comm_init_host(world, rank, tr.table)
+        engine._comm_transport = tr          # callbacks live as long as the engine
+        return world, rank
+    if transport != "rccl":
+        raise ValueError("transport must be 'rccl' or 'host'")
     uid = [engine.comm_unique_id() if rank == 0 else None]
     if dist.get_backend(group) == "nccl":
         t = torch.tensor(list(uid[0]) if rank == 0 else [0] * 128, dtype=torch.uint8,
@@ -39,118 +117,27 @@ def init_comm(engine, group=None, device=None):
     return world, rank
 
 
+# ------------------------------------------------------------------------------------ the partitions
 def block_cyclic_rows(m, world, rank, block_rows=4096):
-    """Row ranges [(start, stop), ...] of `rank` under plda_score_matrix_sharded_dev's partition: block b of
-    `block_rows` rows (rounded up to 256) belongs to rank b mod world; the rows left after the last full
-    round of `world` blocks are dealt out once more in `world` equal smaller blocks."""
-    block = -(-int(block_rows if block_rows > 0 else 4096) // 256) * 256
-    sup = block * world
-    nfull = m // sup
-    out = [(s * sup + rank * block, s * sup + (rank + 1) * block) for s in range(nfull)]
-    rem = m - nfull * sup
-    if rem:
-        tb = -(-(-(-rem // world)) // 256) * 256
-        a = nfull * sup + rank * tb
-        if a < m:
-            out.append((a, min(m, a + tb)))
-    return out
+    """Row ranges [(start, stop), ...] of `rank` under the library's partition of the trials matrix
+    (plda_shard_plan, csrc/comm.hip): block b of `block_rows` rows (rounded up to 256) belongs to rank
+    b mod world; the rows left after the last full round are dealt out once more in `world` equal smaller
+    blocks.  Their order is the row order of the rank's compact slab."""
+    from .libplda import MPlda
+    return MPlda.shard_plan(m, world, rank, block_rows)
+
+
+def local_row_index(m, world, rank, block_rows=4096, device=None):
+    """int64 tensor of the global row numbers of this rank's compact slab, in slab order."""
+    parts = [torch.arange(a, b, dtype=torch.int64, device=device) for a, b in block_cyclic_rows(m, world, rank, block_rows)]
+    return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=device)
 
 
 def shard_rows(m, world, rank):
-    """Contiguous balanced partition of m rows: (start, stop) for `rank`."""
+    """Contiguous balanced partition of m items (the z-norm models): (start, stop) for `rank`."""
     base, extra = divmod(int(m), int(world))
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
-
-
-def padded_shard(m, world):
-    """Rows per rank when every rank's slab is padded to the same size (for all-gather)."""
-    return (int(m) + world - 1) // world
-
-
-def score_matrix_sharded(score_block, U_local, n_local, V, m_global, gather=False, slab_rows=8192,
-                         group=None, out_local=None):
-    """Score this rank's rows; optionally all-gather the full matrix.
-
-    U_local [m_local, D], n_local [m_local] int32 (or None), V [Nt, D] -- tensors on this
-    rank's device.  Returns (scores_local [m_local, Nt] float32, gathered or None); with
-    gather=True `gathered` is [M, Nt] on every rank (rows in global order).
-    """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    start, stop = shard_rows(m_global, world, rank)
-    m_local = stop - start
-    assert U_local.shape[0] == m_local, "U_local must hold exactly this rank's rows"
-    nt = V.shape[0]
-    dev = U_local.device
-    if out_local is None:
-        out_local = torch.empty((m_local, nt), dtype=torch.float32, device=dev)
-    if not gather or world == 1:
-        for r0 in range(0, m_local, slab_rows):
-            r1 = min(m_local, r0 + slab_rows)
-            out_local[r0:r1] = score_block(U_local[r0:r1], None if n_local is None else n_local[r0:r1], V)
-        return out_local, (out_local if gather else None)
-
-    # ---- gather: equal padded slabs, all_gather_into_tensor slab by slab, overlapped ----
-    m_pad = padded_shard(m_global, world)
-    gathered = torch.empty((world, m_pad, nt), dtype=torch.float32, device=dev)
-    use_streams = dev.type == "cuda"
-    side = torch.cuda.Stream(device=dev) if use_streams else None
-    for r0 in range(0, m_pad, slab_rows):
-        r1 = min(m_pad, r0 + slab_rows)
-        send = torch.zeros((r1 - r0, nt), dtype=torch.float32, device=dev)
-        v1 = min(r1, m_local)
-        if v1 > r0:
-            blk = score_block(U_local[r0:v1], None if n_local is None else n_local[r0:v1], V)
-            send[: v1 - r0] = blk
-            out_local[r0:v1] = blk
-        recv = torch.empty((world, r1 - r0, nt), dtype=torch.float32, device=dev)
-        if use_streams:
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-                gathered[:, r0:r1] = recv
-            send.record_stream(side)
-            recv.record_stream(side)
-        else:
-            parts = [torch.empty_like(send) for _ in range(world)]
-            dist.all_gather(parts, send, group=group)
-            for w, p in enumerate(parts):
-                gathered[w, r0:r1] = p
-    if use_streams:
-        torch.cuda.current_stream(dev).wait_stream(side)
-    # drop the padding rows and restore global order
-    rows = []
-    for w in range(world):
-        s, e = shard_rows(m_global, world, w)
-        rows.append(gathered[w, : e - s])
-    return out_local, torch.cat(rows, dim=0)
-
-
-def znorm_stats_sharded(znorm_block, models_local, m_global, group=None):
-    """z-norm statistics sharded by MODEL: every rank holds the whole cohort
-    and computes (mean, std) for its contiguous slab of models with `znorm_block(models) ->
-    (mean[m], std[m])`; the only collective is an all-gather of the padded [M/R, 2] results
-    (a few hundred KB at C5).  Returns (mean[M], std[M]) on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    start, stop = shard_rows(m_global, world, rank)
-    assert models_local.shape[0] == stop - start, "models_local must hold exactly this rank's models"
-    mean, std = znorm_block(models_local)
-    if world == 1:
-        return mean, std
-    m_pad = padded_shard(m_global, world)
-    send = torch.zeros((m_pad, 2), dtype=torch.float64, device=mean.device)
-    send[: stop - start, 0] = mean
-    send[: stop - start, 1] = std
-    parts = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(parts, send, group=group)
-    rows = []
-    for w in range(world):
-        s0, e0 = shard_rows(m_global, world, w)
-        rows.append(parts[w][: e0 - s0])
-    full = torch.cat(rows, dim=0)
-    return full[:, 0].contiguous(), full[:, 1].contiguous()
 
 
 def speaker_shard(labels, world, rank):
@@ -160,150 +147,67 @@ def speaker_shard(labels, world, rank):
     return (labels.to(torch.int64) % int(world)) == int(rank)
 
 
-def fit_sharded(stats_block, em_block, X_local, labels_local, iters=10, group=None):
-    """PLDA fit with the statistics pass sharded by speaker.
+# ------------------------------------------------------------------------------------ tensor wrappers
+def _on_torch_stream(engine, dev):
+    if dev.type == "cuda":
+        engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)   # same stream as the torch ops around the call
 
-    Every rank holds the rows of a disjoint set of speakers (`speaker_shard`).  Per rank:
-    `stats_block(X_local, dense_labels, K_local) -> (means[K_local, D], counts[K_local] int64,
-    scatter[D, D])` is the AddSamples pass (pldamodule.cpp:94-98) over its speakers.  Everything
-    AddSamples accumulates is additive over speakers, so the one exchange is an all-reduce of the
-    D x D offset scatter plus an all-gather of the centroids and counts (K*D*8 bytes: 8 MB at C2,
-    41 MB at C3); the EM (pldamodule.cpp:102-106) is D x D work and runs as a replica on every rank
-    from identical inputs: `em_block(means[K, D], counts[K], scatter, iters)`.
-    Returns the global number of speakers.  A rank may own no speaker at all (K_local = 0).
-    """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+def score_matrix_sharded(engine, U, n, V, n_uniform=0, gather=False, block_rows=4096, zmean=None, zstd=None):
+    """Row-sharded trials matrix on REPLICATED HBM-resident inputs (U [M, D], V [Nt, D] fp64 tensors; n int32 [M]
+    or None with n_uniform): returns (local [m_local, Nt] float32 -- this rank's blocks back to back --, rows
+    int64 [m_local] = their global row numbers, full [M, Nt] on every rank or None)."""
+    dev = U.device
+    _on_torch_stream(engine, dev)
+    world, rank = engine.comm_info()
+    m, nt = U.shape[0], V.shape[0]
+    rows = local_row_index(m, world, rank, block_rows, device=dev)
+    buf = torch.empty((max(rows.numel(), 1), nt), dtype=torch.float32, device=dev)   # (a rank may own no row)
+    local = buf[:rows.numel()]
+    full = torch.empty((m, nt), dtype=torch.float32, device=dev) if gather else None
+    engine.score_matrix_sharded_local_dev(
+        U.data_ptr(), n.data_ptr() if n is not None else None, n_uniform, m, V.data_ptr(), nt,
+        buf.data_ptr(), nt, block_rows,
+        dfull=full.data_ptr() if gather else None, ld_full=nt,
+        dzmean=zmean.data_ptr() if zmean is not None else None, dzstd=zstd.data_ptr() if zstd is not None else None)
+    return local, rows, full
+
+
+def znorm_stats_sharded(engine, bkg, models, num_examples=0):
+    """MPlda_norm sharded by MODEL: every rank scans the whole cohort `bkg` [Nb, Din] for its slab of the
+    replicated `models` [M, Dout]; (mean[M], std[M]) on every rank."""
+    dev = models.device
+    _on_torch_stream(engine, dev)
+    m = models.shape[0]
+    mean = torch.empty(m, dtype=torch.float64, device=dev)
+    std = torch.empty(m, dtype=torch.float64, device=dev)
+    engine.znorm_stats_sharded_dev(bkg.data_ptr(), bkg.shape[0], num_examples, bkg.shape[1], models.data_ptr(), m,
+                                   mean.data_ptr(), std.data_ptr())
+    return mean, std
+
+
+def fit_sharded(engine, X_local, labels_local, iters=10):
+    """PLDA fit with the statistics pass over THIS rank's speakers (`speaker_shard`): labels are compacted to
+    the local dense 0..K-1 on the device, plda_fit_sharded_dev does the rest (all-reduce of the scatter,
+    all-gather of centroids and counts in rank order, replica EM).  Every rank must own at least one speaker."""
     dev = X_local.device
-    d = X_local.shape[1]
-    labels_local = torch.as_tensor(labels_local)
-    if labels_local.numel():
-        _, dense = torch.unique(labels_local.to(torch.int64), sorted=True, return_inverse=True)
-        k_local = int(dense.max().item()) + 1
-        means, counts, scatter = stats_block(X_local, dense.to(dev), k_local)
-    else:
-        k_local = 0
-        means = torch.zeros((0, d), dtype=torch.float64, device=dev)
-        counts = torch.zeros((0,), dtype=torch.int64, device=dev)
-        scatter = torch.zeros((d, d), dtype=torch.float64, device=dev)
-    if world > 1:
-        ks = torch.tensor([k_local], dtype=torch.int64, device=dev)
-        all_k = [torch.empty_like(ks) for _ in range(world)]
-        dist.all_gather(all_k, ks, group=group)
-        all_k = [int(t.item()) for t in all_k]
-        k_pad = max(max(all_k), 1)
-        send_m = torch.zeros((k_pad, d), dtype=torch.float64, device=dev)
-        send_c = torch.zeros((k_pad,), dtype=torch.int64, device=dev)
-        send_m[:k_local] = means
-        send_c[:k_local] = counts
-        parts_m = [torch.empty_like(send_m) for _ in range(world)]
-        parts_c = [torch.empty_like(send_c) for _ in range(world)]
-        dist.all_gather(parts_m, send_m, group=group)
-        dist.all_gather(parts_c, send_c, group=group)
-        scatter = scatter.contiguous()
-        dist.all_reduce(scatter, op=dist.ReduceOp.SUM, group=group)
-        means = torch.cat([p[:k] for p, k in zip(parts_m, all_k)], dim=0).contiguous()
-        counts = torch.cat([p[:k] for p, k in zip(parts_c, all_k)], dim=0).contiguous()
-    k_global = int(means.shape[0])
-    em_block(means, counts, scatter, int(iters))
-    return k_global
+    _on_torch_stream(engine, dev)
+    X_local = X_local.contiguous()
+    _, dense = torch.unique(torch.as_tensor(labels_local).to(dev).to(torch.int64), sorted=True, return_inverse=True)
+    dense = dense.contiguous()
+    k_local = int(dense.max().item()) + 1
+    engine.fit_sharded_dev(X_local.data_ptr(), X_local.shape[0], X_local.shape[1], dense.data_ptr(), k_local, iters)
+    return k_local
 
 
-def gpu_fit_blocks(engine):
-    """(stats_block, em_block) over MPlda.fit_stats_dev / fit_em_dev for HBM-resident tensors."""
-    if torch.cuda.is_available():
-        engine.set_stream(torch.cuda.current_stream().cuda_stream)   # same stream as the torch ops around them
-
-    def stats_block(X, dense, k):
-        X = X.contiguous()
-        lab = dense.to(torch.int64).contiguous()     # non-negative: same bits as the u64 the ABI reads
-        n, d = X.shape
-        means = torch.empty((k, d), dtype=torch.float64, device=X.device)
-        counts = torch.empty((k,), dtype=torch.int64, device=X.device)
-        scatter = torch.empty((d, d), dtype=torch.float64, device=X.device)
-        engine.fit_stats_dev(X.data_ptr(), n, d, lab.data_ptr(), k)
-        engine.fit_get_stats_dev(means.data_ptr(), counts.data_ptr(), scatter.data_ptr())
-        return means, counts, scatter
-
-    def em_block(means, counts, scatter, iters):
-        engine.fit_em_dev(means.data_ptr(), counts.data_ptr(), means.shape[0], scatter.data_ptr(),
-                          means.shape[1], iters)
-    return stats_block, em_block
-
-
-def eer_sharded(engine, scores_local, enrol_spk_local, test_spk, group=None):
+def eer_sharded(engine, scores_local, enrol_spk_local, test_spk):
     """Equal error rate of a ROW-SHARDED trials matrix without gathering it: every rank histograms its own
-    slab (`scores_local` [m_local, Nt] float32 on its GPU, speaker ids of its enrol rows, all test speaker
-    ids), and the counts are summed over the ranks between the three passes -- 3 x 32 KiB + 8 bytes of
-    traffic for any number of trials.  Returns the 6-vector (threshold, FAR, FRR, EER, #targets,
-    #impostors), identical on every rank and identical to the single-GPU result on the assembled matrix.
-    A rank may own no row (m_local = 0)."""
-    import ctypes as C
-    import numpy as np
-    from . import _native as N
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    on_gpu = world > 1 and dist.get_backend(group) == "nccl"
-    dev = scores_local.device
-
-    def allreduce(t, op):
-        if world == 1:
-            return t
-        if on_gpu:
-            g = t.to(dev)
-            dist.all_reduce(g, op=op, group=group)
-            return g.cpu()
-        dist.all_reduce(t, op=op, group=group)
-        return t
-
-    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.POINTER(C.c_uint))
-
-    def reduce(ctx, hist, below, above):
-        try:
-            if hist:
-                a = np.ctypeslib.as_array(hist, shape=(4096,))
-                t = allreduce(torch.from_numpy(a.view(np.int64).copy()), dist.ReduceOp.SUM)
-                a[:] = t.numpy().view(np.uint64)
-            else:
-                below[0] = int(allreduce(torch.tensor([below[0]], dtype=torch.int64), dist.ReduceOp.MAX)[0])
-                above[0] = int(allreduce(torch.tensor([above[0]], dtype=torch.int64), dist.ReduceOp.MIN)[0])
-            return 0
-        except Exception:       # never let an exception cross the C boundary
-            return 1
-
-    cb = CB(reduce)
-    if scores_local.is_cuda:
-        engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)   # the slab was produced on torch's stream
-    m, nt = scores_local.shape
-    out = np.zeros(6)
+    compact slab (`scores_local` [m_local, Nt] float32, int64 speaker ids of ITS rows, all test speaker ids);
+    the counters are summed over the ranks by the handle's collectives between the three passes (3 x 32 KiB +
+    8 bytes for any number of trials).  Identical 6-vector on every rank; a rank may own no row."""
+    dev = test_spk.device
+    _on_torch_stream(engine, dev)
     scores_local = scores_local.contiguous()
-    N.check(engine._h, engine._lib.plda_eer_matrix_sharded_dev(
-        engine._h, C.c_void_p(scores_local.data_ptr() if m else 0), nt, m, nt,
-        C.c_void_p(enrol_spk_local.data_ptr() if m else 0), C.c_void_p(test_spk.data_ptr()), C.cast(cb, C.c_void_p),
-        None, C.c_void_p(out.ctypes.data)))
-    return out
-
-
-def gpu_znorm_block(engine, dbkg, nb, din):
-    """znorm_block over MPlda.znorm_stats_dev: cohort `dbkg` [nb, din] fp64 tensor resident on this GPU."""
-    if dbkg.is_cuda:
-        engine.set_stream(torch.cuda.current_stream(dbkg.device).cuda_stream)   # same stream as the torch ops around it
-
-    def fn(models):
-        m = models.shape[0]
-        mean = torch.empty(m, dtype=torch.float64, device=models.device)
-        std = torch.empty(m, dtype=torch.float64, device=models.device)
-        engine.znorm_stats_dev(dbkg.data_ptr(), nb, 0, din, models.data_ptr(), m, mean.data_ptr(), std.data_ptr())
-        return mean, std
-    return fn
-
-
-def gpu_score_block(engine, n_uniform=0):
-    """score_block over MPlda.score_matrix_dev for HBM-resident fp64 tensors."""
-    import torch as _t
-    engine.set_stream(_t.cuda.current_stream().cuda_stream)   # 0 = HIP's default stream, honoured as such
-
-    def fn(U, n, V):
-        out = torch.empty((U.shape[0], V.shape[0]), dtype=torch.float32, device=U.device)
-        engine.score_matrix_dev(U.data_ptr(), n.data_ptr() if n is not None else None, n_uniform, U.shape[0],
-                                V.data_ptr(), V.shape[0], out.data_ptr(), V.shape[0])
-        return out
-    return fn
+    m, nt = scores_local.shape
+    return engine.eer_matrix_comm_dev(scores_local.data_ptr() if m else 0, nt, m, nt,
+                                      enrol_spk_local.data_ptr() if m else 0, test_spk.data_ptr())

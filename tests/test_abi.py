@@ -30,7 +30,7 @@ def test_ctypes_table_matches_header():
     from plda_amd import _native
     assert sorted(_native.SIGNATURES) == _declared()
     lib = _native.load()
-    assert lib.plda_abi_version() == 1
+    assert lib.plda_abi_version() == 2
 
 
 def test_header_cites_reference_interfaces():

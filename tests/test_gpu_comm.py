@@ -1,9 +1,9 @@
 """GPU: the library's own multi-GPU entry points (include/plda_hip.h, csrc/comm.hip) on the one GPU of the
-test box.  plda_comm_emulate lets a handle play rank r of R without a communicator, so every rank's shard
-can be produced in turn and checked to tile the single-call result exactly; a real RCCL communicator is
-exercised at world size 1 (unique id -> comm_init -> sharded call with gather -> destroy).  The RCCL
-collectives across ranks can only run on the driver's multi-GPU node; the index arithmetic they use (in-place
-all-gather of R consecutive blocks) is what the emulation pins down."""
+test box, in ONE process.  plda_comm_emulate lets a handle play rank r of R without a communicator, so every
+rank's shard can be produced in turn and checked to tile the single-call result exactly; a real RCCL
+communicator is exercised at world size 1 (unique id -> comm_init -> sharded call with gather -> destroy).
+The collectives themselves run between processes in tests/test_gpu_comm_procs.py (host transport; RCCL
+refuses two ranks on one device, its cross-rank run is the driver's multi-GPU bench)."""
 import numpy as np
 import pytest
 
@@ -51,6 +51,14 @@ def test_block_cyclic_shards_tile_the_matrix(world, block, mixed):
         assert np.array_equal(rows, want)                       # exactly this rank's blocks, nothing else
         covered += rows
         out[torch.from_numpy(rows).to(dev)] = mine[torch.from_numpy(rows).to(dev)]
+        # the same blocks back to back in a compact slab (plda_score_matrix_sharded_local_dev)
+        nloc = int(rows.sum())
+        slab = torch.full((nloc + 1, nt), float("nan"), dtype=torch.float32, device=dev)
+        eng.score_matrix_sharded_local_dev(dU.data_ptr(), n.data_ptr() if mixed else None, 0 if mixed else 3, m,
+                                           dV.data_ptr(), nt, slab.data_ptr(), nt, block_rows=block)
+        torch.cuda.synchronize()
+        assert torch.equal(slab[:nloc], full[torch.from_numpy(rows).to(dev)])
+        assert torch.isnan(slab[nloc]).all()                      # nothing written past the slab
     eng.comm_emulate(1, 0)
     assert (covered == 1).all()                                  # every row scored by exactly one rank
     assert torch.equal(out, full)                                # and bit-identical to the single call
@@ -68,6 +76,8 @@ def test_real_communicator_world_1():
     assert len(uid) == 128
     eng.comm_init(1, 0, uid)
     assert eng.comm_info() == (1, 0)
+    desc = eng.comm_describe()
+    assert desc["transport"] == "rccl" and desc["nranks"] == 1 and desc["rank"] == 0 and desc["rccl_version"] > 0
     dU = torch.from_numpy(rng.standard_normal((m, d))).to(dev)
     dV = torch.from_numpy(rng.standard_normal((nt, d))).to(dev)
     a = torch.empty((m, nt), dtype=torch.float32, device=dev)
@@ -93,7 +103,7 @@ def test_real_communicator_world_1():
     torch.cuda.synchronize()
     assert torch.allclose(za, zb, rtol=1e-6, atol=0)
     eng.comm_destroy()
-    assert eng.comm_info() == (1, 0)
+    assert eng.comm_info() == (1, 0) and eng.comm_describe()["transport"] == "none"
 
 
 @pytest.mark.parametrize("world", [2, 4])

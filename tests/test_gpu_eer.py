@@ -104,7 +104,7 @@ def _eer_rank(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from plda_amd import MPlda, eer
-    from plda_amd.sharding import eer_sharded, shard_rows
+    from plda_amd.sharding import eer_sharded, init_comm, shard_rows
     dev = torch.device("cuda", 0)                      # both ranks share the one GPU of the test box
     rng = np.random.default_rng(17)                    # same data on every rank
     m, nt = 301, 997
@@ -114,13 +114,14 @@ def _eer_rank(rank, world, port, q):
     spans = [shard_rows(m, 2, 0), shard_rows(m, 2, 1), (m, m)] if world == 3 else [shard_rows(m, world, r) for r in range(world)]
     a, b = spans[rank]
     eng = MPlda(0)
+    init_comm(eng, transport="host")                   # the library's collectives over this gloo group (RCCL needs one GPU per rank)
     S = torch.from_numpy(sc[a:b].copy()).to(dev)
     e_l = torch.from_numpy(es[a:b].copy()).to(dev)
     t_all = torch.from_numpy(ts).to(dev)
     out = eer_sharded(eng, S, e_l, t_all)
     full = torch.from_numpy(sc).to(dev)
     e_all = torch.from_numpy(es).to(dev)
-    ref = eer.eer_from_matrix_dev(eng, full.data_ptr(), nt, m, nt, e_all.data_ptr(), t_all.data_ptr())
+    ref = eer.eer_from_matrix_dev(MPlda(0), full.data_ptr(), nt, m, nt, e_all.data_ptr(), t_all.data_ptr())
     q.put((rank, bool(np.array_equal(out, ref)), out.tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -128,8 +129,8 @@ def _eer_rank(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_eer_of_a_row_sharded_matrix(world):
-    """EER over row slabs held by different ranks (gloo group, all ranks on this box's GPU): counts are
-    reduced between the histogram passes, nothing is gathered; the result equals the one-GPU EER of
+    """EER over row slabs held by different ranks (plda_eer_matrix_comm_dev; the handle's collectives travel over a
+    gloo group, all ranks on this box's GPU): counts are reduced between the histogram passes, nothing is gathered; the result equals the one-GPU EER of
     the assembled matrix on every rank, also when a rank owns no row."""
     import multiprocessing as mp
     import os

@@ -223,18 +223,33 @@ def test_maximum_feature_dim_is_reported():
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_fit_sharded_by_speaker_matches_single_fit(oracle, world):
     """SURVEY.md section 8e "fit statistics": per-shard plda_fit_stats_dev, summed scatter + concatenated centroids,
-    then plda_fit_em_dev must equal the one-call fit.  The shards run one after another on this
-    GPU through plda_amd.sharding.fit_sharded's own blocks (the collective step is emulated by
-    the sum/concat it performs; the gloo world-2 test covers the real exchange)."""
+    then plda_fit_em_dev must equal the one-call fit.  The shards run one after another on this GPU through the
+    C ABI's two halves of the fit; the exchange itself (plda_fit_sharded_dev's all-reduce / all-gather) runs between
+    processes in tests/test_gpu_comm_procs.py."""
     import torch
     from plda_amd import MPlda
-    from plda_amd.sharding import gpu_fit_blocks, speaker_shard
+    from plda_amd.sharding import speaker_shard
     x, y = make_data(31, 2600, 48, 37, skew=True, scale_between=0.4)
     dev = torch.device("cuda:0")
     dx = torch.from_numpy(x).to(dev)
     ty = torch.from_numpy(y.astype(np.int64))
     eng = MPlda(0)
-    stats_block, em_block = gpu_fit_blocks(eng)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def stats_block(X, dense, k):
+        X = X.contiguous()
+        lab = dense.to(torch.int64).contiguous()     # non-negative: same bits as the u64 the ABI reads
+        n, d = X.shape
+        m_ = torch.empty((k, d), dtype=torch.float64, device=dev)
+        c_ = torch.empty((k,), dtype=torch.int64, device=dev)
+        s_ = torch.empty((d, d), dtype=torch.float64, device=dev)
+        eng.fit_stats_dev(X.data_ptr(), n, d, lab.data_ptr(), k)
+        eng.fit_get_stats_dev(m_.data_ptr(), c_.data_ptr(), s_.data_ptr())
+        return m_, c_, s_
+
+    def em_block(means, counts, scatter, iters):
+        eng.fit_em_dev(means.data_ptr(), counts.data_ptr(), means.shape[0], scatter.data_ptr(), means.shape[1], iters)
+
     means, counts, scatter = [], [], torch.zeros((48, 48), dtype=torch.float64, device=dev)
     for r in range(world):
         mask = speaker_shard(ty, world, r)

@@ -174,10 +174,11 @@ def test_trial_list_scoring_matches_per_call_score(engine, oracle):
 
 
 def test_sharded_scorer_on_device_tensors(engine, oracle):
-    """plda_amd.sharding on HBM-resident tensors (world size 1 here; the 2-rank logic is
-    covered by the gloo test): row slabs through MPlda.score_matrix_dev reproduce the oracle."""
+    """plda_amd.sharding's tensor wrapper of plda_score_matrix_sharded_local_dev (world size 1 here; several ranks:
+    tests/test_gpu_comm.py by emulation, tests/test_gpu_comm_procs.py between processes): the compact slab is the
+    whole matrix, the row map the identity, and gather=True assembles the same matrix once more."""
     import torch
-    from plda_amd.sharding import gpu_score_block, score_matrix_sharded
+    from plda_amd.sharding import score_matrix_sharded
     d = 40
     m, x, y = _model(oracle, 19, 800, d, 25, scale_between=0.4)
     _load(engine, m)
@@ -186,12 +187,11 @@ def test_sharded_scorer_on_device_tensors(engine, oracle):
     U = np.stack([oracle.transform_ivector(m, r, c) for r, c in zip(rng.random((150, d)), counts)])
     V = np.stack([oracle.transform_ivector(m, r, 1) for r in rng.random((90, d))])
     dev = torch.device("cuda", 0)
-    loc, full = score_matrix_sharded(gpu_score_block(engine), torch.from_numpy(U).to(dev),
-                                     torch.from_numpy(counts).to(dev), torch.from_numpy(V).to(dev), 150,
-                                     gather=True, slab_rows=64)
+    loc, rows, full = score_matrix_sharded(engine, torch.from_numpy(U).to(dev), torch.from_numpy(counts).to(dev),
+                                           torch.from_numpy(V).to(dev), gather=True, block_rows=64)
     torch.cuda.synchronize()
     ref = oracle.score_block(m["psi"], U, counts, V)
-    assert full is loc and loc.shape == (150, 90)
+    assert loc.shape == (150, 90) and rows.tolist() == list(range(150)) and torch.equal(full, loc)
     assert (np.abs(loc.cpu().numpy() - ref) <= score_tol(ref)).all()
     engine.set_stream(None)
 

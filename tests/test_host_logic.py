@@ -1,6 +1,6 @@
-"""CPU: host-side logic of the shim (argument checks mirror pldamodule.cpp's
-ValueErrors) and the row-sharding path on a 2-process gloo group with the oracle as
-the per-slab scorer."""
+"""CPU: host-side logic of the shim (argument checks mirror pldamodule.cpp's ValueErrors), the row
+partition of the trials matrix (plda_shard_plan through the C ABI) and the host transport of the
+library's collectives on a 2-process gloo group."""
 import os
 import sys
 
@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 from plda_amd import libplda
-from plda_amd.sharding import padded_shard, shard_rows
+from plda_amd.sharding import shard_rows
 
 
 def test_feature_and_label_checks():
@@ -40,151 +40,96 @@ def test_shard_rows_partition(m, world):
     for (a, b), (c, d) in zip(spans, spans[1:]):
         assert b == c and b >= a and d >= c
     sizes = [b - a for a, b in spans]
-    assert max(sizes) - min(sizes) <= 1 and max(sizes) == padded_shard(m, world)
+    assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, gather, q):
+# ---- the HOST transport of the library's collectives (plda_host_collectives over gloo), world size 2 on CPU.
+#      On the GPU box the very same callbacks carry csrc/comm.hip's collectives between processes
+#      (tests/test_gpu_comm_procs.py); here they are driven directly on host buffers. ----
+def _transport_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import binding as ob
-    from plda_amd.sharding import score_matrix_sharded, shard_rows as sr
-    rng = np.random.default_rng(0)            # same data on every rank
-    d, m, nt = 12, 37, 23
-    psi = np.sort(rng.random(d) * 3)[::-1].copy()
-    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
-    counts = rng.integers(1, 5, m).astype(np.int32)
-    a, b = sr(m, world, rank)
-
-    def block(Ub, nb, Vb):
-        return torch.from_numpy(ob.score_block(psi, Ub.numpy(), nb.numpy(), Vb.numpy()).astype(np.float32))
-
-    loc, full = score_matrix_sharded(block, torch.from_numpy(U[a:b]), torch.from_numpy(counts[a:b]),
-                                     torch.from_numpy(V), m, gather=gather, slab_rows=8)
-    ref = ob.score_block(psi, U, counts, V).astype(np.float32)
-    ok = np.array_equal(loc.numpy(), ref[a:b])
-    if gather:
-        ok = ok and full is not None and np.array_equal(full.numpy(), ref)
-    else:
-        ok = ok and full is None
-    q.put((rank, bool(ok)))
+    import ctypes as C
+    from plda_amd import _native as N
+    from plda_amd.libplda import MPlda
+    from plda_amd.sharding import TorchHostTransport
+    tr = TorchHostTransport()
+    t = tr.table
+    ok = {}
+    # ragged all-gather in place: rank q owns bytes [offs[q], offs[q] + counts[q]) of the same buffer
+    for name, counts in [("ragged", [1000, 37]), ("empty_piece", [0, 513]), ("equal", [256, 256]), ("big", [3 << 20, (3 << 20) + 5])]:
+        offs = [64, 64 + counts[0] + 11]                       # pieces need not be adjacent
+        total = offs[1] + counts[1]
+        want = np.zeros(total, np.uint8)
+        for r in range(world):
+            want[offs[r]:offs[r] + counts[r]] = (np.arange(counts[r]) * (r + 3) + r) % 251
+        buf = np.zeros(total, np.uint8)
+        buf[offs[rank]:offs[rank] + counts[rank]] = want[offs[rank]:offs[rank] + counts[rank]]
+        o, c = (C.c_int64 * world)(*offs), (C.c_int64 * world)(*counts)
+        rc = t.all_gather_v(None, buf.ctypes.data, o, c)
+        ok["agv_" + name] = rc == 0 and np.array_equal(buf, want)
+    # reductions: f64 sum, u64 sum (the EER histograms), u32 max / min (its bracket)
+    a = np.arange(1000, dtype=np.float64) * (rank + 1)
+    ok["sum_f64"] = t.all_reduce(None, a.ctypes.data, a.size, N.PLDA_DT_F64, N.PLDA_OP_SUM) == 0 and \
+        np.array_equal(a, np.arange(1000, dtype=np.float64) * 3)
+    u = (np.arange(4096, dtype=np.uint64) << np.uint64(40)) + np.uint64(rank)
+    ok["sum_u64"] = t.all_reduce(None, u.ctypes.data, u.size, N.PLDA_DT_U64, N.PLDA_OP_SUM) == 0 and \
+        np.array_equal(u, (np.arange(4096, dtype=np.uint64) << np.uint64(41)) + np.uint64(1))
+    w = np.array([7 + 100 * rank, 4000000000 - rank], np.uint32)
+    lo, hi = w.copy(), w.copy()
+    ok["max_u32"] = t.all_reduce(None, hi.ctypes.data, 2, N.PLDA_DT_U32, N.PLDA_OP_MAX) == 0 and hi.tolist() == [107, 4000000000]
+    ok["min_u32"] = t.all_reduce(None, lo.ctypes.data, 2, N.PLDA_DT_U32, N.PLDA_OP_MIN) == 0 and lo.tolist() == [7, 3999999999]
+    # a failing callback reports 1 and keeps the exception; nothing propagates into the C caller
+    ok["bad_dtype"] = t.all_reduce(None, a.ctypes.data, 4, 99, N.PLDA_OP_SUM) == 1 and isinstance(tr.last_error, ValueError)
+    # the partition each rank computes for itself (plda_shard_plan through the C ABI) tiles the rows
+    plans = [None] * world
+    dist.all_gather_object(plans, MPlda.shard_plan(2900, world, rank, 256))
+    cover = np.zeros(2900, np.int32)
+    for pl in plans:
+        for x, y in pl:
+            cover[x:y] += 1
+    ok["plans_tile"] = bool((cover == 1).all())
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _znorm_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import binding as ob
-    from conftest import make_data
-    from plda_amd.sharding import shard_rows as sr, znorm_stats_sharded
-    x, y = make_data(61, 400, 10, 20, scale_between=0.5)
-    model = ob.fit(x, y, 3)
-    _, _, models = ob.transform_groups(model, x[:95], np.arange(95, dtype=np.uint64))   # 95 models: uneven slabs
-    bkg = x[200:260]
-    a, b = sr(95, world, rank)
-
-    def block(mods):
-        m, s = ob.norm(model, bkg, mods.numpy())
-        return torch.from_numpy(m), torch.from_numpy(s)
-
-    mean, std = znorm_stats_sharded(block, torch.from_numpy(models[a:b]), 95)
-    rm, rs = ob.norm(model, bkg, models)
-    q.put((rank, bool(np.array_equal(mean.numpy(), rm) and np.array_equal(std.numpy(), rs))))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def _fit_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import plda_oracle_np as onp
-    from conftest import make_data
-    from plda_amd.sharding import fit_sharded, speaker_shard
-    x, y = make_data(71, 300, 8, 13, scale_between=0.7)      # 13 speakers, unequal counts, uneven split
-    mask = speaker_shard(torch.from_numpy(y.astype(np.int64)), world, rank).numpy()
-    got = {}
-
-    def stats_block(X, dense, k):
-        st = onp.stats(X.numpy(), dense.numpy())
-        assert st["means"].shape[0] == k
-        return (torch.from_numpy(st["means"]), torch.from_numpy(st["counts"].astype(np.int64)),
-                torch.from_numpy(st["scatter"]))
-
-    def em_block(means, counts, scatter, iters):
-        means, counts = means.numpy(), counts.numpy()
-        w = 1.0 / counts
-        st = dict(means=means, counts=counts, scatter=scatter.numpy(), sum=(means * w[:, None]).sum(0),
-                  class_weight=w.sum(), example_weight=float(len(counts)))
-        d = means.shape[1]
-        W, B = np.eye(d), np.eye(d)
-        for _ in range(iters):
-            W, B = onp.em_iter(st, W, B)
-        got.update(onp.get_output(st, W, B))
-
-    k = fit_sharded(stats_block, em_block, torch.from_numpy(x[mask]), torch.from_numpy(y[mask].astype(np.int64)), iters=4)
-    ref = onp.fit(x, y, 4)
-    T, R = got["transform"], ref["transform"]
-    ok = (k == 13 and np.allclose(got["psi"], ref["psi"], rtol=1e-10, atol=1e-12)
-          and np.allclose(T.T @ T, R.T @ R, rtol=1e-9, atol=1e-11) and np.allclose(got["mean"], ref["mean"], atol=1e-13))
-    q.put((rank, bool(ok)))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_sharded_fit_gloo_world2(oracle):
-    """fit statistics sharded by speaker: all-reduce of the scatter + all-gather of the centroids, then the
-    replica EM, must reproduce the single-process fit on every rank."""
+def test_host_transport_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+    for rank, ok in res:
+        assert all(ok.values()), (rank, ok)
 
 
-def test_sharded_znorm_gloo_world2(oracle):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_znorm_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
-
-
-@pytest.mark.parametrize("gather", [False, True])
-def test_sharded_trials_matrix_gloo_world2(oracle, gather):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (1 if gather else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, gather, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+def test_shard_plan_capacity_and_arguments():
+    """plda_shard_plan is a pure function of the library (no handle, no GPU)."""
+    import ctypes as C
+    from plda_amd import _native as N
+    lib = N.load()
+    nb, rows = C.c_int64(), C.c_int64()
+    assert lib.plda_shard_plan(100000, 8, 3, 4096, None, None, 0, C.byref(nb), C.byref(rows)) == N.PLDA_OK
+    assert nb.value == 4 and rows.value == 3 * 4096 + 256          # 3 full rounds + a 1696-row tail in blocks of 256
+    st, ct = np.zeros(2, np.int64), np.zeros(2, np.int64)
+    assert lib.plda_shard_plan(100000, 8, 3, 4096, st.ctypes.data, ct.ctypes.data, 2, C.byref(nb), C.byref(rows)) == N.PLDA_E_CAPACITY
+    assert st.tolist() == [3 * 4096, 8 * 4096 + 3 * 4096] and ct.tolist() == [4096, 4096]
+    assert lib.plda_shard_plan(10, 0, 0, 256, None, None, 0, None, None) == N.PLDA_E_INVAL
+    assert lib.plda_shard_plan(10, 2, 2, 256, None, None, 0, None, None) == N.PLDA_E_INVAL
+    assert lib.plda_shard_plan(0, 2, 1, 256, None, None, 0, C.byref(nb), C.byref(rows)) == N.PLDA_OK and nb.value == 0
 
 
 def test_block_cyclic_rows_tile_exactly():
-    """The Python mirror of plda_score_matrix_sharded_dev's partition (csrc/comm.hip): every row belongs to exactly
-    one rank, blocks are multiples of 256 rows, the remainder is dealt out in equal smaller blocks."""
+    """plda_score_matrix_sharded_dev's partition (csrc/comm.hip, read through plda_shard_plan): every row belongs to
+    exactly one rank, blocks are multiples of 256 rows, the remainder is dealt out in equal smaller blocks."""
     from plda_amd.sharding import block_cyclic_rows
     for m, world, block in [(1, 1, 256), (5, 4, 256), (2900, 2, 256), (2900, 3, 512), (2900, 8, 256),
                             (100000, 8, 4096), (100000, 2, 4096), (40000, 8, 4096), (40000, 4, 0), (4096 * 8, 8, 4096)]:
