@@ -10,17 +10,21 @@ GetOutput on the GPU (fp64); a "step" = one pass of the hot path over one batch 
 fp64 -> fp32 operand packing, fp32-MFMA GEMM, 40 GB of fp32 scores written to HBM.  Inputs are
 HBM-resident before the timed region; scores stay in HBM.
 
-N > 1 (one process per GPU, torchrun): STRONG scaling of the same trials matrix.  Every rank holds
-the replicated model, enrol and test sets and calls the library's own sharded entry point
-`plda_score_matrix_sharded_dev` (RCCL inside libplda_hip.so; torch.distributed only carries the
-128-byte unique id, the model broadcast and the timing reduction): enrol rows are dealt out
-block-cyclically and every rank writes its blocks in place into the full matrix.
+N > 1 (one process per GPU, torchrun): WEAK scaling by default -- the trials matrix grows with the job: N x 100k
+enrol models against the same 100k tests, so every GPU scores as many trials per step as the single GPU does
+(`--scaling strong` keeps the 100k x 100k matrix and splits it instead).  Every rank holds the replicated model,
+enrol and test sets and calls the library's own sharded entry point `plda_score_matrix_sharded_local_dev`
+(csrc/comm.hip; torch.distributed only carries the 128-byte unique id, the model broadcast and the timing
+reduction): enrol rows are dealt out block-cyclically and every rank writes its blocks back to back into a
+compact slab of M/N rows.
   value            = trials/s with the scores left row-sharded (no data-path collective: what
                      thresholding, counting, EER and z-norm consume);
-  gather_inclusive = the same K steps with every block all-gathered in place over xGMI, on a side
+  gather_inclusive = K steps of the 100k x 100k matrix with every block all-gathered in place over xGMI, on a side
                      stream, overlapped with the scoring of the following blocks (north_star's
                      "RCCL all-gather to assemble scores"): its volume -- (N-1)/N of 40 GB into every
-                     rank -- not the GEMM bounds it, which is why it is reported beside `value`.
+                     rank -- not the GEMM bounds it, which is why it is reported beside `value`;
+  multi_gpu        = who took part, as the TRANSPORT reports it (ncclCommCount / UserRank / CuDevice + PCI bus id of
+                     every rank) and a cross-rank checksum of gathered row blocks against their owners' copies.
 --config C3 / C4 run the other BASELINE shapes (C3: 10k models (n = 100) x 1M tests at D = 512;
 C4: 40k models (n in 1..5) x 1.2M tests at D = 256, 192 GB of scores) through the same code.
 """
@@ -79,16 +83,61 @@ def cpu_best_effort(D, psi, side=12000):
             "sample": "%dx%d trials, fp64 GEMM form (oracle/plda_oracle_np.py), %.1f s" % (side, side, dt)}
 
 
-def cpu_em_baseline(X, y, seconds_cap=60.0):
+def cpu_em_baseline(X, y, gpu_one_iter=None):
     """One Kaldi-style EM iteration (per-class loop, explicit inversions) of the oracle on
-    the SAME C2 statistics, single thread."""
+    the SAME C2 statistics, single thread; its W, B are also the checker of the GPU's first
+    iteration (`gpu_one_iter` = the engine's means / scatter / W / B after a 1-iteration fit)."""
     from oracle import binding as ob
     st = ob.stats(X, y)
     D = X.shape[1]
     t0 = time.perf_counter()
-    ob.em_iter(st, np.eye(D), np.eye(D))
+    W, B = ob.em_iter(st, np.eye(D), np.eye(D))
     dt = time.perf_counter() - t0
-    return {"em_iters_per_s": 1.0 / dt, "sample": "1 EM iteration at N=%d D=%d K=%d, %.1f s" % (X.shape[0], D, int(y.max()) + 1, dt)}
+    res = {"em_iters_per_s": 1.0 / dt, "sample": "1 EM iteration at N=%d D=%d K=%d, %.1f s" % (X.shape[0], D, int(y.max()) + 1, dt)}
+    if gpu_one_iter is not None:
+        rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())    # noqa: E731
+        res["gpu_vs_oracle_after_one_iteration"] = {
+            "counts_equal": bool(np.array_equal(gpu_one_iter["counts"], st["counts"])),
+            "means_rel_err": rel(gpu_one_iter["means"], st["means"]), "scatter_rel_err": rel(gpu_one_iter["scatter"], st["scatter"]),
+            "W_rel_err": rel(gpu_one_iter["W"], W), "B_rel_err": rel(gpu_one_iter["B"], B)}
+    return res
+
+
+def end_to_end(eng, X, y, D, dout):
+    """The reference user's view (SURVEY.md section 8d "also report end-to-end incl. H2D"): NumPy arrays in, NumPy
+    arrays out through the drop-in API -- pageable host memory on both sides, PCIe inclusive.  Never `value`."""
+    rng = np.random.default_rng(99)
+    res = {}
+    side = 20000
+    E, T = rng.random((side, D)), rng.random((side, D))
+    U, V = eng.transform_array(E, 1), eng.transform_array(T, 1)
+    eng.score_matrix((1, U), (1, V), znorm=False)                   # warm: pinned ring, copy threads, code
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter(); S = eng.score_matrix((1, U), (1, V), znorm=False); best = min(best, time.perf_counter() - t0)
+    res["score_matrix"] = {"shape": [side, side], "ms": round(best * 1e3, 2), "trials_per_s": side * side / best,
+                           "bytes_to_host": side * side * 4, "d2h_GBps": round(side * side * 4 / best / 1e9, 1),
+                           "how": "plda_score_matrix on NumPy arrays, fresh float32 output per call (page faults included): "
+                                  "GEMM of slab i+1 | DMA of slab i into a pinned ring | host threads land slab i-1"}
+    del S
+    if X is not None:
+        yy = y.astype(np.uint64)
+        eng.fit(X, yy, 10)
+        t0 = time.perf_counter(); eng.fit(X, yy, 10); dt = time.perf_counter() - t0
+        res["fit"] = {"rows": int(X.shape[0]), "ms": round(dt * 1e3, 2), "h2d_bytes": int(X.nbytes),
+                      "how": "liblda-style fit(X, y, 10) on NumPy arrays: np.unique label compaction on the host, upload through the pinned ring, statistics + EM + GetOutput"}
+        t0 = time.perf_counter(); tr = eng.transform(X, yy); dt = time.perf_counter() - t0
+        res["transform"] = {"rows": int(X.shape[0]), "labels": len(tr), "ms": round(dt * 1e3, 2),
+                            "how": "transform(X, y) -> dict {label: (n, vec)} built without a per-key Python round trip"}
+        ks = list(tr)[:64]
+        t0 = time.perf_counter()
+        for _ in range(40):
+            for k in ks:
+                eng.score(k, tr[k], tr[ks[0]])
+        dt = (time.perf_counter() - t0) / (40 * len(ks))
+        res["score_call"] = {"us_per_call": round(dt * 1e6, 2),
+                             "how": "plda.score(id, (n, u), (n, v)) from Python: one LLR on the handle's host mirror of psi (plda_score_one)"}
+    return res
 
 
 def latest_traffic(M, Nt, dout):
@@ -118,16 +167,24 @@ def main():
     ap.add_argument("--speakers", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--targetdim", type=int, default=0, help="build extension: keep the top-psi dims (0 = all)")
-    ap.add_argument("--block-rows", type=int, default=4096, help="N>1: rows per block of the block-cyclic row partition")
+    ap.add_argument("--block-rows", type=int, default=0,
+                    help="N>1: rows per block of the block-cyclic row partition of the sharded leg (0 = one block per rank: "
+                         "ceil(M / N) rounded up to 256); the gather leg always uses 4096-row blocks (overlap granularity)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the targetdim-150 extra measurement (profiling runs: every launch of the trials kernel "
                          "is then the timed workload)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = N x the enrol rows (per-GPU work fixed, the default); strong = the same matrix split N ways")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the gather-inclusive second timed region")
     ap.add_argument("--shard-fit", action="store_true",
                     help="N>1: shard the fit statistics by speaker through plda_fit_sharded_dev (all-reduce of the "
                          "scatter + all-gather of the centroids over RCCL, replica EM) instead of rank-0 fit + broadcast")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the control plane (nccl = RCCL)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="collectives of the library's sharded entry points: rccl (xGMI; one GPU per rank) or host (pinned "
+                         "staging + the torch.distributed group, e.g. --backend gloo: lets N ranks share ONE GPU -- a check of "
+                         "this script's N > 1 path on a single-GPU box, not a measurement)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="logic check on ONE GPU: play R ranks in turn through plda_comm_emulate (no collective, no gather "
                          "timing); the printed rate is not a multi-GPU measurement")
@@ -142,6 +199,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     emu = args.emulate_ranks if world == 1 else 0
+    if emu:
+        args.scaling = "strong"        # the emulation is a logic check of the partition on one GPU's memory
+    if args.transport == "host":
+        local_rank = local_rank % torch.cuda.device_count()     # ranks may share a GPU under the host transport
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -159,7 +220,7 @@ def main():
     eng.set_stream(stream.cuda_stream)
     if world > 1:
         from plda_amd.sharding import init_comm
-        init_comm(eng, device=dev)          # RCCL communicator inside libplda_hip.so
+        init_comm(eng, device=dev, transport=args.transport)   # RCCL communicator inside libplda_hip.so (or the host transport)
 
     cfg = dict(CONFIGS[args.config])
     if args.n:
@@ -169,6 +230,10 @@ def main():
     if args.speakers:
         cfg["K"] = args.speakers
     N, D, K, M, Nt = cfg["N"], cfg["D"], cfg["K"], cfg["M"], cfg["Nt"]
+    parts = (args.emulate_ranks if world == 1 else world) or 1
+    M1 = M                                            # enrol rows of the single-GPU problem (the gather leg's matrix)
+    if args.scaling == "weak" and parts > 1:
+        M = M1 * parts                                # weak scaling: every rank scores M1 x Nt trials per step
 
     # ---- synthetic fit data: uniform [0,1) rows (the reference's usage, README.md:54), N / K utterances per speaker.
     #      C2: np.random.default_rng(2) on the host (as round 1); the larger shapes draw on the device ----
@@ -187,6 +252,7 @@ def main():
 
     # ---- fit: rank 0 + broadcast of the model, or sharded by speaker over the library's RCCL communicator ----
     fit_info = None
+    gpu_one_iter = None
     if args.shard_fit and world > 1:
         dX, dy = fit_rows()
         mine = (dy % world) == rank                      # a partition BY SPEAKER: every centroid is rank-local
@@ -208,6 +274,10 @@ def main():
     elif rank == 0:
         dX, dy = fit_rows()
         torch.cuda.synchronize(dev)
+        if X is not None and not args.no_cpu:
+            eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, 1)         # one EM iteration: checked against the oracle's below
+            torch.cuda.synchronize(dev)
+            gpu_one_iter = eng.fit_internals()
         eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)   # warm (allocations, code load)
         t0 = time.perf_counter()
         eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)
@@ -262,7 +332,7 @@ def main():
     else:
         dn = None
         n_uniform = int(cfg["counts"])
-    if args.config == "C2":
+    if args.config == "C2" and M == M1:
         dE = torch.from_numpy(np.random.default_rng(1000).random((M, D))).to(dev)
         dVr = torch.from_numpy(np.random.default_rng(7).random((Nt, D))).to(dev)
     else:
@@ -273,9 +343,17 @@ def main():
     eng.transform_rows_dev(dE.data_ptr(), M, D, dn.data_ptr() if dn is not None else None, n_uniform, dU.data_ptr())
     eng.transform_rows_dev(dVr.data_ptr(), Nt, D, None, 1, dT.data_ptr())
     del dE, dVr
-    out = torch.empty((M, Nt), dtype=torch.float32, device=dev)
+    from plda_amd.sharding import block_cyclic_rows
+    gather_block = 4096
+    if args.block_rows <= 0:
+        args.block_rows = -(-(-(-M // parts)) // 256) * 256 if parts > 1 else 4096
+    my_blocks = block_cyclic_rows(M, parts, rank if world > 1 else 0, args.block_rows)   # (emulation: rank 0's, for the shape)
+    local_rows = sum(b - a for a, b in my_blocks) if world > 1 else M
+    # N > 1: a compact slab of this rank's rows; the full matrix exists only in the gather leg (M1 rows)
+    out = torch.empty((max(local_rows, 1) if world > 1 else M, Nt), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     dnp = dn.data_ptr() if dn is not None else None
+    full = None
 
     def step(gather=False):
         if emu:
@@ -286,9 +364,12 @@ def main():
             eng.comm_emulate(1, 0)
         elif world == 1:
             eng.score_matrix_dev(dU.data_ptr(), dnp, n_uniform, M, dT.data_ptr(), Nt, out.data_ptr(), Nt)
+        elif gather:
+            eng.score_matrix_sharded_dev(dU.data_ptr(), dnp, n_uniform, M1, dT.data_ptr(), Nt, full.data_ptr(), Nt,
+                                         block_rows=gather_block, gather=True)
         else:
-            eng.score_matrix_sharded_dev(dU.data_ptr(), dnp, n_uniform, M, dT.data_ptr(), Nt, out.data_ptr(), Nt,
-                                         block_rows=args.block_rows, gather=gather)
+            eng.score_matrix_sharded_local_dev(dU.data_ptr(), dnp, n_uniform, M, dT.data_ptr(), Nt, out.data_ptr(), Nt,
+                                               block_rows=args.block_rows)
 
     def timed(gather):
         for _ in range(args.warmup):
@@ -317,33 +398,80 @@ def main():
 
     elapsed, (gemm_ms, launches, gemm_flop) = timed(False)
 
-    # ---- spot parity check of the timed output against the fp64 trial-list kernel (rows of THIS rank's blocks) ----
-    from plda_amd.sharding import block_cyclic_rows
-    mine = block_cyclic_rows(M, emu or world, (emu - 1) if emu else rank, args.block_rows) if (world > 1 or emu) else [(0, M)]
-    rows = sorted({mine[0][0], mine[0][1] - 1, mine[-1][0], mine[-1][1] - 1})
-    sel_e = torch.tensor(rows, device=dev)
-    sel_t = torch.tensor([0, 5, Nt // 3, Nt - 1], device=dev)
+    # ---- parity of the TIMED output: a 64 x 64 sample (rows of THIS rank's blocks, block boundaries included) against
+    #      the fp64 oracle's per-trial LLR (oracle/plda_oracle.c) and against the engine's own fp64 trial-list kernel ----
+    from plda_amd.sharding import local_row_index
+    if world > 1:
+        grow = local_row_index(M, world, rank, args.block_rows, device=dev)       # global row of every slab row
+    elif emu:
+        grow = torch.arange(M, device=dev)
+    else:
+        grow = torch.arange(M, device=dev)
+    nloc = int(grow.numel())
+    pick = torch.unique(torch.cat([torch.tensor([0, nloc - 1], device=dev),
+                                   torch.linspace(0, nloc - 1, 62, device=dev).long()]))[:64]
+    sel_t = torch.unique(torch.cat([torch.tensor([0, 5, Nt - 1], device=dev), torch.linspace(0, Nt - 1, 61, device=dev).long()]))[:64]
+    sel_e = grow[pick]
     Uh, Th = dU[sel_e].cpu().numpy(), dT[sel_t].cpu().numpy()
-    nh = dn[sel_e].cpu().numpy() if dn is not None else np.full(len(rows), n_uniform, np.int32)
-    got = out[sel_e][:, sel_t].cpu().numpy()
-    ref = eng.score_trials((nh, Uh), (1, Th), np.repeat(np.arange(len(rows)), 4), np.tile(np.arange(4), len(rows))).reshape(len(rows), 4)
+    nh = dn[sel_e].cpu().numpy() if dn is not None else np.full(len(sel_e), n_uniform, np.int32)
+    got = (out[pick] if world > 1 else out[sel_e])[:, sel_t].cpu().numpy().astype(np.float64)
+    ne, nt_ = got.shape
+    ref = eng.score_trials((nh, Uh), (1, Th), np.repeat(np.arange(ne), nt_), np.tile(np.arange(nt_), ne)).reshape(ne, nt_)
     spot = float(np.abs(got - ref).max())
+    oracle_check = None
+    if not args.no_cpu:
+        try:
+            from oracle import binding as ob
+            ob.build()
+            oref = ob.score_block(psi[:dout], Uh, nh, Th)
+            tol = 1e-4 * np.maximum(np.abs(oref), np.abs(oref).mean())       # north_star: 1e-4 relative
+            oracle_check = {"sample": "%d x %d trials of the timed output (this rank's rows)" % (ne, nt_),
+                            "max_abs_err": float(np.abs(got - oref).max()), "max_err_over_tol": float((np.abs(got - oref) / tol).max()),
+                            "within_1e-4": bool((np.abs(got - oref) <= tol).all()),
+                            "trial_list_kernel_vs_oracle_max_abs": float(np.abs(ref - oref).max()),
+                            "oracle": "oracle/plda_oracle.c per-trial LogLikelihoodRatio, fp64"}
+        except Exception as e:   # noqa: BLE001
+            oracle_check = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world > 1:                                   # every rank's sample must pass, not only rank 0's
+        bad = torch.tensor([0.0 if (oracle_check is None or oracle_check.get("within_1e-4", False)) else 1.0, spot],
+                           dtype=torch.float64, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        spot = float(bad[1].item())
+        if oracle_check is not None and "within_1e-4" in oracle_check:
+            oracle_check["within_1e-4_on_every_rank"] = bool(bad[0].item() == 0.0)
 
+    # ---- who took part (as the transport reports it), and the gather-inclusive leg on the single-GPU matrix ----
+    multi = None
     gather_info = None
+    if world > 1:
+        descs = [None] * world
+        dist.all_gather_object(descs, eng.comm_describe())
+        multi = {"transport": descs[0]["transport"], "rccl_nranks": descs[0]["nranks"], "rccl_version": descs[0].get("rccl_version"),
+                 "ranks": [{"rank": d_["rank"], "device": d_["device"], "pci_bus_id": d_["pci_bus_id"]} for d_ in descs],
+                 "distinct_devices": len({d_["pci_bus_id"] for d_ in descs}),
+                 "scores_per_rank_GB": round(out.numel() * 4 / 1e9, 2)}
     if world > 1 and not args.no_gather:
         try:   # the second leg must not cost the run its (already measured) main line
+            full = torch.empty((M1, Nt), dtype=torch.float32, device=dev)
             el_g, _ = timed(True)
-            # after a gathered step every rank holds every row: check one row of another rank's block
-            other = block_cyclic_rows(M, world, (rank + 1) % world, args.block_rows)[0][0]
-            g2 = out[other, sel_t].cpu().numpy()
-            r2 = eng.score_trials((nh[:1] if dn is None else dn[other:other + 1].cpu().numpy(), dU[other:other + 1].cpu().numpy()),
-                                  (1, Th), np.zeros(4, np.int64), np.arange(4))
-            gather_info = {"value": float(M) * Nt * args.steps / el_g, "unit": "trials/s", "ms_per_step": el_g / args.steps * 1e3,
-                           "bytes_received_per_rank_per_step": int(M * Nt * 4 * (world - 1) / world),
-                           "ingest_GBps_per_rank": round(M * Nt * 4 * (world - 1) / world / (el_g / args.steps) / 1e9, 1),
-                           "peer_row_max_abs_err": float(np.abs(g2 - r2).max()),
-                           "how": "plda_score_matrix_sharded_dev(gather=1): in-place ncclAllGather of every %d x %d-row super-block on a "
-                                  "side stream, overlapped with the scoring of the next one" % (world, args.block_rows)}
+            # after a gathered step every rank holds every row: bit patterns of the first block of every OTHER rank, as
+            # this rank received them, against the owner's own copy
+            def cks(a, b):
+                return int(full[a:b].view(torch.int32).to(torch.int64).sum().item())
+            firsts = [block_cyclic_rows(M1, world, r, gather_block)[0] for r in range(world)]
+            seen = [None] * world
+            dist.all_gather_object(seen, [cks(a, b) for a, b in firsts])
+            agree = all(seen[r][q] == seen[q][q] for r in range(world) for q in range(world))
+            gather_info = {"value": float(M1) * Nt * args.steps / el_g, "unit": "trials/s", "ms_per_step": el_g / args.steps * 1e3,
+                           "matrix": "%d x %d (the single-GPU problem, assembled on every rank)" % (M1, Nt),
+                           "bytes_received_per_rank_per_step": int(M1 * Nt * 4 * (world - 1) / world),
+                           "ingest_GBps_per_rank": round(M1 * Nt * 4 * (world - 1) / world / (el_g / args.steps) / 1e9, 1),
+                           "gathered_blocks_bit_identical_to_their_owners": bool(agree),
+                           "how": "plda_score_matrix_sharded_dev(gather=1): in-place all-gather of every %d x %d-row super-block on a "
+                                  "side stream, overlapped with the scoring of the next one" % (world, gather_block)}
+            if multi is not None:
+                multi["cross_rank_checksum_ok"] = bool(agree)
+            full = None
         except Exception as e:   # noqa: BLE001
             gather_info = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -417,27 +545,32 @@ def main():
 
     if rank == 0:
         gemm_k = (2 if dn is not None else 1) * dout            # algorithmic GEMM depth: D (uniform n) or 2 D (mixed n)
-        trials = float(M) * Nt * args.steps                      # whole job: the matrix is the same at every N
+        trials = float(M) * Nt * args.steps                      # whole job (weak scaling: M = N x the single-GPU rows)
         value = trials / elapsed
         avg_gemm_s = gemm_ms / 1e3 / max(launches, 1)
         achieved = (gemm_flop / max(launches, 1)) / avg_gemm_s / 1e12 if avg_gemm_s > 0 else 0.0
         res = {
             "metric": "PLDA LLR trials/sec", "value": value, "unit": "trials/s",
             "n_gpus": world, **({"emulated_ranks_on_one_gpu": emu} if emu else {}), "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if (world > 1 or emu) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s; fit %d EM iters; D_eff=%d" % (cfg["what"], args.iters, dout),
-                       "trials_per_step": M * Nt, "parallelism": "enrol rows block-cyclic over %d rank(s), scores left sharded" % world,
+                       "trials_per_step": M * Nt, "enrol_models": M, "test_vectors": Nt,
+                       "parallelism": "enrol rows block-cyclic over %d rank(s) (%s scaling: %d enrol models in all), scores left sharded in compact slabs"
+                                      % (world, args.scaling, M) if world > 1 else "one GPU",
                        "score_dtype": "f32 (fp64 bias terms, fp32 MFMA contraction)", "fit_dtype": "f64"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": M * Nt * 4,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": int(gemm_flop / max(launches, 1) / (2 * gemm_k) * 4),
                          "kernel": "trials_gemm_bt2_kernel (rank 0's launches)",
                          "flop_per_trial": 2 * gemm_k, "avg_kernel_ms": round(avg_gemm_s * 1e3, 4),
                          "launches": launches,
                          "hbm_write_GBps": round(gemm_flop / max(launches, 1) / (2 * gemm_k) * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None},
-            "fit": fit_info, "spot_check_max_abs_err": spot,
+            "fit": fit_info, "spot_check_max_abs_err": spot, "oracle_check": oracle_check,
         }
+        if multi:
+            res["multi_gpu"] = multi
         if td:
             res["targetdim150"] = td
         if zn:
@@ -454,10 +587,18 @@ def main():
                 cb["best_effort"] = {"error": str(e)}
             if X is not None:
                 try:
-                    cb["fit_em"] = cpu_em_baseline(X, y)
+                    cb["fit_em"] = cpu_em_baseline(X, y, gpu_one_iter)
                 except Exception as e:  # the EM leg is informative only
                     cb["fit_em"] = {"error": str(e)}
             res["cpu_baseline"] = cb
+        if world == 1 and not emu and not args.no_extra and not args.targetdim:
+            try:
+                if td:
+                    eng.set_model(packed[:D], packed[D:D + D * D].reshape(D, D), psi)    # (the targetdim leg truncated it)
+                del out
+                res["end_to_end"] = end_to_end(eng, X, y, D, dout)
+            except Exception as e:   # noqa: BLE001 -- informative leg
+                res["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         eng.comm_destroy()

@@ -135,6 +135,13 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
                      const double *V, int64_t Nt, const int64_t *e_idx,
                      const int64_t *t_idx, int64_t P, const double *zmean,
                      const double *zstd, double *out);
+/* ONE trial, evaluated on the host: plda.score() (pldamodule.cpp:258-277) is one LogLikelihoodRatio (:266) per
+ * Python call, i.e. 2 D numbers and ~5 D flop -- a GPU launch + synchronisation costs ten times that, so the scalar
+ * call is served from the handle's host mirror of psi (fp64, per-count terms cached; the library's own code, no
+ * oracle).  u, v: already-transformed vectors [Dout]; has_z != 0 applies (s - zmean) / zstd where zstd != 0 (:269-273).
+ * Batches belong on plda_score_pairs / plda_score_matrix. */
+int plda_score_one(plda_handle *h, const double *u, int32_t n_enrol, const double *v, int32_t has_z,
+                   double zmean, double zstd, double *out);
 /* Dense trials matrix out[i*ld_out + j] = LLR(U[i], n[i], V[j]) for the M x Nt
  * block (the nested Python loop of scoring/scorePLDA.py:302-318 and
  * tests/pldatest.py:29-33 as one launch): fp64 bias terms + fp32 MFMA GEMM,

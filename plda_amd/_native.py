@@ -60,6 +60,7 @@ SIGNATURES = {
     "plda_transform_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "plda_transform_rows_dev": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "plda_score_pairs": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "plda_score_one": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _f64, _f64, C.POINTER(_f64)]),
     "plda_score_matrix": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
     "plda_score_matrix_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
     "plda_profile_enable": (C.c_int, [_vp, _i32]),

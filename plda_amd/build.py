@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libplda_hip.so")
-SOURCES = ["api.hip", "score.hip", "linalg.hip", "fit.hip", "frontend.hip", "eer.hip", "lda.hip", "comm.hip", "eig_dc.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "plda_hip.h")]
+SOURCES = ["api.hip", "score.hip", "linalg.hip", "fit.hip", "frontend.hip", "eer.hip", "lda.hip", "comm.hip", "eig_dc.hip", "hostio.hip"]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "hostio.hpp"), os.path.join(HERE, "..", "include", "plda_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc compilation failed")
     if force or procs or _stale(SO, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]   # librccl is opened lazily by plda_comm_init (csrc/comm.hip)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl", "-lpthread"]   # librccl is opened lazily by plda_comm_init (csrc/comm.hip)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

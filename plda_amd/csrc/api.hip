@@ -2,11 +2,13 @@
 // Host-pointer entry points stage through device buffers owned by the handle and
 // call the *_device implementations; nothing here computes on the CPU.
 #include "common.hpp"
+#include "hostio.hpp"
 
 #include <mutex>
 
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -81,9 +83,47 @@ int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const
 int eer_matrix_comm_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
                            const int64_t *dtspk, double *out);
 
+// the pinned ring + copy threads of the host-pointer entry points (hostio.hip), created on first use
+static int host_pipe(plda_handle *h, HostPipe **out) {
+  if (!h->hostpipe) {
+    h->hostpipe = new HostPipe(default_host_threads());
+  }
+  PLDA_HIP(h, h->hostpipe->init());
+  *out = h->hostpipe;
+  return PLDA_OK;
+}
+
+// caller (pageable) memory -> a fresh device temporary; large arrays travel through the pinned ring
 static int upload(plda_handle *h, Tmp &t, const void *src, size_t bytes) {
   PLDA_HIP(h, t.alloc(bytes));
-  if (bytes) PLDA_HIP(h, hipMemcpyAsync(t.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+  if (!bytes) return PLDA_OK;
+  if (bytes >= ((size_t)4 << 20) && h->host_variant == 0) {
+    HostPipe *hp = nullptr;
+    PLDA_TRY(host_pipe(h, &hp));
+    PLDA_HIP(h, hp->upload(h->stream, t.p, src, bytes));
+    return PLDA_OK;
+  }
+  PLDA_HIP(h, hipMemcpyAsync(t.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return PLDA_OK;
+}
+
+// device -> caller (pageable) memory, contiguous; synchronises the stream
+static int download(plda_handle *h, void *dst, const void *dsrc, size_t bytes) {
+  if (bytes >= ((size_t)4 << 20) && h->host_variant == 0) {
+    HostPipe *hp = nullptr;
+    PLDA_TRY(host_pipe(h, &hp));
+    advise_huge(dst, bytes);
+    size_t i = 0;
+    for (size_t off = 0; off < bytes; off += HostPipe::SLOT_BYTES, ++i) {
+      const size_t n = std::min(HostPipe::SLOT_BYTES, bytes - off);
+      const hipError_t e = hp->ship_slab(h->stream, i, static_cast<const char *>(dsrc) + off, n, static_cast<char *>(dst) + off, n, n, 1);
+      if (e != hipSuccess) { (void)hp->finish(); return hip_fail(h, e, "ship_slab", __FILE__, __LINE__); }
+    }
+    PLDA_HIP(h, hp->finish());
+    return PLDA_OK;
+  }
+  PLDA_HIP(h, hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
   return PLDA_OK;
 }
 
@@ -164,6 +204,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_TRANSFORM_VARIANT")) h->transform_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_ZNORM_VARIANT")) h->znorm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
+    if (const char *v = std::getenv("PLDA_HOST_VARIANT")) h->host_variant = std::atoi(v);
     *out = h;
     return PLDA_OK;
   });
@@ -182,10 +223,12 @@ int plda_destroy(plda_handle *h) {
     }
     for (auto &sp : h->trace_spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
     (void)comm_destroy(h);
+    delete h->hostpipe;
+    h->hostpipe = nullptr;
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
-                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small};
+                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1]};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->w) b.release();
     if (h->one_host) (void)hipHostFree(h->one_host);
@@ -398,6 +441,7 @@ int plda_set_model(plda_handle *h, int32_t Dout, int32_t Din, const double *mean
     h->h_offset.assign(Dout, 0.0);
     PLDA_TRY(model_to_device(h));
     h->fitted = true;
+    ++h->model_epoch;
     return refresh_offset(h);
   });
 }
@@ -413,6 +457,7 @@ int plda_truncate(plda_handle *h, int32_t targetdim) {
     h->h_transform.resize((size_t)targetdim * h->Din);
     h->h_psi.resize(targetdim);
     h->h_offset.resize(targetdim);
+    ++h->model_epoch;
     return PLDA_OK;  // device arrays are row-major prefixes: nothing to move
   });
 }
@@ -428,6 +473,7 @@ int plda_smooth(plda_handle *h, double factor) {
     PLDA_LAUNCH_CHECK(h);
     PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, (size_t)h->Dout * h->Din * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+    ++h->model_epoch;
     return refresh_offset(h);
   });
 }
@@ -459,9 +505,7 @@ int plda_transform_rows(plda_handle *h, const double *Xbar, int64_t R, int32_t D
     if (num_examples) PLDA_TRY(upload(h, dN, num_examples, (size_t)R * 4));
     PLDA_HIP(h, dO.alloc((size_t)R * h->Dout * 8));
     PLDA_TRY(transform_rows_device(h, dX.as<double>(), R, Din, num_examples ? dN.as<int32_t>() : nullptr, n_uniform, dO.as<double>()));
-    PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)R * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    return PLDA_OK;
+    return download(h, out, dO.p, (size_t)R * h->Dout * 8);
   });
 }
 
@@ -530,7 +574,7 @@ int plda_transform_groups(plda_handle *h, const double *X, int64_t N, int32_t Di
     std::vector<int32_t> c32((size_t)G);
     PLDA_HIP(h, hipMemcpyAsync(c32.data(), dC.p, (size_t)G * 4, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipMemcpyAsync(out_labels, dU.p, (size_t)G * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(out_vecs, dO.p, (size_t)G * h->Dout * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_TRY(download(h, out_vecs, dO.p, (size_t)G * h->Dout * 8));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
     for (int64_t g = 0; g < G; ++g) out_counts[g] = c32[g];
     *Ku = G;
@@ -550,6 +594,49 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
   });
 }
 
+// the round-1/2 form of the host-pointer trials matrix: one slab buffer, the runtime's pageable copy, a
+// synchronisation per slab.  Kept as the A/B arm (PLDA_HOST_VARIANT=1) and for test sets so wide that a
+// single row of scores does not fit a slot of the pinned ring.
+static int score_matrix_host_serial(plda_handle *h, const double *U, const int32_t *n_enrol, int32_t n_uniform, int64_t M,
+                                    const double *V, int64_t Nt, const double *zmean, const double *zstd, float *out,
+                                    int64_t ld_out) {
+  const int D = h->Dout;
+  Tmp dV, dU, dN, dZm, dZs, dO;
+  PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
+  // row slabs so that the device score block stays <= 1 GiB
+  int64_t slab = std::max<int64_t>(128, ((1ll << 30) / 4 / Nt) / 128 * 128);
+  slab = std::min(slab, round_up(M, 128));
+  PLDA_HIP(h, dU.alloc((size_t)slab * D * 8));
+  PLDA_HIP(h, dO.alloc((size_t)slab * Nt * 4));
+  if (n_enrol) PLDA_HIP(h, dN.alloc((size_t)slab * 4));
+  if (zmean && zstd) { PLDA_HIP(h, dZm.alloc((size_t)slab * 8)); PLDA_HIP(h, dZs.alloc((size_t)slab * 8)); }
+  for (int64_t r0 = 0; r0 < M; r0 += slab) {
+    const int64_t m = std::min(slab, M - r0);
+    PLDA_HIP(h, hipMemcpyAsync(dU.p, U + r0 * D, (size_t)m * D * 8, hipMemcpyHostToDevice, h->stream));
+    if (n_enrol) PLDA_HIP(h, hipMemcpyAsync(dN.p, n_enrol + r0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    if (zmean && zstd) {
+      PLDA_HIP(h, hipMemcpyAsync(dZm.p, zmean + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+      PLDA_HIP(h, hipMemcpyAsync(dZs.p, zstd + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
+                                 dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
+                                 (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt,
+                                 /*reuse_packed_B=*/r0 > 0));   // the test side is packed once, not per slab
+    if (ld_out == Nt)
+      PLDA_HIP(h, hipMemcpyAsync(out + r0 * ld_out, dO.p, (size_t)m * Nt * 4, hipMemcpyDeviceToHost, h->stream));
+    else
+      PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
+                                   (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  return PLDA_OK;
+}
+
+// Host-pointer trials matrix.  What bounds it is PCIe, not the GEMM (1.4 TB/s of scores against <= 64 GB/s of
+// link): slabs of <= 64 MiB of scores alternate between two device buffers; while the GEMM of slab i + 1 runs,
+// slab i crosses the link into a pinned slot on the copy stream and slab i - 1 is copied from its slot into the
+// caller's array by the host threads, which also take the page faults of a freshly allocated output in
+// parallel (hostio.hip).  Enrol vectors, counts and z-norm maps are uploaded once, not per slab.
 int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, int32_t n_uniform, int64_t M,
                       const double *V, int64_t Nt, const double *zmean, const double *zstd, float *out,
                       int64_t ld_out) {
@@ -559,41 +646,47 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
     if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
     if (M <= 0 || Nt <= 0) return PLDA_OK;
     if (!U || !V || !out || ld_out < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
+    if (!n_enrol && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix: n_uniform must be > 0 when n_enrol is NULL");
     PLDA_TRY(set_device(h));
     const int D = h->Dout;
-    Tmp dV, dU, dN, dZm, dZs, dO;
-    PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
-    // row slabs so that the device score block stays <= 1 GiB
-    int64_t slab = std::max<int64_t>(128, ((1ll << 30) / 4 / Nt) / 128 * 128);
-    slab = std::min(slab, round_up(M, 128));
-    PLDA_HIP(h, dU.alloc((size_t)slab * D * 8));
-    PLDA_HIP(h, dO.alloc((size_t)slab * Nt * 4));
-    if (n_enrol) PLDA_HIP(h, dN.alloc((size_t)slab * 4));
-    if (zmean && zstd) { PLDA_HIP(h, dZm.alloc((size_t)slab * 8)); PLDA_HIP(h, dZs.alloc((size_t)slab * 8)); }
-    for (int64_t r0 = 0; r0 < M; r0 += slab) {
-      const int64_t m = std::min(slab, M - r0);
-      PLDA_HIP(h, hipMemcpyAsync(dU.p, U + r0 * D, (size_t)m * D * 8, hipMemcpyHostToDevice, h->stream));
-      if (n_enrol) PLDA_HIP(h, hipMemcpyAsync(dN.p, n_enrol + r0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
-      if (zmean && zstd) {
-        PLDA_HIP(h, hipMemcpyAsync(dZm.p, zmean + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
-        PLDA_HIP(h, hipMemcpyAsync(dZs.p, zstd + r0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
-      }
-      PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
-                                   dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
-                                   (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt,
-                                   /*reuse_packed_B=*/r0 > 0));   // the test side is packed once, not per slab
-      // a contiguous slab goes out as one linear copy.  (What bounds this entry point is the first touch of the
-      // caller's freshly allocated pageable output: 28 GB/s against 52 GB/s into touched pages,
-      // scripts/probe/pcie_probe.hip; 4.1e9 trials/s end to end at 20k x 20k.)
-      if (ld_out == Nt)
-        PLDA_HIP(h, hipMemcpyAsync(out + r0 * ld_out, dO.p, (size_t)m * Nt * 4, hipMemcpyDeviceToHost, h->stream));
-      else
-        PLDA_HIP(h, hipMemcpy2DAsync(out + r0 * ld_out, (size_t)ld_out * 4, dO.p, (size_t)Nt * 4, (size_t)Nt * 4,
-                                     (size_t)m, hipMemcpyDeviceToHost, h->stream));
-      PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    }
+    const bool zn = zmean && zstd;
     h->last_M = M;
-    return PLDA_OK;
+    const int64_t fit_rows = (int64_t)(HostPipe::SLOT_BYTES / 4) / Nt;      // rows of scores per pinned slot
+    if (h->host_variant == 1 || fit_rows < 1 || (size_t)M * D * 8 > ((size_t)2 << 30)) {
+      const int rc = score_matrix_host_serial(h, U, n_enrol, n_uniform, M, V, Nt, zmean, zstd, out, ld_out);
+      h->last_M = M;
+      return rc;
+    }
+    HostPipe *hp = nullptr;
+    PLDA_TRY(host_pipe(h, &hp));
+    const int64_t slab = fit_rows >= 256 ? fit_rows / 128 * 128 : fit_rows;
+    Tmp dV, dU, dN, dZm, dZs;
+    PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
+    PLDA_TRY(upload(h, dU, U, (size_t)M * D * 8));
+    if (n_enrol) PLDA_TRY(upload(h, dN, n_enrol, (size_t)M * 4));
+    if (zn) { PLDA_TRY(upload(h, dZm, zmean, (size_t)M * 8)); PLDA_TRY(upload(h, dZs, zstd, (size_t)M * 8)); }
+    for (auto &b : h->hio_O) PLDA_HIP(h, b.reserve((size_t)std::min(slab, M) * Nt * 4));
+    advise_huge(out, (size_t)((M - 1) * ld_out + Nt) * 4);
+    size_t i = 0;
+    int rc = PLDA_OK;
+    for (int64_t r0 = 0; r0 < M && rc == PLDA_OK; r0 += slab, ++i) {
+      const int64_t m = std::min(slab, M - r0);
+      float *dO = h->hio_O[i & 1].as<float>();
+      hipError_t e = hp->begin_slab(h->stream, i);
+      if (e != hipSuccess) { rc = hip_fail(h, e, "begin_slab", __FILE__, __LINE__); break; }
+      rc = score_matrix_device(h, dU.as<double>() + r0 * D, n_enrol ? dN.as<int32_t>() + r0 : nullptr, n_uniform, m,
+                               dV.as<double>(), Nt, zn ? dZm.as<double>() + r0 : nullptr, zn ? dZs.as<double>() + r0 : nullptr,
+                               dO, Nt, /*reuse_packed_B=*/r0 > 0);
+      if (rc != PLDA_OK) break;
+      e = hp->ship_slab(h->stream, i, dO, (size_t)m * Nt * 4, reinterpret_cast<char *>(out + r0 * ld_out), (size_t)ld_out * 4,
+                        (size_t)Nt * 4, (size_t)m);
+      if (e != hipSuccess) rc = hip_fail(h, e, "ship_slab", __FILE__, __LINE__);
+    }
+    const hipError_t ef = hp->finish();                       // also on failure: nothing of this call stays in flight
+    if (rc == PLDA_OK && ef != hipSuccess) rc = hip_fail(h, ef, "HostPipe::finish", __FILE__, __LINE__);
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));              // the temporaries go out of scope
+    h->last_M = M;
+    return rc;
   });
 }
 
@@ -802,6 +895,57 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
                                 zn ? dZs.as<double>() : nullptr, dO.as<double>()));
     PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
+}
+
+// One trial on the HOST -- the reference's MPlda_score call (pldamodule.cpp:258-277: Plda::LogLikelihoodRatio at :266,
+// z-norm at :269-273) for callers that score one pair per Python call (scoring/scorePLDA.py:302-318,
+// tests/pldatest.py:29-33).  A single trial is 2 D numbers and ~5 D flop: any trip to the GPU (>= 30 us of launch and
+// synchronisation latency) costs ten times what the arithmetic does, so this entry point evaluates
+//   -1/2 [ sum_d log var_d - log(1 + psi_d) + (v_d - c_d u_d)^2 / var_d - v_d^2 / (1 + psi_d) ],
+//   c_d = n psi_d / (n psi_d + 1),  var_d = 1 + psi_d / (n psi_d + 1)
+// on the handle's host mirror of psi, with the per-count terms (c, 1/var, 1/(1 + psi), the log sum) cached for the last
+// n.  fp64; own code of the library (the oracle is not involved); callers with more than a handful of trials belong
+// on plda_score_pairs / plda_score_matrix.
+int plda_score_one(plda_handle *h, const double *u, int32_t n, const double *v, int32_t has_z, double zmean, double zstd,
+                   double *out) {
+  return guarded(h, "plda_score_one", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score: model not fitted");
+    if (!u || !v || !out) return fail(h, PLDA_E_INVAL, "score_one: bad argument");
+    if (n <= 0) return fail(h, PLDA_E_INVAL, "score_one: num_examples must be > 0");
+    const int D = h->Dout;
+    auto &o = h->one;
+    if (o.epoch != h->model_epoch || o.n != n || o.D != D) {
+      o.c.resize(D); o.ivar.resize(D); o.ipsi1.resize(D);
+      double lt = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double ps = h->h_psi[d], den = (double)n * ps + 1.0;
+        const double var = 1.0 + ps / den;
+        o.c[d] = (double)n * ps / den;
+        o.ivar[d] = 1.0 / var;
+        o.ipsi1[d] = 1.0 / (1.0 + ps);
+        lt += std::log(var) - std::log(1.0 + ps);
+      }
+      o.logterm = lt; o.epoch = h->model_epoch; o.n = n; o.D = D;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // four partial sums: the loop vectorises
+    const double *c = o.c.data(), *iv = o.ivar.data(), *ip = o.ipsi1.data();
+    int d = 0;
+    for (; d + 4 <= D; d += 4) {
+      const double e0 = v[d] - c[d] * u[d], e1 = v[d + 1] - c[d + 1] * u[d + 1];
+      const double e2 = v[d + 2] - c[d + 2] * u[d + 2], e3 = v[d + 3] - c[d + 3] * u[d + 3];
+      a0 += e0 * e0 * iv[d] - v[d] * v[d] * ip[d];
+      a1 += e1 * e1 * iv[d + 1] - v[d + 1] * v[d + 1] * ip[d + 1];
+      a2 += e2 * e2 * iv[d + 2] - v[d + 2] * v[d + 2] * ip[d + 2];
+      a3 += e3 * e3 * iv[d + 3] - v[d + 3] * v[d + 3] * ip[d + 3];
+    }
+    for (; d < D; ++d) { const double e = v[d] - c[d] * u[d]; a0 += e * e * iv[d] - v[d] * v[d] * ip[d]; }
+    double sc = -0.5 * (o.logterm + ((a0 + a1) + (a2 + a3)));
+    if (has_z && zstd != 0.0) sc = (sc - zmean) / zstd;   // zstd == 0: left un-normalised, as the trial-list kernel does
+    *out = sc;
     return PLDA_OK;
   });
 }
@@ -1025,9 +1169,7 @@ int plda_lda_transform(plda_handle *h, const double *X, int64_t N, int32_t D, in
     PLDA_TRY(upload(h, dX, X, (size_t)N * D * 8));
     PLDA_HIP(h, dO.alloc((size_t)N * ncomp * 8));
     PLDA_TRY(lda_transform_device(h, dX.as<double>(), N, ncomp, dO.as<double>()));
-    PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)N * ncomp * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    return PLDA_OK;
+    return download(h, out, dO.p, (size_t)N * ncomp * 8);
   });
 }
 
@@ -1068,9 +1210,7 @@ int plda_htk_frames(plda_handle *h, const void *blob, int64_t blob_bytes, const 
     const size_t obytes = (size_t)T * (2 * frm_ext + 1) * samplesize;
     PLDA_HIP(h, dOut.alloc(obytes));
     PLDA_TRY(htk_frames_device(h, dB.p, dF.as<int64_t>(), dO.as<int64_t>(), U, T, samplesize, frm_ext, dOut.as<float>()));
-    PLDA_HIP(h, hipMemcpyAsync(out, dOut.p, obytes, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    return PLDA_OK;
+    return download(h, out, dOut.p, obytes);
   });
 }
 

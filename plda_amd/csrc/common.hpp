@@ -39,6 +39,8 @@ struct Tmp {
 
 }  // namespace plda
 
+namespace plda { struct HostPipe; }
+
 struct plda_handle {
   std::recursive_mutex mu;   // taken by every C-ABI entry point (api.hip)
   int device = 0;
@@ -64,7 +66,16 @@ struct plda_handle {
   int64_t lda_K = 0;
   plda::DevBuf l_means, l_priors, l_xbar, l_scalings, l_coef, l_intercept, l_evr;
 
-  // ---- one-trial score(): host buffer mapped into the device address space ----
+  // ---- host-pointer entry points: pinned ring + copy threads (hostio.hip), two alternating score slabs ----
+  plda::HostPipe *hostpipe = nullptr;
+  plda::DevBuf hio_O[2];
+  int host_variant = 0;          // PLDA_HOST_VARIANT=1: the serial pageable-copy arm of rounds 1-2 (A/B)
+
+  // ---- one-trial score() on the host mirror of psi (plda_score_one): per-n coefficient cache ----
+  uint64_t model_epoch = 0;      // bumped whenever the model changes (fit, set_model, truncate, smooth)
+  struct OneTrial { uint64_t epoch = ~0ull; int n = 0, D = 0; double logterm = 0.0; std::vector<double> c, ivar, ipsi1; } one;
+
+  // ---- one-trial score through the trial-list kernel: host buffer mapped into the device address space ----
   void *one_host = nullptr, *one_dev = nullptr;
   size_t one_cap = 0;
 

@@ -670,6 +670,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   }
   const double t3 = now_ms();
   h->fitted = true;
+  ++h->model_epoch;
   h->fit_K = K; h->fit_D = D;
   h->fit_ms[1] = t2 - t1; h->fit_ms[2] = t3 - t2; h->fit_ms[3] = (double)iters;
   return PLDA_OK;

@@ -211,14 +211,15 @@ class MPlda(object):
             self.smooth(float(smoothfactor))
         dout, _ = self.dims()
         cap = C.c_int64(n)
-        out_labels = np.zeros(n, np.uint64)
-        out_counts = np.zeros(n, np.int64)
-        out_vecs = np.zeros((n, dout), np.float64)
+        out_labels = np.empty(n, np.uint64)
+        out_counts = np.empty(n, np.int64)
+        out_vecs = np.empty((n, dout), np.float64)
         self._ck(self._lib.plda_transform_groups(self._h, _ptr(X), n, d, _ptr(Y), _ptr(out_labels),
                                                  _ptr(out_counts), _ptr(out_vecs), C.byref(cap)))
         g = cap.value
         vecs = out_vecs[:g].copy()
-        return {int(out_labels[i]): (int(out_counts[i]), vecs[i]) for i in range(g)}
+        # keys / counts as Python ints and one row view per label, all built by C-level iteration
+        return dict(zip(out_labels[:g].tolist(), zip(out_counts[:g].tolist(), vecs)))
 
     def transform_array(self, xbar, num_examples=1):
         """Batched Plda::TransformIvector on already-averaged rows -> ndarray [R, D]."""
@@ -276,19 +277,13 @@ class MPlda(object):
     # ---------------------------------------------------------------- score
     def score(self, target, xvec, yvec):
         """MPlda_score (pldamodule.cpp:258-277): LLR of enrol model `xvec=(n, vec)`
-        against test `yvec=(n, vec)`, z-normalised if `target` has statistics."""
+        against test `yvec=(n, vec)`, z-normalised if `target` has statistics.
+
+        One trial per call is latency, not throughput: plda_score_one evaluates it on the handle's host
+        mirror of psi (a GPU round trip costs ten times the arithmetic); batches belong on score_matrix /
+        score_trials."""
         if not isinstance(xvec, tuple) or not isinstance(yvec, tuple):
             raise TypeError("score(target, (n, vec), (n, vec)): enrol model and test must be tuples")
-        # one trial per call is latency, not throughput: the per-call scratch arrays are kept on the object and
-        # the library's one-trial path (plda_score_pairs with M = Nt = P = 1) copies nothing through the copy engine
-        tl = self.__dict__.get("_score_tls")
-        if tl is None:
-            tl = self._score_tls = threading.local()      # per thread: ctypes drops the GIL inside the call
-        sc = getattr(tl, "scratch", None)
-        if sc is None:
-            sc = tl.scratch = (np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1), np.zeros(1), np.zeros(1))
-        n, zero, out, zm, zs = sc
-        n[0] = int(xvec[0])
         u, v = xvec[1], yvec[1]
         if not (type(u) is np.ndarray and u.dtype == np.float64 and u.ndim == 1 and u.flags.c_contiguous):
             u = np.ascontiguousarray(np.asarray(u, np.float64).reshape(-1))
@@ -297,13 +292,37 @@ class MPlda(object):
         dout = self._dout_cached()
         if u.shape[0] != dout or v.shape[0] != dout:
             raise ValueError("score: vectors must have the model dimension %d" % dout)
+        tl = self.__dict__.get("_score_tls")
+        if tl is None:
+            tl = self._score_tls = threading.local()      # per thread: ctypes drops the GIL inside the call
+        out = getattr(tl, "out", None)
+        if out is None:
+            out = tl.out = C.c_double()
+        zm = self._meanz.get(int(target))
+        if zm is None:
+            rc = self._lib.plda_score_one(self._h, u.ctypes.data, int(xvec[0]), v.ctypes.data, 0, 0.0, 0.0, out)
+        else:
+            rc = self._lib.plda_score_one(self._h, u.ctypes.data, int(xvec[0]), v.ctypes.data, 1, zm,
+                                          self._stdvz[int(target)], out)
+        if rc:
+            self._ck(rc)
+        return out.value
+
+    def score_on_device(self, target, xvec, yvec):
+        """The same trial through the GPU's fp64 trial-list kernel (plda_score_pairs with P = 1): ~30 us per
+        call; kept for parity tests of the two paths."""
+        n = np.array([int(xvec[0])], np.int32)
+        zero, out = np.zeros(1, np.int64), np.zeros(1)
+        u = np.ascontiguousarray(np.asarray(xvec[1], np.float64).reshape(-1))
+        v = np.ascontiguousarray(np.asarray(yvec[1], np.float64).reshape(-1))
+        dout = self._dout_cached()
+        if u.shape[0] != dout or v.shape[0] != dout:
+            raise ValueError("score: vectors must have the model dimension %d" % dout)
         t = int(target)
         has_z = t in self._meanz
-        if has_z:
-            zm[0], zs[0] = self._meanz[t], self._stdvz[t]
-        self._ck(self._lib.plda_score_pairs(self._h, u.ctypes.data, n.ctypes.data, 1, v.ctypes.data, 1, zero.ctypes.data,
-                                            zero.ctypes.data, 1, zm.ctypes.data if has_z else None,
-                                            zs.ctypes.data if has_z else None, out.ctypes.data))
+        zm, zs = np.array([self._meanz.get(t, 0.0)]), np.array([self._stdvz.get(t, 0.0)])
+        self._ck(self._lib.plda_score_pairs(self._h, _ptr(u), _ptr(n), 1, _ptr(v), 1, _ptr(zero), _ptr(zero), 1,
+                                            _ptr(zm) if has_z else None, _ptr(zs) if has_z else None, _ptr(out)))
         return float(out[0])
 
     def _dout_cached(self):
@@ -346,7 +365,7 @@ class MPlda(object):
         ids, counts, U = self._unpack(enrol)
         _, _, V = self._unpack(test)
         m, nt = U.shape[0], V.shape[0]
-        out = np.zeros((m, nt), np.float32)
+        out = np.empty((m, nt), np.float32)   # every element is written; the pages are first touched by the copy threads
         if m == 0 or nt == 0:
             return out
         zm, zs = self._zn_arrays(ids, znorm)
