@@ -101,7 +101,7 @@ def test_real_communicator_world_1():
     e2.znorm_stats_dev(bkg.data_ptr(), 300, 300, d, models.data_ptr(), 50, za[0].data_ptr(), za[1].data_ptr())
     e2.znorm_stats_sharded_dev(bkg.data_ptr(), 300, 300, d, models.data_ptr(), 50, zb[0].data_ptr(), zb[1].data_ptr())
     torch.cuda.synchronize()
-    assert torch.allclose(za, zb, rtol=1e-6, atol=0)
+    assert torch.allclose(za, zb, rtol=1e-12, atol=0)
     eng.comm_destroy()
     assert eng.comm_info() == (1, 0) and eng.comm_describe()["transport"] == "none"
 
@@ -123,4 +123,4 @@ def test_znorm_model_shards_tile(world):
         eng.znorm_stats_sharded_dev(bkg.data_ptr(), 200, 200, d, models.data_ptr(), m, got[0].data_ptr(), got[1].data_ptr())
     eng.comm_emulate(1, 0)
     torch.cuda.synchronize()
-    assert torch.allclose(got, ref, rtol=1e-6, atol=0)
+    assert torch.allclose(got, ref, rtol=1e-12, atol=0)

@@ -23,13 +23,13 @@ def test_engine_matches_golden(name):
     it = p._instance.fit_internals()
     T, psi = m["transform"], m["psi"]
     b = g["TtT"].shape[0]
-    assert np.abs(psi - g["psi"]).max() <= 1e-8 * g["psi"].max()
+    assert np.abs(psi - g["psi"]).max() <= 1e-9 * g["psi"].max()
     assert _rel(m["mean"], g["mean"]) < 1e-12
-    assert _rel((T.T @ T)[:b, :b], g["TtT"]) < 1e-8
-    assert _rel((T.T @ np.diag(psi) @ T)[:b, :b], g["TtPsiT"]) < 1e-8
-    assert _rel(it["W"][:b, :b], g["W"]) < 1e-8 and _rel(it["B"][:b, :b], g["B"]) < 1e-8
+    assert _rel((T.T @ T)[:b, :b], g["TtT"]) < 1e-9
+    assert _rel((T.T @ np.diag(psi) @ T)[:b, :b], g["TtPsiT"]) < 1e-9
+    assert _rel(it["W"][:b, :b], g["W"]) < 1e-9 and _rel(it["B"][:b, :b], g["B"]) < 1e-9
     tr = np.array([np.trace(T.T @ T), np.trace(T.T @ np.diag(psi) @ T), np.trace(it["W"]), np.trace(it["B"])])
-    np.testing.assert_allclose(tr, g["traces"], rtol=1e-8)
+    np.testing.assert_allclose(tr, g["traces"], rtol=1e-9)
     ne, nt = int(g["enrol_n"]), int(g["test_n"])
     enrol = p.transform(x[:ne], y[:ne])
     assert list(enrol.keys()) == [int(v) for v in g["enrol_labels"]]
@@ -44,5 +44,7 @@ def test_engine_matches_golden(name):
     p.norm(g["bkg"], enrol)
     zm, zs = p._instance.znorm_stats()
     gm = np.array([zm[k] for k in enrol]); gs = np.array([zs[k] for k in enrol])
-    assert (np.abs(gm - g["znorm_mean"]) <= 1e-4 * np.maximum(np.abs(g["znorm_mean"]), np.abs(g["znorm_mean"]).mean())).all()
-    assert (np.abs(gs - g["znorm_std"]) <= 1e-4 * g["znorm_std"]).all(), (np.abs(gs - g["znorm_std"]) / g["znorm_std"]).max()
+    # (the statistics are those of the engine's OWN fit, 1e-10 from the fixture's model: 1e-6, not the 1e-10 of the
+    #  statistics kernel itself, which tests/test_gpu_scoring.py holds on a shared model)
+    assert (np.abs(gm - g["znorm_mean"]) <= 1e-6 * np.maximum(np.abs(g["znorm_mean"]), np.abs(g["znorm_mean"]).mean())).all()
+    assert (np.abs(gs - g["znorm_std"]) <= 1e-6 * g["znorm_std"]).all(), (np.abs(gs - g["znorm_std"]) / g["znorm_std"]).max()
