@@ -81,7 +81,9 @@ struct plda_handle {
 
   // ---- scoring workspace ----
   plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias, s_rpair, s_cpair;
-  plda::DevBuf tf_pad;   // zero-padded copy of the transform for the one-pass K4 kernel
+  plda::DevBuf tf_pad;   // zero-padded copy of the transform for the one-pass K4 kernel, cached per model
+  uint64_t tf_pad_epoch = ~0ull;
+  int tf_pad_rows = 0, tf_pad_dinp = 0;
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
 
@@ -95,9 +97,8 @@ struct plda_handle {
   bool eig_keep_sign = false;   // LDA: keep negative eigenvalues (PLDA floors them, Kaldi ApplyFloor)
 
   bool panel_attr_set[16] = {};
-  bool tf_attr_set[5] = {};
   int num_cus = 256;           // hipDeviceAttributeMultiprocessorCount (persistent grids)
-  int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass (A/B arm)
+  int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass; 2: no tail launch (A/B arms)
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament

@@ -854,273 +854,6 @@ __global__ void score_pairs_kernel(const double *__restrict__ U, const int32_t *
 }
 
 // ------------------------------------------------------------------------------------
-// TransformIvector epilogue (Plda::TransformIvector + GetNormalizationFactor,
-// reached at pldamodule.cpp:171,224): t = offset + T x (the GEMM wrote T x into out),
-// f = sqrt(Dout / sum_d t_d^2 / (psi_d + 1/n)), out = f t.  One wave per row, fp64.
-// ------------------------------------------------------------------------------------
-__global__ void length_norm_kernel(double *__restrict__ out, int64_t R, int Dout,
-                                   const double *__restrict__ offset, const double *__restrict__ psi,
-                                   const int32_t *__restrict__ n_arr, int n_uniform) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const double inv_n = 1.0 / (n_arr ? (double)n_arr[row] : (double)n_uniform);
-  double *t = out + row * (int64_t)Dout;
-  double acc = 0.0;
-  for (int d = lane; d < Dout; d += 64) {
-    const double v = t[d] + offset[d];
-    acc += v * v / (psi[d] + inv_n);
-  }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  const double f = sqrt((double)Dout / acc);
-  for (int d = lane; d < Dout; d += 64) t[d] = f * (t[d] + offset[d]);
-}
-
-// ------------------------------------------------------------------------------------
-// K4 in one pass (Dout <= 512): out[r][:] = f_r (offset + T x_r).  A workgroup of 8 waves owns 16 * 8 / CH rows and
-// ALL columns: wave (rg, ch) accumulates 16 rows x NT 16-column tiles in v_mfma_f64_16x16x4_f64 accumulators
-// (CH = 2: two column halves per row group), so the row's sum of t_d^2 / (psi_d + 1/n) is there when the
-// contraction ends and the normalised row is written once.  (The general GEMM + length_norm_kernel pair writes
-// T x, reads it back and writes it again: 24 N D bytes moved for 16, and 17-25 % of the time.)  Operand stages
-// of 16 k: T's rows for all columns + the workgroup's rows of X, k-contiguous with a row pitch of 17 doubles
-// (conflict-free fragment reads), fetched global -> registers under the MFMAs of the previous stage and written
-// to the other buffer behind them; one barrier per stage.  Same k order and accumulator layout as gemm_f64_kernel.
-// Tried and dropped: 4-wave workgroups of 64 rows (T re-read twice as often: 25-50 % slower at D = 200 and 256, also
-// where two of them fit a CU); a second fragment register set filled one k-step ahead, with and without
-// sched_group_barrier forcing one LDS read between every two MFMAs (3-10 % slower, spills at (16, 2)) -- so the idle
-// 30 % of the matrix pipe is not LDS latency the schedule could hide.  Time follows the number of 16-column tiles, not the row pitch (D = 248 and 256: the same 3.06 ms for
-// 1.2M rows): the kernel is bound by its own issue rhythm -- 12.5k cycles per stage against 8.2k of MFMA work per
-// SIMD -- not by memory.
-// ------------------------------------------------------------------------------------
-typedef double f64x4s __attribute__((ext_vector_type(4)));
-constexpr int TF_LD = 17;
-
-__device__ __forceinline__ double tf_rcp(double x) {   // hardware estimate + two Newton steps: full precision
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-
-// T arrives zero-padded ([TP * 32 rows][Dinp = Din rounded up to 16], pad_transform_kernel), so its loads need no
-// clamps and its LDS writes no predicates; X's row pointers are clamped once, before the loop.  (With clamped
-// indices and zero-selects at every load and store the stage loop carried 2.3 vector-ALU instructions per MFMA --
-// 64-bit address arithmetic, compares, selects -- each costing the SIMD's matrix pipe an issue slot: PMC, MFMA busy
-// 70 % of the cycles at D = 256.)
-template <int NT, int CH>
-__global__ __launch_bounds__(512) void transform_fused_kernel(const double *__restrict__ X, int64_t R, int Din,
-                                                              const double *__restrict__ Tpad, int Dinp, int Dout,
-                                                              const double *__restrict__ offset,
-                                                              const double *__restrict__ psi,
-                                                              const int32_t *__restrict__ n_arr, int n_uniform,
-                                                              double *__restrict__ out) {
-  constexpr int RG = 8 / CH;              // row groups of 16
-  constexpr int ROWS = 16 * RG;
-  constexpr int COLS = 16 * NT * CH;
-  constexpr int TP = (COLS + 31) / 32;    // fetch passes over T's rows (32 rows x 16 k per pass)
-  constexpr int CP = TP * 32;             // rows of the padded T and of its LDS stage
-  constexpr int XP = ROWS / 32;
-  constexpr int STAGE = (CP + ROWS) * TF_LD;
-  extern __shared__ __attribute__((aligned(16))) double tf_lds[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int rg = wave % RG, ch = wave / RG;
-  const int fi = lane & 15, fk = lane >> 4;
-  const int lk = t & 15, lr = t >> 4;     // this thread's k and first row inside a fetch pass
-  const double *tptr = Tpad + (int64_t)lr * Dinp + lk;
-  const int64_t tstep = (int64_t)32 * Dinp;
-  const int tfrag = (ch * NT * 16 + fi) * TF_LD + fk, xfrag = (CP + rg * 16 + fi) * TF_LD + fk;
-  const bool early = wave >= 4;
-  // Persistent: one workgroup per CU walks over the row blocks.  (One workgroup fills a CU -- registers -- so between
-  // two of them the CU stood idle for the whole turnaround, ~17k cycles per 128-row block: wave launch, LDS
-  // allocation, the first loads.)
-  const int64_t nblocks = (R + ROWS - 1) / ROWS;
-  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-  const int64_t r0 = blk * ROWS;
-
-  f64x4s acc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) acc[i] = f64x4s{0.0, 0.0, 0.0, 0.0};
-  double rt[TP], rx[XP];
-  const double *xptr[XP];
-#pragma unroll
-  for (int p = 0; p < XP; ++p) xptr[p] = X + min(r0 + lr + 32 * p, R - 1) * (int64_t)Din + lk;
-
-  // fetch half q (q = 4: everything): the loads of a stage are issued in two halves, behind the MFMAs of the first
-  // two k-steps (later ones arrive too late for the wave's LDS write and it waits for them).  All at once at the top of a stage they are 48 KB per workgroup through the CU's 64 B/clk vector
-  // memory path: ~750 cycles in which both waves of every SIMD stand in load issue and nobody feeds the matrix pipe
-  // (phase timing, scripts/probe/transform_tl.hip: stage time = 8 192 MFMA cycles + exactly that).
-  auto fetch = [&](int k0, int q) {
-#pragma unroll
-    for (int p = 0; p < TP; ++p)
-      if (q == 4 || (p & 1) == q) rt[p] = tptr[p * tstep + k0];
-    // the last stage of a Din that is not a multiple of 16 must not read past a row's end (zeroed at the LDS write)
-    const int ko = (k0 + 16 <= Din) ? k0 : min(k0 + lk, Din - 1) - lk;
-#pragma unroll
-    for (int p = 0; p < XP; ++p)
-      if (q == 4 || (p & 1) == q) rx[p] = xptr[p][ko];
-  };
-  auto stage = [&](double *buf, int k0) {
-#pragma unroll
-    for (int p = 0; p < TP; ++p) buf[(lr + 32 * p) * TF_LD + lk] = rt[p];
-    if (k0 + 16 <= Din) {
-#pragma unroll
-      for (int p = 0; p < XP; ++p) buf[(CP + lr + 32 * p) * TF_LD + lk] = rx[p];
-    } else {
-      const bool kok = k0 + lk < Din;
-#pragma unroll
-      for (int p = 0; p < XP; ++p) buf[(CP + lr + 32 * p) * TF_LD + lk] = kok ? rx[p] : 0.0;
-    }
-  };
-
-  // The two waves of a SIMD (w and w + 4) take their non-MFMA work at opposite ends of a stage: the first fetches
-  // the next stage, runs its MFMAs and writes the fetched registers to the other buffer at the END; the second
-  // writes them at the START (they were fetched one stage earlier), fetches the stage after next and then runs its
-  // MFMAs -- so one of the two is feeding the matrix pipe while the other moves data.
-  fetch(0, 4);
-  stage(tf_lds, 0);
-  if (early && Din > 16) fetch(16, 4);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = 0; k0 < Din; k0 += 16) {
-    const bool more = k0 + 16 < Din;
-    if (early && more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
-    const int kf = early ? k0 + 32 : k0 + 16;     // the stage this wave fetches during this one
-    const bool dofetch = kf < Din;
-    const double *Ts = tf_lds + cur * STAGE + tfrag, *Xs = tf_lds + cur * STAGE + xfrag;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const double a = Xs[kk * 4];
-#pragma unroll
-      for (int tn = 0; tn < NT; ++tn) {
-        const double b = Ts[tn * 16 * TF_LD + kk * 4];
-        acc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tn], 0, 0, 0);
-      }
-      if (dofetch && kk < 2) fetch(kf, kk);
-      // fragment reads stay inside their k-step (all four steps' reads hoisted to the top of the stage need
-      // 4 x (1 + NT) register pairs next to the accumulators and spill at NT = 16); the SIMD's other wave covers them
-      asm volatile("" ::: "memory");
-    }
-    if (!early && more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + 16);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // offset and psi of every column go through LDS (the stage buffers are dead behind the loop's last barrier): read
-  // from global tile by tile -- the only order that does not spill -- they were 16 dependent L2 round trips, half of
-  // the 19k-cycle epilogue of a workgroup that has the CU to itself.
-  double *eo = tf_lds, *ep = tf_lds + COLS;
-  for (int c = t; c < COLS; c += 512) {
-    eo[c] = c < Dout ? offset[c] : 0.0;
-    ep[c] = c < Dout ? psi[c] : 1.0;
-  }
-  __syncthreads();
-  // accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row group
-  double inv_n[4], part[4] = {0.0, 0.0, 0.0, 0.0};
-  int64_t grow[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    grow[r] = r0 + rg * 16 + fk + 4 * r;
-    inv_n[r] = 1.0 / (n_arr ? (double)n_arr[min(grow[r], R - 1)] : (double)n_uniform);
-  }
-#pragma unroll
-  for (int tn = 0; tn < NT; ++tn) {
-    const int col = (ch * NT + tn) * 16 + fi;
-    const bool cok = col < Dout;
-    const double off = eo[col], ps = ep[col];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double v = cok ? acc[tn][r] + off : 0.0;
-      acc[tn][r] = v;
-      part[r] = fma(v * v, tf_rcp(ps + inv_n[r]), part[r]);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) part[r] += __shfl_xor(part[r], o);
-  }
-  if (CH == 2) {     // the other column half of the same rows lives in wave (rg, 1 - ch): exchange through LDS
-    double *red = tf_lds + 2 * COLS;        // behind the offset / psi copies
-    if (fi == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 + fk + 4 * r] = part[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[r] = red[rg * 16 + fk + 4 * r] + red[ROWS + rg * 16 + fk + 4 * r];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double f = sqrt((double)Dout / part[r]);
-    if (grow[r] < R) {
-      double *o = out + grow[r] * (int64_t)Dout;
-#pragma unroll
-      for (int tn = 0; tn < NT; ++tn) {
-        const int col = (ch * NT + tn) * 16 + fi;
-        if (col < Dout) o[col] = f * acc[tn][r];
-      }
-    }
-  }
-  __syncthreads();   // the epilogue's LDS copies are read; the next block stages over them
-  }
-}
-
-__global__ void pad_transform_kernel(const double *__restrict__ T, int Dout, int Din, double *__restrict__ Tpad, int rows,
-                                     int Dinp) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * Dinp) return;
-  const int r = idx / Dinp, c = idx % Dinp;
-  Tpad[idx] = (r < Dout && c < Din) ? T[(int64_t)r * Din + c] : 0.0;
-}
-
-template <int NT, int CH>
-static int launch_transform_fused(plda_handle *h, int slot, const double *dX, int64_t R, int Din, const int32_t *dn,
-                                  int n_uniform, double *dout) {
-  constexpr int ROWS = 16 * (8 / CH), COLS = 16 * NT * CH, CP = (COLS + 31) / 32 * 32;
-  constexpr size_t lds = (size_t)2 * (CP + ROWS) * TF_LD * 8;
-  if (!h->tf_attr_set[slot]) {
-    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->tf_attr_set[slot] = true;
-  }
-  // the model may have changed since the last call (fit, set_model, truncate, smoothing, load): the padded copy of T
-  // is rebuilt every time -- 2 MB at most, a few microseconds
-  const int Dinp = (int)round_up(Din, 16);
-  PLDA_HIP(h, h->tf_pad.reserve((size_t)CP * Dinp * 8));
-  pad_transform_kernel<<<(unsigned)ceil_div((int64_t)CP * Dinp, 256), 256, 0, h->stream>>>(
-      h->d_transform.as<double>(), h->Dout, Din, h->tf_pad.as<double>(), CP, Dinp);
-  transform_fused_kernel<NT, CH><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)ROWS), h->num_cus), 512, lds, h->stream>>>(
-      dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
-      n_uniform, dout);
-  PLDA_LAUNCH_CHECK(h);
-  return PLDA_OK;
-}
-
-int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
-                          int n_uniform, double *dout) {
-  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "transform: model not fitted");
-  if (Din != h->Din) return fail(h, PLDA_E_INVAL, "transform: feature dim %d != model dim %d", Din, h->Din);
-  if (R <= 0) return PLDA_OK;
-  // out[r][o] = sum_k X[r][k] T[o][k]
-  TraceScope ts(h, "transform.gemm + length_norm (K4)", 2.0 * (double)R * h->Dout * Din, 1);
-  if (h->Dout <= 512 && h->transform_variant != 1 && R < ((int64_t)1 << 31) * 64) {
-    const int D = h->Dout;
-    if (D <= 128) return launch_transform_fused<8, 1>(h, 0, dX, R, Din, dn, n_uniform, dout);
-    if (D <= 208) return launch_transform_fused<13, 1>(h, 1, dX, R, Din, dn, n_uniform, dout);
-    if (D <= 256) return launch_transform_fused<16, 1>(h, 2, dX, R, Din, dn, n_uniform, dout);
-    if (D <= 384) return launch_transform_fused<12, 2>(h, 3, dX, R, Din, dn, n_uniform, dout);
-    return launch_transform_fused<16, 2>(h, 4, dX, R, Din, dn, n_uniform, dout);
-  }
-  PLDA_TRY(gemm_f64(h, R, h->Dout, Din, 1.0, dX, Din, 1, h->d_transform.as<double>(), 1, Din,
-                    nullptr, 0.0, dout, h->Dout));
-  const int wpb = 4;
-  length_norm_kernel<<<(unsigned)ceil_div(R, wpb), wpb * 64, 0, h->stream>>>(
-      dout, R, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn, n_uniform);
-  PLDA_LAUNCH_CHECK(h);
-  return PLDA_OK;
-}
-
-// ------------------------------------------------------------------------------------
 // host orchestration of a trials-matrix call
 // ------------------------------------------------------------------------------------
 
