@@ -293,6 +293,227 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   }
 }
 
+// ------------------------------------------------------------------------------------
+// A/B arm (PLDA_TRANSFORM_VARIANT=7): the same block shapes with the operand stages brought in by LDS DMA
+// (`buffer_load_dwordx4 ... lds`) instead of global -> registers -> ds_write: no staging registers, no LDS-write
+// instructions, no load issue in the MFMA stream, a ring of three stage buffers with a stage in flight across each
+// barrier (raw s_barrier + counted vmcnt: __syncthreads would drain the DMA), the DMA stream running through the epilogue
+// into the next block.  Built because the kernel above still spends 55 % of its time when its MFMAs are taken out
+// (round-3 ablation) -- and measured 2-6 % SLOWER than it (C2 0.513 against 0.533 of the fp64 peak, C4 0.725 / 0.748,
+// C3 0.721 / 0.766): what the stage rhythm costs is not the staging instructions.  Same results bit for bit.
+//   * LDS image of a stage: rows of 128 B (16 k), UNPADDED -- a DMA piece is one wave's 64 lanes x 16 B = 1 KiB = 8 rows,
+//     lane-linear -- with the 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7 on the SOURCE side (lane l of a piece
+//     fetches chunk (l & 7) ^ swizzle of row l >> 3), so that the fragment read of 16 rows x one k-quad hits 32 different
+//     bank pairs.  T rows first (COLS of them), then the block's ROWS rows of X.
+//   * piece p of a stage belongs to wave p mod 8 (every wave issues the same number: the count of its `vmcnt`); odd and
+//     even pieces differ in the swizzle's high bit, and a wave only ever has one parity: one lane offset per operand.
+//   * rows of X beyond R come back as zeros (buffer bounds); k beyond Din is cut by skipping whole k-steps and zeroing
+//     the A fragment of a partial one (T's padding is zero, but 0 x a neighbour row's NaN would not be).
+//   * offset / weight vectors live in LDS for the whole kernel; the DMA stream runs through the epilogue into the next
+//     block (its stages land in the ring while the rows are normalised and stored).
+// ------------------------------------------------------------------------------------
+#define TF_LDS_AS __attribute__((address_space(3)))
+
+template <int NT, int CH>
+struct TfDmaGeom {
+  static constexpr int RG = 8 / CH, ROWS = 16 * RG, COLS = 16 * NT * CH;
+  static constexpr int TPC = COLS / 8, XPC = ROWS / 8, NPC = TPC + XPC, PPW = (NPC + 7) / 8;
+  static constexpr int SB = (COLS + ROWS) * 128;                      // bytes of one stage
+  static constexpr int SCRB = (2 * COLS + CH * ROWS) * 8;             // offset / weights / row-sum exchange
+  static constexpr int NSTG = (3 * SB + SCRB <= 160 * 1024) ? 3 : 2;
+  static constexpr size_t LDS_BYTES = (size_t)NSTG * SB + SCRB;
+};
+
+template <int NT, int CH, bool PERROW>
+__global__ __launch_bounds__(512) void transform_dma_kernel(const double *__restrict__ X, int64_t R, int Din,
+                                                            const double *__restrict__ Tpad, int Dinp, int padrows, int Dout,
+                                                            const double *__restrict__ offset,
+                                                            const double *__restrict__ psi,
+                                                            const int32_t *__restrict__ n_arr, int n_uniform,
+                                                            double *__restrict__ out) {
+  using G = TfDmaGeom<NT, CH>;
+  constexpr int RG = G::RG, ROWS = G::ROWS, COLS = G::COLS, TPC = G::TPC, NPC = G::NPC, PPW = G::PPW;
+  constexpr int SB = G::SB, NSTG = G::NSTG;
+  static_assert(NPC >= 8, "every wave moves at least one piece");
+  extern __shared__ __attribute__((aligned(16))) double tf_lds[];
+  TF_LDS_AS char *const lds = (TF_LDS_AS char *)tf_lds;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int rg = wave % RG, ch = wave / RG;
+  const int fi = lane & 15, fk = lane >> 4;
+  const int64_t nblocks = (R + ROWS - 1) / ROWS;
+  int64_t blk = blockIdx.x;
+  if (blk >= nblocks) return;
+  const int nstages = (Din + 15) >> 4;
+
+  // offset and length-norm weights of every column, once.  Uniform count: ep = 1 / (psi + 1/n); per-row counts: ep = psi.
+  double *const eo = reinterpret_cast<double *>(reinterpret_cast<char *>(tf_lds) + NSTG * SB), *const ep = eo + COLS, *const red = ep + COLS;
+  {
+    const double inv_nu = PERROW ? 0.0 : 1.0 / (double)n_uniform;
+    for (int c = t; c < COLS; c += 512) {
+      eo[c] = c < Dout ? offset[c] : 0.0;
+      const double ps = c < Dout ? psi[c] : 1.0;
+      ep[c] = PERROW ? ps : tf_rcp(ps + inv_nu);
+    }
+  }
+
+  // ---- DMA side ----
+  const int rl = lane >> 3;
+  const int clog = (lane & 7) ^ ((((wave & 1) << 2) + (rl >> 1)) & 7);     // the chunk of its row this lane fetches
+  const int vT = rl * Dinp * 8 + clog * 16, vX = rl * Din * 8 + clog * 16;
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Tpad), 0, padrows * Dinp * 8, 0x00020000);
+  int64_t dblk = blk;
+  int dst = 0, dbuf = 0;
+  bool dok = true;
+  auto x_rsrc = [&](int64_t b) {
+    const int64_t rows = min((int64_t)ROWS, R - b * ROWS);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(X + b * ROWS * (int64_t)Din), 0, (int)(rows * Din * 8), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t rsX = x_rsrc(dblk);
+  auto issue = [&]() {       // the cursor's stage into ring slot dbuf, then step the cursor
+    if (dok) {
+      const int kb = dst * 128;
+      TF_LDS_AS char *const sb = lds + dbuf * SB;
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        int p = wave + 8 * j;
+        if (p >= NPC) p -= 8;                                           // (a duplicate: equal piece counts for every wave)
+        if (p < TPC)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (TF_LDS_AS void *)(sb + p * 1024), 16, vT, p * 8 * Dinp * 8 + kb, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (TF_LDS_AS void *)(sb + p * 1024), 16, vX, (p - TPC) * 8 * Din * 8 + kb, 0, 0);
+      }
+    }
+    dbuf = dbuf + 1 == NSTG ? 0 : dbuf + 1;
+    if (++dst == nstages) {
+      dst = 0;
+      dblk += gridDim.x;
+      dok = dok && dblk < nblocks;
+      if (dok) rsX = x_rsrc(dblk);
+    }
+  };
+
+  // ---- compute side ----
+  const int sw = (fi >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + (fk >> 1)) ^ sw) << 4) + ((fk & 1) << 3);
+  const int aoff = (COLS + rg * 16 + fi) * 128, boff = (ch * NT * 16 + fi) * 128;
+  const int tailk = Din & 3;                                   // a partial last k-step: lanes fk >= tailk carry no data
+  int cbuf = 0;
+  bool prev_real = false, stores_pending = false;
+#pragma unroll
+  for (int i = 0; i < NSTG - 1; ++i) { prev_real = dok; issue(); }
+
+  for (;;) {
+    const int64_t r0 = blk * ROWS;
+    f64x4s acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f64x4s{0.0, 0.0, 0.0, 0.0};
+    for (int st = 0; st < nstages; ++st) {
+      // this wave's pieces of the stage have landed (one younger stage may stay in flight); then everybody's have,
+      // and nobody reads the slot the next DMA overwrites
+      if (NSTG >= 3 && prev_real && !stores_pending) __builtin_amdgcn_s_waitcnt(0x0070 | PPW);   // vmcnt(PPW) lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(0x0070);                                                   // vmcnt(0) lgkmcnt(0)
+      stores_pending = false;
+      __builtin_amdgcn_s_barrier();
+      prev_real = dok;
+      issue();
+      const char *const sbase = reinterpret_cast<const char *>(tf_lds) + cbuf * SB;
+      const int k0 = st << 4;
+      const int ksteps = min(4, (Din - k0 + 3) >> 2);
+      const int zkk = (tailk && st == nstages - 1 && fk >= tailk) ? ksteps - 1 : -1;
+      // (fragments one k-step ahead on a second register set -- there is room for it here -- were 10-12 % SLOWER again, as
+      //  in the register-staged kernel: C2 0.47 against 0.52, C4 0.66 against 0.75)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < ksteps) {
+          double a = *reinterpret_cast<const double *>(sbase + aoff + koff[kk]);
+          a = kk == zkk ? 0.0 : a;
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) {
+            const double b = *reinterpret_cast<const double *>(sbase + boff + tn * 2048 + koff[kk]);
+            acc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tn], 0, 0, 0);
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+      cbuf = cbuf + 1 == NSTG ? 0 : cbuf + 1;
+    }
+
+    // ---- epilogue (the DMA of the next block's first stages is in flight) ----
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    int64_t grow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) grow[r] = r0 + rg * 16 + fk + 4 * r;
+    if constexpr (PERROW) {
+      double inv_n[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) inv_n[r] = 1.0 / (double)n_arr[min(grow[r], R - 1)];
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int col = (ch * NT + tn) * 16 + fi;
+        const bool cok = col < Dout;
+        const double off = eo[col], ps = ep[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = cok ? acc[tn][r] + off : 0.0;
+          acc[tn][r] = v;
+          part[r] = fma(v * v, tf_rcp(ps + inv_n[r]), part[r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int col = (ch * NT + tn) * 16 + fi;
+        const bool cok = col < Dout;
+        const double off = eo[col], w = ep[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = cok ? acc[tn][r] + off : 0.0;
+          acc[tn][r] = v;
+          part[r] = fma(v * v, w, part[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) part[r] += __shfl_xor(part[r], o);
+    }
+    if (CH > 1) {     // the other column slices of the same rows live in waves (rg, ch'): exchange through LDS
+      if (fi == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 + fk + 4 * r] = part[r];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0) only: the DMA stays in flight across this barrier
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) sum += red[c * ROWS + rg * 16 + fk + 4 * r];   // fixed order: every slice gets the same sum
+        part[r] = sum;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double f = sqrt((double)Dout / part[r]);
+      if (grow[r] < R) {
+        double *o = out + grow[r] * (int64_t)Dout;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          const int col = (ch * NT + tn) * 16 + fi;
+          if (col < Dout) o[col] = f * acc[tn][r];
+        }
+      }
+    }
+    stores_pending = true;            // stores and loads retire out of order with respect to each other: count nothing
+    blk += gridDim.x;
+    if (blk >= nblocks) break;
+  }
+}
+
 __global__ void pad_transform_kernel(const double *__restrict__ T, int Dout, int Din, double *__restrict__ Tpad, int rows,
                                      int Dinp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,11 +543,34 @@ static int launch_transform_fused_t(plda_handle *h, const double *dX, int64_t R,
   return PLDA_OK;
 }
 
+template <int NT, int CH, bool PERROW>
+static int launch_transform_dma_t(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
+                                  int n_uniform, double *dout, int Dinp, int padrows) {
+  using G = TfDmaGeom<NT, CH>;
+  static_assert(G::LDS_BYTES <= 160 * 1024, "stage ring exceeds the LDS of a CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_dma_kernel<NT, CH, PERROW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+    attr_set = true;
+  }
+  transform_dma_kernel<NT, CH, PERROW><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)G::ROWS), h->num_cus), 512,
+                                         G::LDS_BYTES, h->stream>>>(
+      dX, R, Din, h->tf_pad.as<double>(), Dinp, padrows, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
+      n_uniform, dout);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 // (the per-row-count epilogue is its own instantiation: as a run-time branch beside the uniform one it made every large
 // block shape spill, 92-372 bytes per lane)
 template <int NT, int CH, int KS>
 static int launch_transform_fused(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
                                   int n_uniform, double *dout, int Dinp) {
+  // PLDA_TRANSFORM_VARIANT=7: the DMA-staged kernel (A/B arm; measured 2-6 % behind the register-staged one)
+  if (KS == 16 && h->transform_variant == 7)
+    return dn ? launch_transform_dma_t<NT, CH, true>(h, dX, R, Din, dn, n_uniform, dout, Dinp, h->tf_pad_rows)
+              : launch_transform_dma_t<NT, CH, false>(h, dX, R, Din, dn, n_uniform, dout, Dinp, h->tf_pad_rows);
   return dn ? launch_transform_fused_t<NT, CH, KS, true>(h, dX, R, Din, dn, n_uniform, dout, Dinp)
             : launch_transform_fused_t<NT, CH, KS, false>(h, dX, R, Din, dn, n_uniform, dout, Dinp);
 }

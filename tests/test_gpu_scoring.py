@@ -277,15 +277,17 @@ def test_znorm_statistics_against_the_closed_form():
     assert (np.abs(gs - rs) <= 1e-9 * rs).all(), (np.abs(gs - rs) / rs).max()
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "7"])
 @pytest.mark.parametrize("din,dout", [(7, 7), (77, 77), (128, 128), (129, 129), (200, 200), (200, 150), (209, 209),
                                       (256, 256), (257, 257), (300, 300), (385, 385), (512, 512), (512, 200),
                                       (520, 520)])
 def test_transform_rows_all_dimension_classes(din, dout, variant, monkeypatch):
-    """K4 through every instantiation of the one-pass kernel (column tiles of 8 / 13 / 16 x 16 per wave, one or two
-    column halves, Dout <= 512) and the GEMM + length-norm pair behind it (Dout > 512, or PLDA_TRANSFORM_VARIANT=1):
-    ragged row counts, K not a multiple of 16, truncated models (Dout < Din), per-row and uniform counts, against the
-    NumPy restatement of TransformIvector (pldamodule.cpp:171 -> Plda::TransformIvector)."""
+    """K4 through every instantiation of the one-pass kernel -- the five dimension classes, each with its main block shape
+    (row counts above one round of the persistent grid: 33 017) and its 64 / 32 / 16-row tail shapes (12 000 / 5 000 /
+    <= 1 000 rows), register-staged (product) and DMA-staged (PLDA_TRANSFORM_VARIANT=7) -- and the GEMM + length-norm
+    pair behind it (Dout > 512, or PLDA_TRANSFORM_VARIANT=1): ragged row counts, K not a multiple of 16 or of 4, truncated
+    models (Dout < Din), per-row and uniform counts, against the NumPy restatement of TransformIvector
+    (pldamodule.cpp:171 -> Plda::TransformIvector)."""
     from oracle import plda_oracle_np as onp
     from plda_amd import MPlda
     monkeypatch.setenv("PLDA_TRANSFORM_VARIANT", variant)
@@ -297,7 +299,7 @@ def test_transform_rows_all_dimension_classes(din, dout, variant, monkeypatch):
     eng = MPlda(0)
     eng.set_model(mean, T, psi)
     model = dict(mean=mean, transform=T, psi=psi, offset=-T @ mean)
-    for r in (1, 63, 64, 129, 1000):
+    for r in (1, 63, 64, 129, 1000) + ((5000, 12000, 33017) if variant != "1" or din == 200 else ()):
         x = rng.standard_normal((r, din))
         n = rng.integers(1, 9, r).astype(np.int32)
         for ne in (3, n):
