@@ -155,6 +155,15 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
                           int32_t n_uniform, int64_t M, const double *dV, int64_t Nt,
                           const double *dzmean, const double *dzstd, float *dout,
                           int64_t ld_out);
+/* One test set against many enrol sets (the reference's callers score every enrol model against the same test
+ * utterances, scoring/scorePLDA.py:302-318): plda_score_prepare_dev packs the test side once -- fp64 -> k-quad packed
+ * fp32 (+ V*V when enrol counts differ: mixed_counts != 0; else the column biases for n_uniform) -- and later
+ * plda_score_matrix_dev / _sharded_dev calls with the SAME dV, Nt, model and kind of enrol counts skip that work (C3:
+ * 2.1 of 72 ms per call).  The caller promises that the rows behind dV do not change meanwhile; a different test side,
+ * a model change (fit, set_model, truncate, smooth) or plda_score_unprepare end the reuse.  Test sides whose packed
+ * form would reach 4 GiB are refused (such calls are scored in column blocks, each packed per call). */
+int plda_score_prepare_dev(plda_handle *h, const double *dV, int64_t Nt, int32_t mixed_counts, int32_t n_uniform);
+int plda_score_unprepare(plda_handle *h);
 /* Kernel timing for roofline accounting: when enabled, every trials-GEMM launch is
  * bracketed by HIP events recorded on the stream it is launched on; plda_profile_read
  * synchronises and returns the accumulated GEMM milliseconds, launches, and the

@@ -52,6 +52,7 @@ int model_to_device(plda_handle *h) {
 int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
                         const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
                         float *dout, int64_t ld, bool reuse_packed_B = false);
+int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, bool mixed, int n_uniform);
 int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,
                        const int64_t *de, const int64_t *dt, int64_t P, const double *dzmean,
                        const double *dzstd, double *dout);
@@ -591,6 +592,24 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
     PLDA_LOCK(h);
     PLDA_TRY(set_device(h));
     return score_matrix_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, dout, ld_out);
+  });
+}
+
+int plda_score_prepare_dev(plda_handle *h, const double *dV, int64_t Nt, int32_t mixed_counts, int32_t n_uniform) {
+  return guarded(h, "plda_score_prepare_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return score_prepare_device(h, dV, Nt, mixed_counts != 0, n_uniform);
+  });
+}
+
+int plda_score_unprepare(plda_handle *h) {
+  return guarded(h, "plda_score_unprepare", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    h->prep_valid = false;
+    return PLDA_OK;
   });
 }
 

@@ -86,6 +86,12 @@ struct plda_handle {
   int tf_pad_rows = 0, tf_pad_dinp = 0;
   int64_t last_M = 0, last_Nt = 0;
   int last_k = 0;
+  // a test side packed ahead of time (plda_score_prepare_dev): reused while pointer, size, model and count kind match
+  bool prep_valid = false, prep_mixed = false;
+  const double *prep_dV = nullptr;
+  int64_t prep_Nt = 0;
+  uint64_t prep_epoch = 0;
+  int prep_nuniform = 0;
 
   // ---- Jacobi sweep graph + warm-start state (linalg.hip) ----
   hipGraphExec_t jac_exec = nullptr;

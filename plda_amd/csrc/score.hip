@@ -512,6 +512,9 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
   constexpr bool TL = (MODE & 1) != 0;                            // timeline instrumentation (diagnostic)
   constexpr bool DIRECT = (MODE & 2) == 0;                        // epilogue stores straight from the accumulator layout (MODE bit 1: the LDS-transpose epilogue, A/B arm)
+  // bounding arms (timing only, the scores are garbage): MODE bit 2 = no operand DMA (the MFMA stream, fragment reads,
+  // barriers and the epilogue as they are, operands "resident"), bit 3 = no output stores (the epilogue's cost)
+  constexpr bool NODMA = (MODE & 4) != 0, NOSTORE = (MODE & 8) != 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   float *const bias_lds = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + BT2_BIAS);
 
   auto dma_piece = [&](int jj) {
+    if (NODMA) return;
     if (jj < 4)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void *)(lds + d_lds + ldsw + jj * 8192u), 16, lane16,
                                                (int)(d_offA + (unsigned)jj * strideA2), 0, 0);
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   // slot d_slot) ride with its first stage -- and leaving one are the rare branches.  Past the last
   // tile the pieces re-fetch the last position; nothing consumes them.
   auto dma_advance = [&]() {
-    if (d_st == 0 && d_ok) {
+    if (d_st == 0 && d_ok && !NODMA) {
       // the tile's bias pairs, 2 KiB per side, one piece each from waves 0..3.  Buffer (MUBUF) DMA, not
       // global_load_lds: a pending FLAT-encoded LDS load makes the compiler's waitcnt pass turn every
       // LDS wait of the epilogue into lgkmcnt(0)
@@ -705,7 +709,9 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) stg[(4 * hh + e) * 64 + tn * 32 + i] = acc[tm][tn][4 * q + e];
       };
-      if (DIRECT && interior) {
+      if (NOSTORE && r0 >= 0) {
+        // (bounding arm: r0 is never negative, but the compiler cannot know; the accumulators stay live)
+      } else if (DIRECT && interior) {
         // no LDS round trip: a register of the 32 x 32 accumulator holds rows (8 q + e) and (8 q + e + 4) (lane >> 5)
         // of 32 consecutive columns, i.e. one store instruction = two full 128-byte row pieces.  The row walks on a
         // scalar base; the lane offset (half-row, column) is constant.  128 dword stores per tile and wave against
@@ -872,6 +878,7 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   TraceScope ts(h, "score.pack_operands");
   const int D = h->Dout;
   const int Dp = (int)round_up(D, 8);
+  if (doB) h->prep_valid = false;        // the packed test side is being overwritten (plda_score_prepare_dev re-marks its own)
   op.mixed = dn != nullptr;
   op.Kg = std::max(op.mixed ? 2 * Dp : Dp, 16);   // >= two 8-k steps: the 256 x 256 kernel runs them in pairs
   op.Kg_alg = op.mixed ? 2 * D : D;
@@ -966,13 +973,14 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   // it needs 32-bit byte offsets into each packed operand and into a tile's output rows
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
-                       (h->gemm_variant == 30 || h->gemm_variant == 31 || h->gemm_variant == 32 || h->gemm_variant == 33 ||
-                        (h->gemm_variant == 0 && big));
+                       ((h->gemm_variant >= 30 && h->gemm_variant <= 36) || (h->gemm_variant == 0 && big));
   if (use_bt2) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
       const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
-                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>)};
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>),
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<4>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<8>),
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<12>)};
       for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
@@ -989,6 +997,12 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       h->timeline_valid = true;
     } else if (h->gemm_variant == 32) {
       BT2L(2, nullptr);
+    } else if (h->gemm_variant == 34) {       // bounding arms: timing only
+      BT2L(4, nullptr);
+    } else if (h->gemm_variant == 35) {
+      BT2L(8, nullptr);
+    } else if (h->gemm_variant == 36) {
+      BT2L(12, nullptr);
     } else {
       BT2L(0, nullptr);
     }
@@ -1041,6 +1055,10 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
   const int64_t nrb = ceil_div(M, cap), ncb = ceil_div(Nt, cap);
   const bool zn = dzmean && dzstd;
   h->last_M = M; h->last_Nt = Nt; h->last_k = dn ? 2 * D : D;
+  // a test side packed ahead of time by plda_score_prepare_dev (same rows, same model, same kind of enrol counts)
+  if (ncb == 1 && h->prep_valid && h->prep_dV == dV && h->prep_Nt == Nt && h->prep_epoch == h->model_epoch &&
+      h->prep_mixed == (dn != nullptr) && (dn || h->prep_nuniform == n_uniform))
+    reuse_packed_B = true;
   for (int64_t rb = 0; rb < nrb; ++rb) {
     const int64_t r0 = rb * cap, m = std::min(cap, M - r0);
     for (int64_t cbk = 0; cbk < ncb; ++cbk) {
@@ -1053,6 +1071,25 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
       PLDA_TRY(launch_gemm<0>(h, op, m, nt, o, ld, nullptr, nullptr, nullptr));
     }
   }
+  return PLDA_OK;
+}
+
+// Pack the test side once for many calls (the reference's callers score one test set against enrol model after enrol
+// model: scoring/scorePLDA.py:302-318): V -> k-quad packed fp32 (+ V*V for mixed counts) and the column biases.
+int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, bool mixed, int n_uniform) {
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_prepare: model not fitted");
+  if (!dV || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_prepare: bad argument");
+  if (!mixed && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_prepare: n_uniform must be > 0 for uniform enrol counts");
+  const int D = h->Dout;
+  const int64_t kq8 = std::max<int64_t>((mixed ? 2 : 1) * round_up(D, 8), 16) / 4 + 8;
+  const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;
+  if (Nt > cap) return fail(h, PLDA_E_INVAL, "score_prepare: the packed test side would exceed 4 GiB (such calls are scored in column blocks)");
+  TrialOperands op;
+  static const int32_t dummy_marker = 0;
+  // (only the kind of the enrol counts matters to the test side: a non-null pointer selects the depth-2D form)
+  PLDA_TRY(prepare_operands(h, dV, mixed ? &dummy_marker : nullptr, n_uniform, 0, dV, Nt, nullptr, nullptr, op, /*doA=*/false, /*doB=*/true));
+  h->prep_valid = true; h->prep_dV = dV; h->prep_Nt = Nt; h->prep_epoch = h->model_epoch; h->prep_mixed = mixed;
+  h->prep_nuniform = n_uniform;
   return PLDA_OK;
 }
 

@@ -467,6 +467,14 @@ class MPlda(object):
             C.c_void_p(int(dV)), int(nt), C.c_void_p(int(dzmean)) if dzmean else None,
             C.c_void_p(int(dzstd)) if dzstd else None, C.c_void_p(int(dout)), int(ld)))
 
+    def score_prepare_dev(self, dV, nt, mixed_counts=False, n_uniform=1):
+        """Pack the test side [nt, Dout] (HBM-resident fp64) once; later score_matrix_dev / sharded calls with the same
+        dV, nt, model and kind of enrol counts skip the repacking.  The rows behind dV must not change meanwhile."""
+        self._ck(self._lib.plda_score_prepare_dev(self._h, C.c_void_p(int(dV)), int(nt), 1 if mixed_counts else 0, int(n_uniform)))
+
+    def score_unprepare(self):
+        self._ck(self._lib.plda_score_unprepare(self._h))
+
     # ------------------------------------------------- several GPUs (csrc/comm.hip)
     @staticmethod
     def comm_unique_id():

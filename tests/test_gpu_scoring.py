@@ -306,3 +306,61 @@ def test_transform_rows_all_dimension_classes(din, dout, variant, monkeypatch):
             got = eng.transform_array(x, ne)
             ref = onp.transform_ivector(model, x, ne)
             np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12)
+
+
+def test_prepared_test_side_is_reused_and_invalidated():
+    """plda_score_prepare_dev: the test side packed once gives bit-identical matrices for every later enrol slab (uniform
+    and mixed counts), and the reuse ends when the test rows, the count kind or the model change -- checked by making the
+    reuse WRONG on purpose: after a prepare on V the rows behind the same pointer are overwritten, so a call that still
+    reuses must reproduce the OLD scores and a call that repacks the new ones."""
+    import torch
+    from plda_amd import MPlda
+    dev = torch.device("cuda", 0)
+    d, m, nt = 56, 700, 1300
+    rng = np.random.default_rng(21)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    eng = MPlda(0)
+    eng.set_model(rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy())
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    U = torch.from_numpy(rng.standard_normal((m, d))).to(dev)
+    V = torch.from_numpy(rng.standard_normal((nt, d))).to(dev)
+    V2 = torch.from_numpy(rng.standard_normal((nt, d))).to(dev)
+    n = torch.from_numpy(rng.integers(1, 6, m).astype(np.int32)).to(dev)
+
+    def score(dn, nu, Vt):
+        o = torch.empty((m, nt), dtype=torch.float32, device=dev)
+        eng.score_matrix_dev(U.data_ptr(), dn.data_ptr() if dn is not None else None, nu, m, Vt.data_ptr(), nt, o.data_ptr(), nt)
+        torch.cuda.synchronize()
+        return o
+
+    ref_u, ref_m = score(None, 2, V), score(n, 0, V)
+    ref_u2 = score(None, 2, V2)
+    for mixed, dn, nu, ref in [(False, None, 2, ref_u), (True, n, 0, ref_m)]:
+        eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=mixed, n_uniform=max(nu, 1))
+        assert torch.equal(score(dn, nu, V), ref) and torch.equal(score(dn, nu, V), ref)      # reused, twice
+    # the reuse is real: overwrite the rows behind the prepared pointer -> the stale packing still answers ...
+    eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
+    keep = V.clone()
+    V.copy_(V2)
+    torch.cuda.synchronize()
+    assert torch.equal(score(None, 2, V), ref_u)
+    # ... until anything in the key changes: another count, the other kind of counts, unprepare, the model
+    assert torch.equal(score(None, 3, V), score(None, 3, V2))
+    eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
+    assert torch.equal(score(None, 2, V), ref_u2)
+    V.copy_(keep)
+    eng.score_unprepare()
+    assert torch.equal(score(None, 2, V), ref_u)
+    eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
+    eng.smooth(0.5)                                         # model epoch moves on
+    V.copy_(V2)
+    torch.cuda.synchronize()
+    one = MPlda(0)
+    mdl = eng.get_model()
+    one.set_model(mdl["mean"], mdl["transform"], mdl["psi"])
+    one.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    o1 = torch.empty((m, nt), dtype=torch.float32, device=dev)
+    one.score_matrix_dev(U.data_ptr(), None, 2, m, V2.data_ptr(), nt, o1.data_ptr(), nt)
+    torch.cuda.synchronize()
+    assert torch.equal(score(None, 2, V), o1)
+    eng.set_stream(None)
