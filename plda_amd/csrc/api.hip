@@ -206,6 +206,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_ZNORM_VARIANT")) h->znorm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
     if (const char *v = std::getenv("PLDA_HOST_VARIANT")) h->host_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_SWEEP_VARIANT")) h->sweep_variant = std::atoi(v);
     *out = h;
     return PLDA_OK;
   });
@@ -340,7 +341,7 @@ int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts
     if (!h) return PLDA_E_INVAL;
     PLDA_LOCK(h);
     if (!dmeans || !dcounts || !dscatter || K <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit_em: bad argument");
-    if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
+    if (D > 2048) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 2048 unsupported", D);
     PLDA_TRY(set_device(h));
     PLDA_HIP(h, h->f_means.reserve((size_t)K * D * 8));
     PLDA_HIP(h, h->f_counts.reserve((size_t)K * 8));
@@ -807,7 +808,7 @@ int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, dou
   return guarded(h, "plda_sym_eig", [&]() -> int {
     if (!h) return PLDA_E_INVAL;
     PLDA_LOCK(h);
-    if (!G || !eigenvalues || !eigenvectors || D <= 0 || D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: bad argument");
+    if (!G || !eigenvalues || !eigenvectors || D <= 0 || D > 2048) return fail(h, PLDA_E_INVAL, "sym_eig: bad argument");
     if (method < 0 || method > 2) return fail(h, PLDA_E_INVAL, "sym_eig: method must be 0 (default), 1 (Jacobi) or 2 (direct)");
     PLDA_TRY(set_device(h));
     const size_t DD = (size_t)D * D;

@@ -10,7 +10,7 @@
 //   tridiag_reg_kernel    D <= 256: the matrix lives in the registers of ONE workgroup (lower-triangle 32 x 32
 //                         block ownership as chol_small_kernel), D - 2 steps of (publish column -> v, tau ->
 //                         p = A v -> w -> rank-2 update), three barriers per step, no global synchronisation
-//   tridiag_rows_kernel   D <= 1024: rows dealt cyclically to D/8 workgroups (register-resident), ONE all-gather
+//   tridiag_rows_kernel   D <= 2048: rows dealt cyclically to D/8 workgroups (register-resident), ONE all-gather
 //                         per step through self-validating words (p_i and the next column travel together)
 //   dc_leaf_kernel        implicit QL (Wilkinson shift) on leaves of <= 16, one wave per leaf, d / e in lanes
 //   dc_merge_roots_kernel per merge: rank sort, deflation (dlaed2's two criteria), secular roots by the two-pole
@@ -31,7 +31,7 @@ namespace {
 
 constexpr double DC_EPS = 2.220446049250313e-16;
 constexpr int DC_LEAF = 16;       // leaves have ceil(n / 2^depth) <= 16 rows
-constexpr int DC_NMAX = 1024;
+constexpr int DC_NMAX = 2048;
 constexpr int DC_G = 16;          // lanes per secular root (one DPP row)
 constexpr int DC_RS = 16;         // roots per workgroup of dc_merge_roots_kernel (256 threads)
 
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(1024) void tridiag_reg_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------
-// tridiagonalisation, rows dealt cyclically to W = ceil(n / 8) workgroups, n <= 1024.  A row lives in the registers
+// tridiagonalisation, rows dealt cyclically to W = ceil(n / 8) workgroups, n <= 2048 (above 1024 the row registers spill: correct, slow).  A row lives in the registers
 // of 32 lanes (element k in lane k % 32).  Step j, every workgroup: v, tau from column j (all hold it) ->
 // p_i = A_i . v for its rows -> publish p_i together with A[i][j+1] -> ONE all-gather -> w; column j+1 of the
 // UPDATED matrix follows locally as A[i][j+1] - v_i w_{j+1} - w_i v_{j+1} -> rank-2 update of the own rows.
@@ -1119,14 +1119,14 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   const size_t DD = (size_t)n * n;
   // workspace: Vh, QtA, QtB, UmatT, deltaT (n^2 each), then vectors and lists
   const size_t vec = (size_t)round_up(n, 32);
-  const size_t need = DD * 8 * 5 + vec * 8 * 10 + 8 * 1024 * 8 + 64 + vec * 4 * 4 + vec * sizeof(DcRot) + (8 * vec + 64) * 8 + 4096;
+  const size_t need = DD * 8 * 5 + vec * 8 * 10 + 8 * (size_t)DC_NMAX * 8 + 64 + vec * 4 * 4 + vec * sizeof(DcRot) + (8 * vec + 64) * 8 + 4096;
   PLDA_HIP(h, h->eigdc.reserve(need));
   double *Vh = h->eigdc.as<double>();
   double *QtA = Vh + DD, *QtB = QtA + DD, *UmatT = QtB + DD, *deltaT = UmatT + DD;
   double *dd = deltaT + DD, *ee = dd + vec, *tau = ee + vec, *lamA = tau + vec, *lamB = lamA + vec;
   double *dkg = lamB + vec, *zkg = dkg + vec, *lamU = zkg + vec, *scale = lamU + vec;   // scale: 2 doubles
-  unsigned long long *words = reinterpret_cast<unsigned long long *>(scale + vec);   // all-gather: [parity][4][<= 1024]
-  int *keep = reinterpret_cast<int *>(words + 8 * 1024);
+  unsigned long long *words = reinterpret_cast<unsigned long long *>(scale + vec);   // all-gather: [parity][4][<= DC_NMAX]
+  int *keep = reinterpret_cast<int *>(words + 8 * DC_NMAX);
   int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
   DcRot *rots = reinterpret_cast<DcRot *>(flag + vec);
   double *Tg = reinterpret_cast<double *>(rots + vec);   // compact-WY T blocks: ceil((n - 2) / 8) x 64 doubles
@@ -1155,7 +1155,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
 #undef TR
   } else {
     const int E = (int)ceil_div(n, 32);
-    const int NP = (E <= 7 ? 7 : E <= 8 ? 8 : E <= 16 ? 16 : 32) * 32;
+    const int NP = (E <= 7 ? 7 : E <= 8 ? 8 : E <= 16 ? 16 : E <= 32 ? 32 : 64) * 32;
     PLDA_HIP(h, hipMemsetAsync(words, 0, (size_t)8 * NP * sizeof(unsigned long long), h->stream));
     int nn = n;
     const double *Gp = G;
@@ -1167,7 +1167,8 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     const void *fn = E <= 7    ? reinterpret_cast<const void *>(&tridiag_rows_kernel<7, TR_ROWS>)
                      : E <= 8  ? reinterpret_cast<const void *>(&tridiag_rows_kernel<8, TR_ROWS>)
                      : E <= 16 ? reinterpret_cast<const void *>(&tridiag_rows_kernel<16, TR_ROWS>)
-                               : reinterpret_cast<const void *>(&tridiag_rows_kernel<32, TR_ROWS>);
+                     : E <= 32 ? reinterpret_cast<const void *>(&tridiag_rows_kernel<32, TR_ROWS>)
+                               : reinterpret_cast<const void *>(&tridiag_rows_kernel<64, TR_ROWS>);
     {
       // a device that cannot hold all W workgroups at once (CU masking, a partitioned GPU) refuses the launch:
       // that is not an error of the fit -- the caller falls back to the block Jacobi solver
@@ -1216,7 +1217,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   ts.next("getoutput.eig.back_transform", 2.0 * (double)n * n * n, 1);
   {
     const int E = (int)ceil_div(n, 64);
-    const int EE = E <= 1 ? 1 : E <= 2 ? 2 : E <= 4 ? 4 : E <= 8 ? 8 : 16;
+    const int EE = E <= 1 ? 1 : E <= 2 ? 2 : E <= 4 ? 4 : E <= 8 ? 8 : E <= 16 ? 16 : 32;
     const int ntiles = n >= 3 ? (n - 2 + HB - 1) / HB : 0;
     if (ntiles) householder_T_kernel<<<ntiles, 256, 0, h->stream>>>(Vh, tau, n, Tg);
     const unsigned grid = (unsigned)ceil_div(n, 8);
@@ -1231,7 +1232,8 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     else if (EE == 2) HR(2);
     else if (EE == 4) HR(4);
     else if (EE == 8) HR(8);
-    else HR(16);
+    else if (EE == 16) HR(16);
+    else HR(32);
 #undef HR
   }
   PLDA_LAUNCH_CHECK(h);

@@ -411,7 +411,7 @@ static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int
 int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K) {
   if (!dX || !dlabels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
   if (K <= 0 || K > N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
-  if (D > 1024) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 1024 unsupported", D);
+  if (D > 2048) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 2048 unsupported", D);
   const size_t DD = (size_t)D * D;
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t0 = now_ms();

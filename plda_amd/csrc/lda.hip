@@ -206,7 +206,7 @@ int lda_fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uin
                    int solver, const double *priors_host) {
   if (!dX || !dlabels || N <= 0 || D <= 0 || K <= 0 || K > N) return fail(h, PLDA_E_INVAL, "lda_fit: bad argument");
   if (solver < LDA_SVD || solver > LDA_LSQR) return fail(h, PLDA_E_INVAL, "lda_fit: unknown solver %d", solver);
-  if (D > 1024) return fail(h, PLDA_E_INVAL, "lda_fit: featdim %d > 1024 unsupported", D);
+  if (D > 2048) return fail(h, PLDA_E_INVAL, "lda_fit: featdim %d > 2048 unsupported", D);
   if (solver == LDA_SVD && N <= K) return fail(h, PLDA_E_INVAL, "lda_fit: the svd solver needs more samples than classes");
   const size_t DD = (size_t)D * D;
   h->lda_fitted = false;

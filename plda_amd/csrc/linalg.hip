@@ -945,9 +945,135 @@ __global__ __launch_bounds__(1024) void spd_inverse_sweep_kernel(const double *_
     }
 }
 
+// The same sweep on FOUR waves (round 3): thread (ty, tx) of a 16 x 16 grid owns the lower-triangle elements
+// (16a + ty, 16b + tx), a >= b -- 91 doubles at D = 200, in the 512 registers a wave has when it is alone on its SIMD.
+// What a pivot costs is not its 20 000 FMAs (312 cycles of the CU's fp64 rate, whatever the number of waves) but the
+// exchange around them: with 16 waves every thread re-read its 2 x 7 entries of column k from LDS one double at a time
+// -- 224 wave-level LDS reads and a 16-wave barrier per pivot, 0.87 us.  Here the column is published in a permuted order
+// (entry i at (i mod 16) * PAD + i / 16) so that a thread's entries are contiguous: 2 x 7 16-byte reads per thread, 56 per
+// pivot, a 4-wave barrier: 175 -> ~55 us at D = 200.  One barrier per pivot (column buffers alternate).
+template <int NB>
+__global__ __launch_bounds__(256) void spd_inverse_sweep16_kernel(const double *__restrict__ W,
+                                                                  const double *__restrict__ B,
+                                                                  const double *__restrict__ gn, int D, int ldin,
+                                                                  int64_t stride_in, double *__restrict__ out,
+                                                                  int ldout, int64_t stride_out, int *flag) {
+  constexpr int NE = NB * (NB + 1) / 2;
+  constexpr int PAD = (NB + 1) & ~1;                     // entries per thread row of the published column, even
+  __shared__ __attribute__((aligned(16))) double v[2][16 * PAD];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const double n = gn ? gn[blockIdx.x] : 0.0;
+  W += (int64_t)blockIdx.x * stride_in;      // stride_in == 0: W (and B) shared by the batch, only n differs
+  if (B) B += (int64_t)blockIdx.x * stride_in;
+  out += (int64_t)blockIdx.x * stride_out;
+  double r[NE];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 16 + ty, j = b * 16 + tx;
+      double x = (i == j) ? 1.0 : 0.0;        // (rows / columns beyond D: an identity block, swept like the rest)
+      if (i < D && j <= i) {
+        x = W[(size_t)i * ldin + j];
+        if (B) x = fma(n, B[(size_t)i * ldin + j], x);
+      }
+      r[a * (a + 1) / 2 + b] = x;
+    }
+  bool bad = false;
+  // the block index kb of the pivot is a compile-time constant inside the unrolled outer loop, so the
+  // owners of column / row k are named registers: r[e(a, kb)], a >= kb, and r[e(kb, b)], b <= kb
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    for (int kl = 0; kl < 16; ++kl) {
+      const int k = kb * 16 + kl;
+      if (k >= D) break;
+      double *vv = v[k & 1];
+      if (tx == kl) {   // column k, rows >= k: entry (16a + ty) -> vv[ty * PAD + a]
+#pragma unroll
+        for (int a = kb; a < NB; ++a)
+          if (a > kb || ty >= kl) vv[ty * PAD + a] = r[a * (a + 1) / 2 + kb];
+      }
+      if (ty == kl) {   // row k, columns < k
+#pragma unroll
+        for (int b = 0; b <= kb; ++b)
+          if (b < kb || tx < kl) vv[tx * PAD + b] = r[kb * (kb + 1) / 2 + b];
+      }
+      __syncthreads();
+      const double d = vv[kl * PAD + kb];
+      if (!(d > 0.0)) bad = true;
+      const double inv = rcp_nr(d);
+      double ui[PAD], vj[PAD];
+      const double2 *pu = reinterpret_cast<const double2 *>(vv + ty * PAD), *pv = reinterpret_cast<const double2 *>(vv + tx * PAD);
+#pragma unroll
+      for (int a = 0; a < PAD / 2; ++a) {
+        const double2 u2 = pu[a], v2 = pv[a];
+        ui[2 * a] = -u2.x * inv; ui[2 * a + 1] = -u2.y * inv;
+        vj[2 * a] = v2.x; vj[2 * a + 1] = v2.y;
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) r[a * (a + 1) / 2 + b] = fma(ui[a], vj[b], r[a * (a + 1) / 2 + b]);
+      // owners overwrite column / row k with v / d, the pivot with -1/d
+      if (tx == kl) {
+#pragma unroll
+        for (int a = kb; a < NB; ++a) {
+          if (a > kb || ty > kl) r[a * (a + 1) / 2 + kb] = -ui[a];
+          else if (ty == kl) r[a * (a + 1) / 2 + kb] = -inv;
+        }
+      }
+      if (ty == kl) {
+#pragma unroll
+        for (int b = 0; b <= kb; ++b)
+          if (b < kb || tx < kl) r[kb * (kb + 1) / 2 + b] = vj[b] * inv;
+      }
+    }
+  }
+  if (bad && t == 0) *flag = 1;
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 16 + ty, j = b * 16 + tx;
+      if (i < D && j <= i) {
+        const double x = -r[a * (a + 1) / 2 + b];
+        out[(size_t)i * ldout + j] = x;
+        out[(size_t)j * ldout + i] = x;
+      }
+    }
+}
+
 // out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: W[g]^-1 with batch stride `stride_in`); D <= 256
 int spd_inverse_small(plda_handle *h, const double *W, const double *B, const double *gn, int D, int ldin,
                       int64_t stride_in, double *out, int ldout, int64_t stride_out, int *dflag, int batch) {
+  if (h->sweep_variant == 0) {     // four waves, 16 x 16 ownership (PLDA_SWEEP_VARIANT=1: the 16-wave kernel of round 2)
+    const int nb16 = (int)ceil_div(D, 16);
+#define SW16(NBB)                                                                                             \
+  spd_inverse_sweep16_kernel<NBB><<<batch, 256, 0, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout, \
+                                                                stride_out, dflag)
+    switch (nb16) {
+      case 1: SW16(1); break;
+      case 2: SW16(2); break;
+      case 3: SW16(3); break;
+      case 4: SW16(4); break;
+      case 5: SW16(5); break;
+      case 6: SW16(6); break;
+      case 7: SW16(7); break;
+      case 8: SW16(8); break;
+      case 9: SW16(9); break;
+      case 10: SW16(10); break;
+      case 11: SW16(11); break;
+      case 12: SW16(12); break;
+      case 13: SW16(13); break;
+      case 14: SW16(14); break;
+      case 15: SW16(15); break;
+      case 16: SW16(16); break;
+      default: return fail(h, PLDA_E_INVAL, "spd_inverse: D=%d > 256 unsupported", D);
+    }
+#undef SW16
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
   const int nb = (int)ceil_div(D, 32);
 #define SW(NBB)                                                                                              \
   spd_inverse_sweep_kernel<NBB><<<batch, 1024, 0, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout, \
@@ -1523,7 +1649,7 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
 // eigenvectors); the iteration then starts from A = warm G, V = warm instead of A = G, V = I.
 int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,
                 const double *warm) {
-  if (D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: D=%d > 1024 unsupported", D);
+  if (D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: the block Jacobi solver holds 16 rows in LDS (D=%d > 1024); the direct method is the only one above that", D);
   const size_t DD = (size_t)D * D;
   PLDA_HIP(h, h->w[14].reserve(DD * 8 * 2 + (size_t)D * 8 + 64));
   double *V = h->w[14].as<double>();

@@ -54,10 +54,11 @@ def test_direct_method_against_numpy(n):
         _check(eng, name, G, method=2, expect_method=2)
 
 
-@pytest.mark.parametrize("n", [161, 225, 257, 320, 512, 513, 1000, 1024])
+@pytest.mark.parametrize("n", [161, 225, 257, 320, 512, 513, 1000, 1024, 1025, 1536, 2048])
 def test_direct_method_large(n):
-    """n > 160: the tridiagonalisation runs on ceil(n / 8) cooperating workgroups (register layouts of 7, 8, 16 and 32
-    elements per lane: the sizes straddle their limits; 1024 is the largest supported)."""
+    """n > 160: the tridiagonalisation runs on ceil(n / 8) cooperating workgroups (register layouts of 7, 8, 16, 32 and
+    64 elements per lane: the sizes straddle their limits; 2048 is the largest supported -- 256 workgroups, one per CU;
+    above 1024 the row registers spill and only the direct method exists, the block Jacobi fallback stops at 1024)."""
     from plda_amd import MPlda
     eng = MPlda(0)
     rng = np.random.default_rng(n)

@@ -215,9 +215,38 @@ def test_c3_c4_scale_downs(oracle):
 
 def test_maximum_feature_dim_is_reported():
     from liblda import PLDA
-    x = np.random.default_rng(0).random((40, 1025))
-    with pytest.raises(RuntimeError, match="1024"):
+    x = np.random.default_rng(0).random((40, 2049))
+    with pytest.raises(RuntimeError, match="2048"):
         PLDA().fit(x, (np.arange(40) % 4).astype(np.uint64), 1)
+
+
+def test_fit_above_1024_dimensions(oracle):
+    """The reference has no cap on featdim (its tests stop at 1024, tests/pldatest.py:55); the engine's is 2048 (the
+    direct eigensolver's: one workgroup per CU).  D = 1536: statistics and two EM iterations against the oracle's
+    per-class loop (W, B), GetOutput through its invariants and against SciPy's generalised symmetric eigensolver for
+    psi (the oracle's own Jacobi-style eigensolver needs minutes at this size), then transform / score plumbing."""
+    import scipy.linalg as sl
+    from plda_amd import MPlda
+    d, k = 1536, 48
+    x, y = make_data(77, 4608, d, k, scale_between=0.3)      # (balanced: the oracle inverts once per distinct count)
+    eng = MPlda(0)
+    eng.fit(x, y, 2)
+    it, g = eng.fit_internals(), eng.get_model()
+    st = oracle.stats(x, y)
+    assert np.array_equal(it["counts"], st["counts"]) and _rel(it["means"], st["means"]) < 1e-13
+    assert _rel(it["scatter"], st["scatter"]) < 1e-10
+    W, B = np.eye(d), np.eye(d)
+    for _ in range(2):
+        W, B = oracle.em_iter(st, W, B)
+    assert _rel(it["W"], W) < 1e-9 and _rel(it["B"], B) < 1e-9, (_rel(it["W"], W), _rel(it["B"], B))
+    T, psi = g["transform"], g["psi"]
+    assert np.abs(T @ it["W"] @ T.T - np.eye(d)).max() < 1e-9
+    assert np.abs(T @ it["B"] @ T.T - np.diag(psi)).max() < 1e-9 * max(1.0, psi.max())
+    ref_psi = np.maximum(sl.eigh(B, W, eigvals_only=True)[::-1], 0.0)
+    assert np.abs(psi - ref_psi).max() <= 1e-8 * ref_psi.max()
+    enrol = eng.transform(x[:300], y[:300])
+    S = eng.score_matrix(enrol, (1, eng.transform_array(x[300:340], 1)), znorm=False)
+    assert np.isfinite(S).all() and S.shape == (len(enrol), 40)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])
