@@ -183,6 +183,9 @@ struct TraceScope {
   }
   void open(const char *name, double work, int unit) {
     if (!h->trace_on) return;
+    // bounded: a long-running process that never reads the trace keeps its first 8192 spans (16 384 events), not an
+    // ever-growing vector; plda_trace_read(reset) or plda_destroy start over
+    if (h->trace_used >= 8192) return;
     if (h->trace_used == h->trace_spans.size()) {
       plda_handle::TraceSpan sp{name, nullptr, nullptr, 0.0, 0};
       if (hipEventCreate(&sp.e0) != hipSuccess || hipEventCreate(&sp.e1) != hipSuccess) return;
