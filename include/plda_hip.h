@@ -26,6 +26,9 @@
  *    whole call, pldamodule.cpp has no threads); use one handle per thread for concurrency.
  *    plda_destroy must not race with other calls on the same handle.
  *  - there is NO CPU fallback: without a usable gfx950 device plda_create fails.
+ *  - feature dimension: 1 ... 2048 (plda_fit*, plda_lda_fit*, plda_sym_eig return PLDA_E_INVAL above).  The
+ *    reference has no cap (its own tests stop at 1024, tests/pldatest.py:55); the engine's is the direct eigensolver's
+ *    (one workgroup per 8 rows, all 256 CUs at 2048).  INTEGRATION.md, "Limits".
  */
 #ifndef PLDA_HIP_H_
 #define PLDA_HIP_H_
@@ -65,7 +68,7 @@ int plda_synchronize(plda_handle *h);
  * labels first).  Runs: label counting-sort, per-speaker centroids,
  * AddSamples(1/n_k) scatter (pldamodule.cpp:94-98), `iters` EM iterations
  * (Kaldi PldaEstimator::Estimate, :102-106) and GetOutput, all on the GPU in fp64. */
-int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D,
+int plda_fit(plda_handle *h, const double *X, int64_t N, int32_t D /* <= 2048 */,
              const uint64_t *labels, int32_t iters);
 int plda_fit_dev(plda_handle *h, const double *dX, int64_t N, int32_t D,
                  const uint64_t *dlabels, int64_t K, int32_t iters);
