@@ -25,6 +25,8 @@
 
 #include "common.hpp"
 
+#include <utility>
+
 namespace plda {
 
 namespace {
@@ -237,6 +239,194 @@ __global__ __launch_bounds__(1024) void tridiag_reg_kernel(const double *__restr
 #pragma unroll
     for (int b = 0; b <= a; ++b) {
       const int i = a * 32 + ty, j = b * 32 + tx;
+      const double v = r[a * (a + 1) / 2 + b];
+      if (i == j && i < n && i >= n - 2) dd[i] = v;
+      if (n >= 2 && i == n - 1 && j == n - 2) ee[n - 2] = v;
+    }
+  if (t == 0) {
+    if (n >= 2) tau[n - 2] = 0.0;
+    tau[n - 1] = 0.0;
+    ee[n - 1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The same on FOUR waves (round 3): thread (ty, tx) of a 16 x 16 grid owns A[16a + ty][16b + tx] for the blocks a >= b
+// (diagonal blocks whole) -- 91 doubles at n = 200, in the 512 registers a wave has when it is alone on its SIMD, so the
+// register-resident form reaches n = 256 without spilling and GetOutput at D = 200 no longer pays a fabric round trip
+// (2.6 us) per Householder step.  Vectors live in LDS in a permuted order (entry i at (i mod 16) PAD + i / 16) so that a
+// thread's entries of its rows (16a + ty) and of its columns (16b + tx) are contiguous 16-byte reads.  Per step:
+// publish column j | barrier | v, tau (every wave for itself); p = A v: row sums over tx by DPP inside the 16-lane rows,
+// column sums over ty by two lane exchanges + four per-wave partials in LDS | barrier | p, v.p | barrier | w, rank-2 update.
+// ------------------------------------------------------------------------------------
+template <typename F, int... KB>
+__device__ __forceinline__ void tr16_blocks(F &f, std::integer_sequence<int, KB...>) {
+  (f(std::integral_constant<int, KB>{}), ...);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tridiag_reg16_kernel(const double *__restrict__ G, int n,
+                                                            const double *__restrict__ scale,
+                                                            double *__restrict__ dd, double *__restrict__ ee,
+                                                            double *__restrict__ Vh, double *__restrict__ tau) {
+  constexpr int NE = NB * (NB + 1) / 2;
+  constexpr int PAD = (NB + 1) & ~1;
+  constexpr int NV = 16 * PAD;                // positions of a permuted vector (<= 256)
+  __shared__ __attribute__((aligned(16))) double xs[2][NV];
+  __shared__ __attribute__((aligned(16))) double ps[NV];
+  __shared__ __attribute__((aligned(16))) double prow[NV];
+  __shared__ __attribute__((aligned(16))) double part[4][NV];
+  __shared__ double red[4];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4, lane = t & 63, wave = t >> 6;
+  const double sc = scale[0];
+  // the vector position this thread serves in the per-entry phases, and its index
+  const int pos_i = (t < NV) ? (t % PAD) * 16 + t / PAD : -1;
+  const bool pos_ok = t < NV && (t % PAD) < NB;
+  for (int q = t; q < NV; q += 256) { xs[0][q] = 0.0; xs[1][q] = 0.0; ps[q] = 0.0; prow[q] = 0.0; part[0][q] = part[1][q] = part[2][q] = part[3][q] = 0.0; }
+  double r[NE];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 16 + ty, j = b * 16 + tx;
+      r[a * (a + 1) / 2 + b] = (i < n && j < n) ? G[(size_t)i * n + j] * sc : 0.0;
+    }
+  __syncthreads();
+  // (the block index of the pivot column must be a compile-time constant -- the owners of column j are named registers --
+  //  and a plain `#pragma unroll` gives up on a body of this size from NB = 13 on, which puts r[] into scratch memory:
+  //  the blocks are instantiated one by one)
+  auto block = [&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+    for (int kl = 0; kl < 16; ++kl) {
+      const int j = kb * 16 + kl;
+      if (j >= n - 2) break;
+      double *x = xs[j & 1];
+      // ---- publish column j below the diagonal (zeros above it) ----
+      if (tx == kl) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const int i = a * 16 + ty;
+          double v = 0.0;
+          if (a >= kb) v = (i > j) ? r[a * (a + 1) / 2 + kb] : 0.0;
+          x[ty * PAD + a] = v;
+        }
+        if (ty == kl) dd[j] = r[kb * (kb + 1) / 2 + kb];
+      }
+      __syncthreads();
+      // ---- v, tau (every wave for itself) ----
+      double s2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < (NV + 63) / 64; ++q) {
+        const int pos = lane + 64 * q;
+        if (pos < NV) {
+          const int i = (pos % PAD) * 16 + pos / PAD;
+          const double xv = x[pos];
+          s2 += (i > j + 1) ? xv * xv : 0.0;
+        }
+      }
+      s2 = wave_sum_f64(s2);
+      const double x0 = x[((j + 1) & 15) * PAD + ((j + 1) >> 4)];
+      if (s2 == 0.0) {   // column already tridiagonal (uniform over the workgroup)
+        if (t == 0) { ee[j] = x0; tau[j] = 0.0; }
+        continue;
+      }
+      const double nx2 = fma(x0, x0, s2);
+      const double nx = nx2 * dc_rsqrt(nx2);
+      const double alpha = x0 >= 0.0 ? -nx : nx;
+      const double v0 = x0 - alpha;
+      const double tt = 2.0 * dc_rcp(fma(v0, v0, s2));
+      double vr[PAD], vc[PAD];
+      {
+        const double2 *pr2 = reinterpret_cast<const double2 *>(x + ty * PAD), *pc2 = reinterpret_cast<const double2 *>(x + tx * PAD);
+#pragma unroll
+        for (int a = 0; a < PAD / 2; ++a) {
+          const double2 u = pr2[a], w = pc2[a];
+          vr[2 * a] = u.x; vr[2 * a + 1] = u.y; vc[2 * a] = w.x; vc[2 * a + 1] = w.y;
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          if (a * 16 + ty == j + 1) vr[a] = v0;
+          if (a * 16 + tx == j + 1) vc[a] = v0;
+        }
+      }
+      // ---- p = A v: row sums over the stored blocks + column sums of the strictly-lower blocks ----
+      double pc[PAD];
+#pragma unroll
+      for (int b = 0; b < PAD; ++b) pc[b] = 0.0;
+      double myrow = 0.0;                     // the row sum this lane publishes (block a == tx)
+#pragma unroll
+      for (int a = kb; a < NB; ++a) {
+        double pr = 0.0;
+#pragma unroll
+        for (int b = kb; b <= a; ++b) pr = fma(r[a * (a + 1) / 2 + b], vc[b], pr);
+#pragma unroll
+        for (int b = kb; b < a; ++b) pc[b] = fma(r[a * (a + 1) / 2 + b], vr[a], pc[b]);
+        // sum over tx: the 16-lane row by DPP (every lane of the row ends up with the sum)
+        pr += dpp_f64<0xB1>(pr);
+        pr += dpp_f64<0x4E>(pr);
+        pr += dpp_f64<0x141>(pr);
+        pr += dpp_f64<0x140>(pr);
+        myrow = tx == a ? pr : myrow;
+      }
+      if (tx >= kb && tx < NB) prow[ty * PAD + tx] = myrow;
+      // column sums: over the four rows of the wave by lane exchanges, then one partial per wave
+#pragma unroll
+      for (int b = kb; b < NB - 1; ++b) {
+        double c = pc[b];
+        c += __shfl_xor(c, 16);
+        c += __shfl_xor(c, 32);
+        pc[b] = c;
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int b = 0; b < PAD / 2; ++b)
+          if (2 * b + 1 >= kb) *reinterpret_cast<double2 *>(&part[wave][tx * PAD + 2 * b]) = double2{pc[2 * b], pc[2 * b + 1]};
+      }
+      __syncthreads();
+      double vp = 0.0;
+      if (pos_ok) {
+        const int i = pos_i;
+        double p = 0.0;
+        if (i > j) {
+          p = prow[t];
+          if ((i >> 4) < NB - 1) p += (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        }
+        const double vi = i == j + 1 ? v0 : x[t];
+        ps[t] = p;
+        vp = vi * p;
+        if (i < n) Vh[(size_t)j * n + i] = vi;
+      }
+      vp = wave_sum_f64(vp);
+      if (lane == 0) red[wave] = vp;
+      if (t == 0) { ee[j] = alpha; tau[j] = tt; }
+      __syncthreads();
+      const double vtp = (red[0] + red[1]) + (red[2] + red[3]);
+      const double beta = 0.5 * tt * tt * vtp;
+      // ---- w = tt p - beta v; A -= v w^T + w v^T on the trailing blocks ----
+      double wr[PAD], wc[PAD];
+      {
+        const double2 *pr2 = reinterpret_cast<const double2 *>(ps + ty * PAD), *pc2 = reinterpret_cast<const double2 *>(ps + tx * PAD);
+#pragma unroll
+        for (int a = 0; a < PAD / 2; ++a) {
+          const double2 u = pr2[a], w = pc2[a];
+          wr[2 * a] = fma(tt, u.x, -beta * vr[2 * a]); wr[2 * a + 1] = fma(tt, u.y, -beta * vr[2 * a + 1]);
+          wc[2 * a] = fma(tt, w.x, -beta * vc[2 * a]); wc[2 * a + 1] = fma(tt, w.y, -beta * vc[2 * a + 1]);
+        }
+      }
+#pragma unroll
+      for (int a = kb; a < NB; ++a)
+#pragma unroll
+        for (int b = kb; b <= a; ++b)
+          r[a * (a + 1) / 2 + b] = fma(-vr[a], wc[b], fma(-wr[a], vc[b], r[a * (a + 1) / 2 + b]));
+    }
+  };
+  tr16_blocks(block, std::make_integer_sequence<int, NB>{});
+  // ---- the last 2 x 2 block ----
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      const int i = a * 16 + ty, j = b * 16 + tx;
       const double v = r[a * (a + 1) / 2 + b];
       if (i == j && i < n && i >= n - 2) dd[i] = v;
       if (n >= 2 && i == n - 1 && j == n - 2) ee[n - 2] = v;
@@ -1139,7 +1329,30 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   // tridiagonalisation: one workgroup with the matrix in registers while that fits without spilling (n <= 160),
   // else rows over ceil(n / 8) cooperating workgroups (PLDA_EIG_VARIANT=2 / 3 force one or the other)
   const bool reg_kernel = h->eig_variant == 2 ? n <= 256 : (h->eig_variant == 3 ? false : n <= 160);
-  if (reg_kernel) {
+  // round 3: the four-wave register kernel up to n = 224 (PLDA_SWEEP_VARIANT=1 or PLDA_EIG_VARIANT=2 / 3: the round-2 choice)
+  if (h->sweep_variant == 0 && h->eig_variant == 0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
+    const int nb = (int)ceil_div(n, 16);
+#define TR16(NBB) tridiag_reg16_kernel<NBB><<<1, 256, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
+    switch (nb) {
+      case 1: TR16(1); break;
+      case 2: TR16(2); break;
+      case 3: TR16(3); break;
+      case 4: TR16(4); break;
+      case 5: TR16(5); break;
+      case 6: TR16(6); break;
+      case 7: TR16(7); break;
+      case 8: TR16(8); break;
+      case 9: TR16(9); break;
+      case 10: TR16(10); break;
+      case 11: TR16(11); break;
+      case 12: TR16(12); break;
+      case 13: TR16(13); break;
+      case 14: TR16(14); break;
+      case 15: TR16(15); break;
+      default: TR16(16); break;
+    }
+#undef TR16
+  } else if (reg_kernel) {
     const int nb = (int)ceil_div(n, 32);
 #define TR(NBB) tridiag_reg_kernel<NBB><<<1, 1024, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
     switch (nb) {
