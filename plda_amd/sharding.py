@@ -87,13 +87,99 @@ class TorchHostTransport(object):
             return 1
 
 
+class TorchDeviceTransport(object):
+    """`plda_collectives` (the DEVICE-level table, plda_comm_init_custom) over a torch.distributed group: every
+    operation synchronises the stream, moves the pieces through host memory with hipMemcpy and the group's CPU
+    collectives, and returns with the data in place.  A reference implementation of the table for binders (a real
+    one would use peer copies); the tests use it to cover plda_comm_init_custom between processes."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.last_error = None
+        self.calls = {"all_gather": 0, "all_gather_v": 0, "all_reduce": 0}
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self._ag = N.DEV_ALL_GATHER(self._all_gather)
+        self._agv = N.DEV_ALL_GATHER_V(self._all_gather_v)
+        self._ar = N.DEV_ALL_REDUCE(self._all_reduce)
+        self.table = N.Collectives(None, self._ag, self._agv, self._ar, N.DESTROY_FN())
+
+    def _src(self, q):
+        return dist.get_global_rank(self.group, q) if self.group is not None else q
+
+    def _d2h(self, dptr, nbytes):
+        a = np.empty(nbytes, np.uint8)
+        if nbytes and self._hip.hipMemcpy(a.ctypes.data, dptr, nbytes, 2) != 0:
+            raise RuntimeError("hipMemcpy device -> host failed")
+        return a
+
+    def _h2d(self, dptr, a):
+        if a.size and self._hip.hipMemcpy(dptr, a.ctypes.data, a.size, 1) != 0:
+            raise RuntimeError("hipMemcpy host -> device failed")
+
+    def _gather_v(self, dbuf, o, c, stream):
+        if self._hip.hipStreamSynchronize(stream) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
+        for q in range(self.world):
+            if c[q] <= 0:
+                continue
+            piece = self._d2h(dbuf + o[q], c[q]) if q == self.rank else np.empty(c[q], np.uint8)
+            dist.broadcast(torch.from_numpy(piece), src=self._src(q), group=self.group)
+            if q != self.rank:
+                self._h2d(dbuf + o[q], piece)
+
+    def _all_gather(self, ctx, dsend, drecv, nbytes, stream):
+        try:
+            nbytes = int(nbytes)
+            if self._hip.hipStreamSynchronize(stream) != 0:
+                raise RuntimeError("hipStreamSynchronize failed")
+            mine = int(drecv) + self.rank * nbytes
+            if int(dsend) != mine:
+                self._h2d(mine, self._d2h(int(dsend), nbytes))
+            self._gather_v(int(drecv), [q * nbytes for q in range(self.world)], [nbytes] * self.world, stream)
+            self.calls["all_gather"] += 1
+            return 0
+        except Exception as e:       # noqa: BLE001
+            self.last_error = e
+            return 1
+
+    def _all_gather_v(self, ctx, dbuf, offs, counts, stream):
+        try:
+            self._gather_v(int(dbuf), [int(offs[q]) for q in range(self.world)], [int(counts[q]) for q in range(self.world)], stream)
+            self.calls["all_gather_v"] += 1
+            return 0
+        except Exception as e:       # noqa: BLE001
+            self.last_error = e
+            return 1
+
+    def _all_reduce(self, ctx, dbuf, count, dtype, op, stream):
+        try:
+            if self._hip.hipStreamSynchronize(stream) != 0:
+                raise RuntimeError("hipStreamSynchronize failed")
+            np_t = {N.PLDA_DT_F64: np.float64, N.PLDA_DT_U64: np.int64, N.PLDA_DT_U32: np.uint32}[int(dtype)]
+            rop = {N.PLDA_OP_SUM: dist.ReduceOp.SUM, N.PLDA_OP_MAX: dist.ReduceOp.MAX, N.PLDA_OP_MIN: dist.ReduceOp.MIN}[int(op)]
+            a = self._d2h(int(dbuf), int(count) * np.dtype(np_t).itemsize).view(np_t)
+            t = torch.from_numpy(a.astype(np.int64) if np_t is np.uint32 else a.copy())
+            dist.all_reduce(t, op=rop, group=self.group)
+            self._h2d(int(dbuf), np.ascontiguousarray(t.numpy().astype(np_t)).view(np.uint8))
+            self.calls["all_reduce"] += 1
+            return 0
+        except Exception as e:       # noqa: BLE001
+            self.last_error = e
+            return 1
+
+
 def init_comm(engine, group=None, device=None, transport="rccl"):
     """Give `engine` (an MPlda) its communicator; returns (world, rank).
 
     transport "rccl": rank 0 draws the unique id, torch.distributed (any backend -- it only carries 128 bytes)
     hands it round, every rank calls plda_comm_init; afterwards the library's sharded entry points run over
     RCCL without torch in the data path.  transport "host": the collectives travel through `group` itself
-    (TorchHostTransport) -- no RCCL, works with several processes on one GPU."""
+    (TorchHostTransport: the library stages, the group moves host buffers) -- no RCCL, works with several processes on
+    one GPU.  transport "custom": the device-level table itself supplied from here (TorchDeviceTransport)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 1, 0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -102,8 +188,13 @@ def init_comm(engine, group=None, device=None, transport="rccl"):
         engine.comm_init_host(world, rank, tr.table)
         engine._comm_transport = tr          # callbacks live as long as the engine
         return world, rank
+    if transport == "custom":
+        tr = TorchDeviceTransport(group)
+        engine.comm_init_custom(world, rank, tr.table)
+        engine._comm_transport = tr
+        return world, rank
     if transport != "rccl":
-        raise ValueError("transport must be 'rccl' or 'host'")
+        raise ValueError("transport must be 'rccl', 'host' or 'custom'")
     uid = [engine.comm_unique_id() if rank == 0 else None]
     if dist.get_backend(group) == "nccl":
         t = torch.tensor(list(uid[0]) if rank == 0 else [0] * 128, dtype=torch.uint8,
