@@ -215,6 +215,9 @@ int model_to_device(plda_handle *h);
 int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
                      int64_t sak, int64_t strideA, const double *B, int64_t sbk, int64_t sbn, int64_t strideB,
                      const double *kw, double beta, double *C, int64_t ldc, int64_t strideC, int batch);
+// C = X^T diag(kw) X + w2 X2^T X2 (one launch for D <= 208)
+int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ldx, const double *kw, int64_t K2,
+                  const double *X2, int64_t ldx2, double w2, double *C, int64_t ldc);
 int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
              int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,
              const double *kw, double beta, double *C, int64_t ldc);

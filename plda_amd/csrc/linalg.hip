@@ -406,8 +406,11 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const double *__restri
 constexpr int TRI_NT = 13;                 // tile rows: D <= 208
 constexpr int TRI_LD = TRI_NT * 16 + 16;   // LDS row stride in doubles
 
+// Rows [0, K1) come from X with the weights kw (nullptr: 1), rows [K1, K) from X2 with the one weight w2 (round 3: the
+// statistics pass folds - M^T M, the centroids' term of the offset scatter, into the same launch as X^T diag(w) X).
 __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t kchunk, const double *__restrict__ X,
-                                                       int64_t ldx, const double *__restrict__ kw,
+                                                       int64_t ldx, const double *__restrict__ kw, int64_t K1,
+                                                       const double *__restrict__ X2, int64_t ldx2, double w2,
                                                        double *__restrict__ part) {
   __shared__ double Xs[2][GK * TRI_LD];
   __shared__ double Ws[2][GK];
@@ -431,12 +434,12 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
       const int64_t gk = min(k0 + tk + pass * 2, kend - 1);
-      r[pass] = X[gk * ldx + gc];
+      r[pass] = gk < K1 ? X[gk * ldx + gc] : X2[(gk - K1) * ldx2 + gc];
     }
   };
   auto fetch_w = [&](int64_t k0) {
     double w = 0.0;
-    if (t < GK && k0 + t < kend) w = kw ? kw[k0 + t] : 1.0;
+    if (t < GK && k0 + t < kend) w = k0 + t < K1 ? (kw ? kw[k0 + t] : 1.0) : w2;
     return w;
   };
   auto store = [&](double *lds, const double (&r)[8]) {
@@ -547,7 +550,7 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
     splits = (int)ceil_div(K, kchunk);
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
-    syrk_tri_kernel<<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, part);
+    syrk_tri_kernel<<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part);
     syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, alpha, beta, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
@@ -574,6 +577,26 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
   syrk_reduce_kernel<<<(unsigned)(nP * 64), 256, 0, h->stream>>>(part, sd, so, nP, D, alpha, beta, C, ldc);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
+}
+
+// C = X^T diag(kw) X + w2 X2^T X2 in one pass where the single-launch kernel applies (D <= 208), else as two products
+int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ldx, const double *kw, int64_t K2,
+                  const double *X2, int64_t ldx2, double w2, double *C, int64_t ldc) {
+  if (D <= TRI_NT * 16 && h->gemm64_variant == 0) {
+    const int nt = (int)ceil_div(D, 16), ntri = nt * (nt + 1) / 2;
+    const int64_t K = K1 + K2;
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(K, 128)));
+    const int64_t kchunk = round_up(ceil_div(K, splits), GK);
+    splits = (int)ceil_div(K, kchunk);
+    PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
+    double *part = h->w[15].as<double>();
+    syrk_tri_kernel<<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part);
+    syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, ldc);
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
+  PLDA_TRY(gemm_f64(h, D, D, K1, 1.0, X, 1, ldx, X, ldx, 1, kw, 0.0, C, ldc));
+  return gemm_f64(h, D, D, K2, w2, X2, 1, ldx2, X2, ldx2, 1, nullptr, 1.0, C, ldc);
 }
 
 // Small products (the D x D x D GEMMs of the EM, K <= 256): the 64 x 64 kernel above would put 16
