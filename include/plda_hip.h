@@ -198,6 +198,12 @@ int plda_trace_read(plda_handle *h, char *json, int64_t cap, int32_t reset);
  * method or PLDA_E_NUMERIC.  *method_used (nullable) reports 1 or 2. */
 int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, double *eigenvalues,
                  double *eigenvectors, int32_t *method_used);
+/* The SPD inverse of the EM's E-step on its own (diagnostics and tests; the reference reaches it only through
+ * PldaEstimator::GetStatsFromClassMeans, Kaldi ivector/plda.cc:436-447 -> SpMatrix::Invert).  A [D,D] row-major
+ * symmetric positive definite, host pointers; inverse [D,D].  D <= 64: scalar sweep operator in registers,
+ * D <= 256: block sweeps on the fp64 matrix cores, above: blocked whitening.  PLDA_E_NUMERIC when a pivot is not
+ * positive. */
+int plda_spd_inverse(plda_handle *h, const double *A, int32_t D, double *inverse);
 /* algorithmic work of the last score_matrix call: flop of the trials GEMM and
  * its depth, for roofline accounting */
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k);

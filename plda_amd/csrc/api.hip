@@ -803,6 +803,31 @@ int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words) {
   });
 }
 
+int plda_spd_inverse(plda_handle *h, const double *A, int32_t D, double *inverse) {
+  return guarded(h, "plda_spd_inverse", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!A || !inverse || D <= 0 || D > 2048) return fail(h, PLDA_E_INVAL, "spd_inverse: bad argument");
+    PLDA_TRY(set_device(h));
+    const size_t DD = (size_t)D * D;
+    Tmp dA, dO, dS, dF;
+    PLDA_HIP(h, dA.alloc(DD * 8));
+    PLDA_HIP(h, dO.alloc(DD * 8));
+    PLDA_HIP(h, dS.alloc(3 * DD * 8));
+    PLDA_HIP(h, dF.alloc(sizeof(int)));
+    PLDA_HIP(h, hipMemcpyAsync(dA.p, A, DD * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemsetAsync(dF.p, 0, sizeof(int), h->stream));
+    PLDA_TRY(spd_inverse_blocked(h, dA.as<double>(), D, D, (int64_t)DD, dO.as<double>(), D, (int64_t)DD, dS.as<double>(),
+                                 (int64_t)(3 * DD), dF.as<int>(), 1));
+    int bad = 0;
+    PLDA_HIP(h, hipMemcpyAsync(inverse, dO.p, DD * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(&bad, dF.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (bad) return fail(h, PLDA_E_NUMERIC, "spd_inverse: the matrix is not positive definite");
+    return PLDA_OK;
+  });
+}
+
 int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, double *eigenvalues, double *eigenvectors,
                  int32_t *method_used) {
   return guarded(h, "plda_sym_eig", [&]() -> int {

@@ -108,7 +108,8 @@ struct plda_handle {
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
-  int sweep_variant = 0;  // PLDA_SWEEP_VARIANT=1: the 16-wave register kernels of round 2 (SPD inverse, Cholesky, tridiagonalisation)
+  int sweep_variant = 0;  // PLDA_SWEEP_VARIANT=1: the 16-wave register kernels of round 2 (SPD inverse, tridiagonalisation); 2: the four-wave scalar sweep at every size (no matrix-core block sweep)
+  bool sweep_mfma_attr[17] = {};   // dynamic-LDS attribute of spd_inverse_mfma_kernel<NT> set
   int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
   bool bt2_attr_set = false;

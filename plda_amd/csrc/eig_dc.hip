@@ -1330,7 +1330,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   // else rows over ceil(n / 8) cooperating workgroups (PLDA_EIG_VARIANT=2 / 3 force one or the other)
   const bool reg_kernel = h->eig_variant == 2 ? n <= 256 : (h->eig_variant == 3 ? false : n <= 160);
   // round 3: the four-wave register kernel up to n = 224 (PLDA_SWEEP_VARIANT=1 or PLDA_EIG_VARIANT=2 / 3: the round-2 choice)
-  if (h->sweep_variant == 0 && h->eig_variant == 0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
+  if (h->sweep_variant != 1 && h->eig_variant == 0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
     const int nb = (int)ceil_div(n, 16);
 #define TR16(NBB) tridiag_reg16_kernel<NBB><<<1, 256, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
     switch (nb) {

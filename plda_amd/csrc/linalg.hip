@@ -1066,10 +1066,49 @@ __global__ __launch_bounds__(256) void spd_inverse_sweep16_kernel(const double *
     }
 }
 
+// spd_inverse_mfma_kernel<NT>: the sweep in blocks of 16 pivots on the fp64 matrix cores (its own file so that
+// scripts/probe/sweep_mfma_probe.hip can build it with phase clocks)
+#define SWM_CLOCK(i)
+#define SWM_PCLOCK(i)
+#include "sweep_mfma.inc"
+#undef SWM_CLOCK
+#undef SWM_PCLOCK
+
 // out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: W[g]^-1 with batch stride `stride_in`); D <= 256
 int spd_inverse_small(plda_handle *h, const double *W, const double *B, const double *gn, int D, int ldin,
                       int64_t stride_in, double *out, int ldout, int64_t stride_out, int *dflag, int batch) {
-  if (h->sweep_variant == 0) {     // four waves, 16 x 16 ownership (PLDA_SWEEP_VARIANT=1: the 16-wave kernel of round 2)
+  if (h->sweep_variant == 0 && D > 64 && D <= 256) {   // block sweeps on the matrix cores
+    const int nt = (int)ceil_div(D, 16);
+#define SWM(NTT)                                                                                                    \
+  do {                                                                                                              \
+    constexpr size_t lds = (size_t)(3 * NTT * 272 + 4 * 272 + 128) * 8;                                              \
+    if (!h->sweep_mfma_attr[NTT]) {                                                                                 \
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NTT>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+      h->sweep_mfma_attr[NTT] = true;                                                                               \
+    }                                                                                                               \
+    spd_inverse_mfma_kernel<NTT><<<batch, 1024, lds, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout,         \
+                                                                  stride_out, dflag);                                \
+  } while (0)
+    switch (nt) {
+      case 5: SWM(5); break;
+      case 6: SWM(6); break;
+      case 7: SWM(7); break;
+      case 8: SWM(8); break;
+      case 9: SWM(9); break;
+      case 10: SWM(10); break;
+      case 11: SWM(11); break;
+      case 12: SWM(12); break;
+      case 13: SWM(13); break;
+      case 14: SWM(14); break;
+      case 15: SWM(15); break;
+      default: SWM(16); break;
+    }
+#undef SWM
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
+  if (h->sweep_variant == 0 || h->sweep_variant == 2) {     // four waves, 16 x 16 ownership (2: at every size; 1: the 16-wave kernel of round 2)
     const int nb16 = (int)ceil_div(D, 16);
 #define SW16(NBB)                                                                                             \
   spd_inverse_sweep16_kernel<NBB><<<batch, 256, 0, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout, \

@@ -422,6 +422,15 @@ class MPlda(object):
         self._ck(self._lib.plda_sym_eig(self._h, _ptr(G), d, int(method), _ptr(lam), _ptr(vec), C.byref(used)))
         return lam, vec, used.value
 
+    def spd_inverse(self, A):
+        """Inverse of a symmetric positive definite matrix by the E-step's kernels (diagnostics / tests)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("spd_inverse: square matrix expected")
+        out = np.empty_like(A)
+        self._ck(self._lib.plda_spd_inverse(self._h, _ptr(A), A.shape[0], _ptr(out)))
+        return out
+
     def profile_enable(self, on=True):
         self._ck(self._lib.plda_profile_enable(self._h, 1 if on else 0))
 
