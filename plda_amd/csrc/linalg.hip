@@ -1081,7 +1081,7 @@ int spd_inverse_small(plda_handle *h, const double *W, const double *B, const do
     const int nt = (int)ceil_div(D, 16);
 #define SWM(NTT)                                                                                                    \
   do {                                                                                                              \
-    constexpr size_t lds = (size_t)(3 * NTT * 272 + 4 * 272 + 128) * 8;                                              \
+    constexpr size_t lds = (size_t)((3 * NTT + 8) * 272 + 128) * 8;                                              \
     if (!h->sweep_mfma_attr[NTT]) {                                                                                 \
       PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NTT>),                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \

@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
   hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
   hipMemset(dF, 0, 4);
   hipMemcpyToSymbol(HIP_SYMBOL(g_clock), &dC, sizeof(dC));
-  constexpr size_t lds = (size_t)(3 * NT * 272 + 4 * 272 + 128) * 8;
+  constexpr size_t lds = (size_t)((3 * NT + 8) * 272 + 128) * 8;
   hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
@@ -98,11 +98,11 @@ int main(int argc, char **argv) {
     }
   printf("D=%d kernel %.1f us (best of 20), residual %.2e; last run: %.1f us by the 100 MHz counter, %lld clock64 ticks (%.2f GHz)\n", D, best * 1e3, res,
          (c[129] - c[128]) * 0.01, c[131] - c[130], (c[131] - c[130]) / ((c[129] - c[128]) * 10.0));
-  const char *names[8] = {"", "A panel", "barrier 1", "B next cross", "barrier 2", "C update|pivot", "barrier 3", ""};
+  const char *names[8] = {"", "A panel | tile", "barrier 1", "U update|factor", "barrier 2", "", "", ""};
   printf("%-16s", "cycles");
   for (int w = 0; w < 16; w += (w < 12 ? 3 : 1)) printf(" wave%-6d", w);
   printf("\n");
-  for (int p = 1; p < 7; ++p) {
+  for (int p = 1; p < 5; ++p) {
     printf("%-16s", names[p]);
     for (int w = 0; w < 16; w += (w < 12 ? 3 : 1)) printf(" %10lld", c[w * 8 + p]);
     printf("\n");
