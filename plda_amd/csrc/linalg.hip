@@ -675,6 +675,51 @@ __global__ __launch_bounds__(256) void gemm_f64_panel_kernel(int M, int N, int K
   }
 }
 
+// The D x D x D products of the EM and of GetOutput (M, N, K <= 256): what they cost is not their 16 MFLOP but a
+// launch and a dependent chain -- the panel kernel above stages 2 x 51 KB per workgroup through LDS and then runs 50
+// MFMAs on every wave (1.3 us on their own), 7.5 us in all.  Here a workgroup owns ONE 16 x 16 tile and its four waves a
+// quarter of K each: the operand fragments go from global memory straight to the MFMA operand registers (all loads of a
+// wave in flight at once, no LDS stage, no barrier before the arithmetic), 13 MFMAs per wave at K = 200, and the four
+// partial tiles meet in 8 KB of LDS.  169 workgroups at D = 200.
+__global__ __launch_bounds__(256) void gemm_f64_tile16_kernel(int M, int N, int K, double alpha,
+                                                              const double *__restrict__ A, int64_t sam, int64_t sak,
+                                                              const double *__restrict__ B, int64_t sbk, int64_t sbn,
+                                                              double beta, double *__restrict__ C, int64_t ldc,
+                                                              int64_t strideA, int64_t strideB, int64_t strideC) {
+  __shared__ double part[4][256];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
+  A += (int64_t)blockIdx.z * strideA;
+  B += (int64_t)blockIdx.z * strideB;
+  C += (int64_t)blockIdx.z * strideC;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int kq = ((K + 15) / 16) * 4;                 // k per wave, a multiple of the MFMA's 4
+  const int k0 = wave * kq, k1 = min(K, k0 + kq);
+  const double *ap = A + (int64_t)min(m0 + fi, M - 1) * sam, *bp = B + (int64_t)min(n0 + fi, N - 1) * sbn;
+  double va[16], vb[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = k0 + 4 * s + fk;
+    const bool ok = k < k1;
+    va[s] = ok ? ap[(int64_t)k * sak] : 0.0;
+    vb[s] = ok ? bp[(int64_t)k * sbk] : 0.0;
+  }
+  f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 16; s += 2) {
+    if (k0 + 4 * s < k1) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[s], vb[s], acc0, 0, 0, 0);
+    if (k0 + 4 * s + 4 < k1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[s + 1], vb[s + 1], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][(fk + 4 * r) * 16 + fi] = acc0[r] + acc1[r];
+  __syncthreads();
+  const int row = m0 + (t >> 4), col = n0 + (t & 15);
+  if (row < M && col < N) {
+    const double x = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    double *c = C + (int64_t)row * ldc + col;
+    *c = alpha * x + (beta != 0.0 ? beta * *c : 0.0);
+  }
+}
+
 // batch > 1: `batch` independent products with operand strides (a stride of 0 shares the operand);
 // no split-K in that case -- the batch supplies the parallelism.
 int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t sam,
@@ -691,6 +736,15 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
       M <= 1024 && h->gemm64_variant != 2)
     return syrk_f64(h, (int)M, K, alpha, A, sak, kw, beta, C, ldc);
   const int64_t tiles = ceil_div(M, GB) * ceil_div(N, GB);
+  // one 16 x 16 tile per workgroup, K split over its waves: the small square products (PLDA_GEMM64_VARIANT=5: the panel kernel)
+  if (M <= 256 && N <= 256 && K <= 256 && !kw && h->gemm64_variant != 5 && h->gemm64_variant != 4) {
+    if (batch > 65535) return fail(h, PLDA_E_INVAL, "gemm_f64: batch %d too large", batch);
+    const dim3 tgrid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)batch);
+    gemm_f64_tile16_kernel<<<tgrid, 256, 0, h->stream>>>((int)M, (int)N, (int)K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc,
+                                                         strideA, strideB, strideC);
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
   // the panel kernel: every K <= 256, and deeper products whose 64 x 64 tiles would leave most of the chip idle
   if (M <= 1024 && N <= 1024 && !kw && (K <= 256 || (K <= 2048 && tiles * batch < 256)) && h->gemm64_variant != 4) {
     const int nb = (int)std::min<int64_t>(4, ceil_div(K, 64));
