@@ -286,11 +286,13 @@ __global__ void em_group_A_kernel(const double *__restrict__ W, const double *__
 // M-step from the per-group matrices (i <= j computes both (i,j) and (j,i), then symmetrises):
 //   W_stats = S + sum_g [ K_g Mx_g + C_g - n_g (QC_g + QC_g^T) + n_g^2 QCQ_g ]
 //   B_stats =     sum_g [ (K_g / n_g) Mx_g + n_g QCQ_g ]
-__global__ void em_group_mstep_kernel(const double *__restrict__ S, const double *__restrict__ Csum,
-                                      const double *__restrict__ Mx, const double *__restrict__ QC,
-                                      const double *__restrict__ QCQ, const double *__restrict__ gn,
+// next: the buffers of Mx and QCQ are free once this thread has read its two entries of them, and the next iteration
+// wants A_g = W + n_g B and a copy of B in exactly these buffers (the residual of its refinement step): written here
+// instead of by a launch of em_group_A_kernel.
+__global__ void em_group_mstep_kernel(const double *__restrict__ S, const double *__restrict__ Csum, double *Mx,
+                                      const double *__restrict__ QC, double *QCQ, const double *__restrict__ gn,
                                       const double *__restrict__ gk, int G, int D, double cntW, double cntB,
-                                      double *__restrict__ W, double *__restrict__ B) {
+                                      double *__restrict__ W, double *__restrict__ B, bool next) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D * D) return;
   const int i = idx / D, j = idx % D;
@@ -309,6 +311,12 @@ __global__ void em_group_mstep_kernel(const double *__restrict__ S, const double
   const double w = 0.5 * (wij / cntW + wji / cntW), b = 0.5 * (bij / cntB + bji / cntB);
   W[ij] = w; W[ji] = w;
   B[ij] = b; B[ji] = b;
+  if (next)
+    for (int g = 0; g < G; ++g) {
+      const double a = fma(gn[g], b, w);
+      Mx[g * DD + ij] = a; Mx[g * DD + ji] = a;
+      QCQ[g * DD + ij] = b; QCQ[g * DD + ji] = b;
+    }
 }
 
 __global__ void set_identity2_kernel(double *W, double *B, int D) {
@@ -591,14 +599,18 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       // made of O(1) numbers, so the step restores that block; what it adds in the tiny directions is multiplied
       // by the tiny parts of W and B afterwards.  Against a long-double EM (N = 149, D = 200, six iterations,
       // cond(W) = 3e8): W 3.5e-10 -> 3e-14, B 3.4e-8 -> 2e-13 (the reference's own formulation: 7e-13, 3e-10).
-      em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b1, b3);
-      PLDA_LAUNCH_CHECK(h);
+      // (b1 = A_g and b3 = B for the residual: written by the M-step of the previous iteration, D <= 256)
+      if (it == 0 || D > 256) {
+        em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b1, b3);
+        PLDA_LAUNCH_CHECK(h);
+      }
       PLDA_TRY(gemm_f64_batched(h, D, D, D, -1.0, Q, D, 1, sDD, b1, D, 1, sDD, nullptr, 1.0, b3, D, sDD, G));
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b3, D, 1, sDD, inv, D, 1, sDD, nullptr, 1.0, Q, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, W, D, 1, 0, Q, 1, D, sDD, nullptr, 0.0, b1, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, Q, D, 1, sDD, Cg, D, 1, sDD, nullptr, 0.0, QC, D, sDD, G));
+      // b1 = Mx = W Q^T and QC = Q C_g: independent, one launch
+      PLDA_TRY(gemm_f64_pair(h, D, D, D, W, D, 1, 0, Q, 1, D, sDD, b1, D, sDD, Q, D, 1, sDD, Cg, D, 1, sDD, QC, D, sDD, G));
       PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, QC, D, 1, sDD, Q, 1, D, sDD, nullptr, 0.0, b3, D, sDD, G));
-      em_group_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, b1, QC, b3, dgn, dgk, G, D, cntW, cntB, W, B);
+      em_group_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, b1, QC, b3, dgn, dgk, G, D, cntW, cntB, W, B,
+                                                        D <= 256 && it + 1 < iters);
       PLDA_LAUNCH_CHECK(h);
     }
     int hflag = 0;

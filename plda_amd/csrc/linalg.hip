@@ -681,16 +681,25 @@ __global__ __launch_bounds__(256) void gemm_f64_panel_kernel(int M, int N, int K
 // quarter of K each: the operand fragments go from global memory straight to the MFMA operand registers (all loads of a
 // wave in flight at once, no LDS stage, no barrier before the arithmetic), 13 MFMAs per wave at K = 200, and the four
 // partial tiles meet in 8 KB of LDS.  169 workgroups at D = 200.
-__global__ __launch_bounds__(256) void gemm_f64_tile16_kernel(int M, int N, int K, double alpha,
-                                                              const double *__restrict__ A, int64_t sam, int64_t sak,
-                                                              const double *__restrict__ B, int64_t sbk, int64_t sbn,
-                                                              double beta, double *__restrict__ C, int64_t ldc,
-                                                              int64_t strideA, int64_t strideB, int64_t strideC) {
+struct Tile16Operands {
+  double alpha, beta;
+  const double *A, *B;
+  double *C;
+  int64_t sam, sak, sbk, sbn, ldc, strideA, strideB, strideC;
+};
+// blockIdx.z < batch0: product z of the first set of operands, else product z - batch0 of the second (two independent
+// products of the same shape in one launch: gemm_f64_pair)
+__global__ __launch_bounds__(256) void gemm_f64_tile16_kernel(int M, int N, int K, Tile16Operands o0, Tile16Operands o1,
+                                                              int batch0) {
   __shared__ double part[4][256];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
-  A += (int64_t)blockIdx.z * strideA;
-  B += (int64_t)blockIdx.z * strideB;
-  C += (int64_t)blockIdx.z * strideC;
+  const bool second = (int)blockIdx.z >= batch0;
+  const Tile16Operands &o = second ? o1 : o0;
+  const int64_t z = second ? (int)blockIdx.z - batch0 : (int)blockIdx.z;
+  const double *__restrict__ A = o.A + z * o.strideA, *__restrict__ B = o.B + z * o.strideB;
+  double *__restrict__ C = o.C + z * o.strideC;
+  const int64_t sam = o.sam, sak = o.sak, sbk = o.sbk, sbn = o.sbn, ldc = o.ldc;
+  const double alpha = o.alpha, beta = o.beta;
   const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
   const int kq = ((K + 15) / 16) * 4;                 // k per wave, a multiple of the MFMA's 4
   const int k0 = wave * kq, k1 = min(K, k0 + kq);
@@ -740,8 +749,8 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
   if (M <= 256 && N <= 256 && K <= 256 && !kw && h->gemm64_variant != 5 && h->gemm64_variant != 4) {
     if (batch > 65535) return fail(h, PLDA_E_INVAL, "gemm_f64: batch %d too large", batch);
     const dim3 tgrid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)batch);
-    gemm_f64_tile16_kernel<<<tgrid, 256, 0, h->stream>>>((int)M, (int)N, (int)K, alpha, A, sam, sak, B, sbk, sbn, beta, C, ldc,
-                                                         strideA, strideB, strideC);
+    const Tile16Operands o{alpha, beta, A, B, C, sam, sak, sbk, sbn, ldc, strideA, strideB, strideC};
+    gemm_f64_tile16_kernel<<<tgrid, 256, 0, h->stream>>>((int)M, (int)N, (int)K, o, o, batch);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
   }
@@ -827,6 +836,28 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
              int64_t sak, const double *B, int64_t sbk, int64_t sbn, const double *kw, double beta,
              double *C, int64_t ldc) {
   return gemm_f64_batched(h, M, N, K, alpha, A, sam, sak, 0, B, sbk, sbn, 0, kw, beta, C, ldc, 0, 1);
+}
+
+// Two independent batched products of the same shape, C0 = A0 B0 and C1 = A1 B1 (alpha = 1, beta = 0; no k-weights), in ONE
+// launch where the small-product kernel applies (M, N, K <= 256: the EM's W Q^T and Q C_g), else one after the other.
+int gemm_f64_pair(plda_handle *h, int64_t M, int64_t N, int64_t K, const double *A0, int64_t sam0, int64_t sak0,
+                  int64_t strideA0, const double *B0, int64_t sbk0, int64_t sbn0, int64_t strideB0, double *C0,
+                  int64_t ldc0, int64_t strideC0, const double *A1, int64_t sam1, int64_t sak1, int64_t strideA1,
+                  const double *B1, int64_t sbk1, int64_t sbn1, int64_t strideB1, double *C1, int64_t ldc1,
+                  int64_t strideC1, int batch) {
+  if (M <= 256 && N <= 256 && K <= 256 && K > 0 && M > 0 && N > 0 && batch > 0 && 2 * batch <= 65535 &&
+      h->gemm64_variant != 5 && h->gemm64_variant != 4) {
+    const dim3 tgrid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)(2 * batch));
+    const Tile16Operands o0{1.0, 0.0, A0, B0, C0, sam0, sak0, sbk0, sbn0, ldc0, strideA0, strideB0, strideC0};
+    const Tile16Operands o1{1.0, 0.0, A1, B1, C1, sam1, sak1, sbk1, sbn1, ldc1, strideA1, strideB1, strideC1};
+    gemm_f64_tile16_kernel<<<tgrid, 256, 0, h->stream>>>((int)M, (int)N, (int)K, o0, o1, batch);
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
+  PLDA_TRY(gemm_f64_batched(h, M, N, K, 1.0, A0, sam0, sak0, strideA0, B0, sbk0, sbn0, strideB0, nullptr, 0.0, C0, ldc0,
+                            strideC0, batch));
+  return gemm_f64_batched(h, M, N, K, 1.0, A1, sam1, sak1, strideA1, B1, sbk1, sbn1, strideB1, nullptr, 0.0, C1, ldc1,
+                          strideC1, batch);
 }
 
 // fp64 reciprocal / reciprocal square root: hardware estimate refined by Newton steps to full
@@ -1128,40 +1159,51 @@ __global__ __launch_bounds__(256) void spd_inverse_sweep16_kernel(const double *
 #undef SWM_CLOCK
 #undef SWM_PCLOCK
 
-// out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: W[g]^-1 with batch stride `stride_in`); D <= 256
-int spd_inverse_small(plda_handle *h, const double *W, const double *B, const double *gn, int D, int ldin,
-                      int64_t stride_in, double *out, int ldout, int64_t stride_out, int *dflag, int batch) {
-  if (h->sweep_variant == 0 && D > 64 && D <= 256) {   // block sweeps on the matrix cores
-    const int nt = (int)ceil_div(D, 16);
+// mode 0: out = (W + gn B)^-1; mode 1: out = T, the inverse of the Cholesky factor of W (lower triangular); 64 < D <= 256
+static int spd_block_mfma(plda_handle *h, int mode, const double *W, const double *B, const double *gn, int D, int ldin,
+                          int64_t stride_in, double *out, int ldout, int64_t stride_out, int *dflag, int batch) {
+  const int nt = (int)ceil_div(D, 16);
 #define SWM(NTT)                                                                                                    \
   do {                                                                                                              \
-    constexpr size_t lds = (size_t)((3 * NTT + 8) * 272 + 128) * 8;                                              \
+    constexpr size_t lds = (size_t)((3 * NTT + 8) * 272 + 128) * 8;                                                 \
     if (!h->sweep_mfma_attr[NTT]) {                                                                                 \
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NTT>),                \
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NTT, 0>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NTT, 1>),             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
       h->sweep_mfma_attr[NTT] = true;                                                                               \
     }                                                                                                               \
-    spd_inverse_mfma_kernel<NTT><<<batch, 1024, lds, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout,         \
-                                                                  stride_out, dflag);                                \
+    if (mode == 0)                                                                                                  \
+      spd_inverse_mfma_kernel<NTT, 0><<<batch, 1024, lds, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout,    \
+                                                                       stride_out, dflag);                          \
+    else                                                                                                            \
+      spd_inverse_mfma_kernel<NTT, 1><<<batch, 1024, lds, h->stream>>>(W, B, gn, D, ldin, stride_in, out, ldout,    \
+                                                                       stride_out, dflag);                          \
   } while (0)
-    switch (nt) {
-      case 5: SWM(5); break;
-      case 6: SWM(6); break;
-      case 7: SWM(7); break;
-      case 8: SWM(8); break;
-      case 9: SWM(9); break;
-      case 10: SWM(10); break;
-      case 11: SWM(11); break;
-      case 12: SWM(12); break;
-      case 13: SWM(13); break;
-      case 14: SWM(14); break;
-      case 15: SWM(15); break;
-      default: SWM(16); break;
-    }
-#undef SWM
-    PLDA_LAUNCH_CHECK(h);
-    return PLDA_OK;
+  switch (nt) {
+    case 5: SWM(5); break;
+    case 6: SWM(6); break;
+    case 7: SWM(7); break;
+    case 8: SWM(8); break;
+    case 9: SWM(9); break;
+    case 10: SWM(10); break;
+    case 11: SWM(11); break;
+    case 12: SWM(12); break;
+    case 13: SWM(13); break;
+    case 14: SWM(14); break;
+    case 15: SWM(15); break;
+    default: SWM(16); break;
   }
+#undef SWM
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
+// out[g] = (W + gn[g] B)^-1 for g < batch (B == nullptr: W[g]^-1 with batch stride `stride_in`); D <= 256
+int spd_inverse_small(plda_handle *h, const double *W, const double *B, const double *gn, int D, int ldin,
+                      int64_t stride_in, double *out, int ldout, int64_t stride_out, int *dflag, int batch) {
+  if (h->sweep_variant == 0 && D > 64 && D <= 256)   // block sweeps on the matrix cores
+    return spd_block_mfma(h, 0, W, B, gn, D, ldin, stride_in, out, ldout, stride_out, dflag, batch);
   if (h->sweep_variant == 0 || h->sweep_variant == 2) {     // four waves, 16 x 16 ownership (2: at every size; 1: the 16-wave kernel of round 2)
     const int nb16 = (int)ceil_div(D, 16);
 #define SW16(NBB)                                                                                             \
@@ -1332,6 +1374,8 @@ __global__ void zero_block_kernel(double *__restrict__ dst, int ldd, int64_t str
 // (scripts/stress_case.py shape 150 257 4 6 0.2: 6.5e-4 against 6e-7 at cond(W) = 1.4e9).
 int whiten_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *T, int ldt, int64_t st,
                    double *scr, int64_t sscr, int *dflag, int batch) {
+  if (n > 64 && n <= 256 && h->sweep_variant == 0)     // Cholesky factor and its inverse in one kernel, on the matrix cores
+    return spd_block_mfma(h, 1, A, nullptr, nullptr, n, lda, sa, T, ldt, st, dflag, batch);
   if (n <= 256) {
     PLDA_TRY(chol_small(h, A, n, lda, sa, scr, n, sscr, dflag, batch));
     return tri_invert_ld(h, scr, sscr, T, n, ldt, st, batch);

@@ -76,13 +76,13 @@ int main(int argc, char **argv) {
   hipMemset(dF, 0, 4);
   hipMemcpyToSymbol(HIP_SYMBOL(g_clock), &dC, sizeof(dC));
   constexpr size_t lds = (size_t)((3 * NT + 8) * 272 + 128) * 8;
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&spd_inverse_mfma_kernel<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
   for (int rep = 0; rep < 20; ++rep) {
     hipMemset(dC, 0, 160 * 8);
     hipEventRecord(e0);
-    spd_inverse_mfma_kernel<NT><<<1, 1024, lds>>>(dA, nullptr, nullptr, D, D, 0, dX, D, 0, dF);
+    spd_inverse_mfma_kernel<NT, 0><<<1, 1024, lds>>>(dA, nullptr, nullptr, D, D, 0, dX, D, 0, dF);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
   }
