@@ -125,7 +125,7 @@ def end_to_end(eng, X, y, D, dout):
         eng.fit(X, yy, 10)
         t0 = time.perf_counter(); eng.fit(X, yy, 10); dt = time.perf_counter() - t0
         res["fit"] = {"rows": int(X.shape[0]), "ms": round(dt * 1e3, 2), "h2d_bytes": int(X.nbytes),
-                      "how": "liblda-style fit(X, y, 10) on NumPy arrays: np.unique label compaction on the host, upload through the pinned ring, statistics + EM + GetOutput"}
+                      "how": "liblda-style fit(X, y, 10) on NumPy arrays: label compaction on the host (counting, not sorting), upload through the pinned ring, statistics + EM + GetOutput"}
         eng.transform(X, yy)
         t0 = time.perf_counter(); tr = eng.transform(X, yy); dt = time.perf_counter() - t0
         res["transform"] = {"rows": int(X.shape[0]), "labels": len(tr), "ms": round(dt * 1e3, 2),

@@ -65,6 +65,24 @@ def _npz_path(path, for_load=False):
     return path
 
 
+def _compact_labels(Y):
+    """Labels -> dense 0..K-1 in ascending label order (what np.unique(return_inverse=True) gives), and K.  np.unique
+    sorts: 4.2 ms for 100k labels, more than the fit itself.  Labels are small integers in practice (the reference
+    indexes an array by them), so count instead: 0.2 ms, and already-dense labels pass through untouched."""
+    n = Y.shape[0]
+    top = int(Y.max())
+    if top < 16 * n + 1024:
+        signed = Y.view(np.int64)                     # (top < 2^63: same values)
+        present = np.bincount(signed, minlength=top + 1) > 0
+        k = int(np.count_nonzero(present))
+        if k == top + 1:
+            return Y, k
+        remap = np.cumsum(present, dtype=np.int64) - 1
+        return np.ascontiguousarray(remap[signed].astype(np.uint64)), k
+    uniq, inv = np.unique(Y, return_inverse=True)
+    return np.ascontiguousarray(inv.astype(np.uint64)), int(uniq.shape[0])
+
+
 class MPlda(object):
     """GPU-resident PLDA model + z-norm statistics (MPlda struct, pldamodule.cpp:27-34)."""
 
@@ -101,10 +119,9 @@ class MPlda(object):
         Y = _labels(y, n)
         # the reference indexes a VLA by label value (:88-92, quirk Q2): labels must be
         # dense 0..K-1.  Compacting with unique() is the same thing for dense labels.
-        uniq, inv = np.unique(Y, return_inverse=True)
-        if uniq.shape[0] == 1:
+        dense, k = _compact_labels(Y)
+        if k == 1:
             raise ValueError(_ERR_ONE_SPK)
-        dense = np.ascontiguousarray(inv.astype(np.uint64))
         rc = self._lib.plda_fit(self._h, _ptr(X), n, d, _ptr(dense), int(iters))
         if rc == N.PLDA_E_ONE_SPEAKER:
             raise ValueError(_ERR_ONE_SPK)

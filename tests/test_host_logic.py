@@ -144,3 +144,21 @@ def test_block_cyclic_rows_tile_exactly():
         assert (cover == 1).all(), (m, world, block)
         blk = -(-(block if block > 0 else 4096) // 256) * 256
         assert max(sizes) - min(sizes) <= max(blk, 256), (m, world, block, sizes)   # balanced to within one block
+
+
+def test_label_compaction_matches_unique():
+    """fit()'s host-side label compaction (counting for small integer labels, already-dense labels untouched, np.unique
+    for wide ones) gives what np.unique(return_inverse=True) gives: dense ids in ascending label order."""
+    from plda_amd.libplda import _compact_labels
+    rng = np.random.default_rng(5)
+    cases = [np.repeat(np.arange(50, dtype=np.uint64), 7),                              # dense, sorted
+             rng.permutation(np.repeat(np.arange(50, dtype=np.uint64), 7)),             # dense, shuffled
+             rng.choice(np.array([3, 17, 18, 400, 2000], np.uint64), 300),              # sparse small integers
+             rng.integers(0, 2 ** 63, 200, dtype=np.uint64) * np.uint64(2) + np.uint64(1),   # beyond int64: sort path
+             np.full(10, 7, np.uint64),                                                  # one speaker
+             np.array([2 ** 64 - 1, 0, 2 ** 64 - 1], np.uint64)]
+    for y in cases:
+        dense, k = _compact_labels(np.ascontiguousarray(y))
+        uniq, inv = np.unique(y, return_inverse=True)
+        assert k == uniq.shape[0]
+        assert dense.dtype == np.uint64 and np.array_equal(dense, inv.astype(np.uint64))
