@@ -439,6 +439,205 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ------------------------------------------------------------------------------------
+// Eight waves, the FULL matrix in registers (n <= 208: thread (ty, tx) of a 32 x 16 grid owns A[32a + ty][16b + tx], 91
+// doubles), ONE workgroup barrier per Householder step.  With both triangles stored p = A v is row sums only -- no
+// column sums across ty, no per-wave partials, no assembly phase -- and, as in the multi-workgroup kernel below, the
+// next column is not read out of the updated matrix but follows from what everyone can see: its owners publish
+// A[:, j + 1] as it stands beside p, and behind the step's barrier every wave forms for itself
+//     v . p,  w = tau p - beta v,  x' = A[:, j + 1] - v w_{j+1} - w v_{j+1}  (column j + 1 of the updated matrix)
+// into LDS (the eight waves write the same values), then applies the rank-2 update to its registers.  Costs the full
+// update (3 n^2 instead of 2 n^2 FMAs per step) and saves two of the three barriers, the cross-ty lane exchanges, the
+// partial-sum traffic and the p-assembly phase of the symmetric-storage kernel above.  (The same on FOUR waves needs
+// 169 doubles per thread: half of them live in AGPRs and every use pays two v_accvgpr moves -- 0.54 against 0.53 ms.)
+// The two triangles are updated by differently ordered FMAs and drift apart by an ulp per step; p is formed from rows.
+// ------------------------------------------------------------------------------------
+#ifndef TRF_CLOCK
+#define TRF_CLOCK(i)     // (phase clocks of scripts/probe/tridiag_full_probe.hip)
+#endif
+template <int NB, int NA>
+__global__ __launch_bounds__(512) void tridiag_full_kernel(const double *__restrict__ G, int n,
+                                                           const double *__restrict__ scale, double *__restrict__ dd,
+                                                           double *__restrict__ ee, double *__restrict__ Vh,
+                                                           double *__restrict__ tau) {
+  constexpr int NV = 16 * NB;                 // vector length, padded
+  constexpr int NVP = NV + 16;                // (32 NA may exceed it by one 16-block)
+  constexpr int NQ = (NV + 63) / 64;
+  static_assert(32 * NA <= NVP, "row blocks beyond the padded vector");
+  __shared__ double PS[2][NVP];               // p = A v
+  __shared__ double XN[2][NVP];               // column j + 1 before the step's update
+  __shared__ double VW[8][3][NVP];            // every wave's own v (two, alternating) and w: the fragment reads need no fix-ups
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4, lane = t & 63, wave = t >> 6;
+  const double sc = scale[0];
+  for (int q = t; q < NVP; q += 512) { PS[0][q] = PS[1][q] = 0.0; XN[0][q] = XN[1][q] = 0.0; }
+  for (int q = t; q < 24 * NVP; q += 512) (&VW[0][0][0])[q] = 0.0;
+  double *const ww = VW[wave][2];
+  double r[NA][NB];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = a * 32 + ty, j = b * 16 + tx;
+      r[a][b] = (i < n && j < n) ? G[(size_t)i * n + j] * sc : 0.0;
+    }
+  __syncthreads();
+  if (tx == 0) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) XN[1][a * 32 + ty] = r[a][0];     // column 0 (XN[1]: the slot "step -1" would have used)
+  }
+  __syncthreads();
+  // The reflector of a step is prepared where its column is made -- at the end of the step before, ahead of that step's
+  // rank-2 update, whose FMAs cover the chain wave sum -> rsqrt -> reciprocal -- and handed over in registers:
+  // alpha, v0, tau, and v itself in this wave's LDS copy VW[wave][j & 1].
+  double alpha, v0, tt;
+  auto reflector = [&](int j, const double (&xi)[NQ], double s2part) {   // xi: column j below the diagonal, this lane's entries
+    const double s2 = wave_sum_f64(s2part);
+    double x0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x0 = (lane + 64 * q == j + 1) ? xi[q] : x0;
+    x0 = readlane_f64(x0, (j + 1) & 63);
+    const bool skip = s2 == 0.0;            // column already tridiagonal (the same in every wave): H = I
+    const double nx2 = fma(x0, x0, s2);
+    const double nx = nx2 * dc_rsqrt(skip ? 1.0 : nx2);
+    alpha = skip ? x0 : (x0 >= 0.0 ? -nx : nx);
+    v0 = skip ? 0.0 : x0 - alpha;
+    tt = skip ? 0.0 : 2.0 * dc_rcp(fma(v0, v0, s2));
+    double *vnext = VW[wave][j & 1];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = lane + 64 * q;
+      if (i < NV) vnext[i] = i == j + 1 ? v0 : xi[q];
+    }
+  };
+  {
+    double xi[NQ], s2p = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = lane + 64 * q;
+      xi[q] = (i < NV && i > 0) ? XN[1][i] : 0.0;
+      s2p = i > 1 ? fma(xi[q], xi[q], s2p) : s2p;
+    }
+    reflector(0, xi, s2p);
+  }
+#ifdef TRF_PROBE_LOCALS
+  TRF_PROBE_LOCALS
+#endif
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto block = [&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;      // 16-column block of the pivot
+    constexpr int ka = kb / 2;                    // its 32-row block
+    for (int kl = 0; kl < 16; ++kl) {
+      const int j = kb * 16 + kl;
+      if (j >= n - 2) break;
+      const double *vw = VW[wave][j & 1];
+      double *ps = PS[j & 1], *xn = XN[j & 1];
+      TRF_CLOCK(0);
+      if (tx == kl && ty == (j & 31)) dd[j] = r[ka][kb];
+      wave_sync();                          // (v of this step: written by this wave at the end of the last one)
+      TRF_CLOCK(1);
+      // ---- p = A v: row sums over tx by DPP inside the 16-lane rows ----
+      {
+        double vc[NB];
+#pragma unroll
+        for (int b = kb; b < NB; ++b) vc[b] = vw[b * 16 + tx];
+        double myrow = 0.0;
+#pragma unroll
+        for (int a = ka; a < NA; ++a) {
+          double pr = 0.0;
+#pragma unroll
+          for (int b = kb; b < NB; ++b) pr = fma(r[a][b], vc[b], pr);
+          pr += dpp_f64<0xB1>(pr);
+          pr += dpp_f64<0x4E>(pr);
+          pr += dpp_f64<0x141>(pr);
+          pr += dpp_f64<0x140>(pr);
+          myrow = tx == a ? pr : myrow;
+        }
+        if (tx >= ka && tx < NA) ps[tx * 32 + ty] = myrow;
+      }
+      // ---- column j + 1 as it stands ----
+      if (tx == ((j + 1) & 15)) {
+        if (kl < 15) {
+#pragma unroll
+          for (int a = 0; a < NA; ++a) xn[a * 32 + ty] = r[a][kb];
+        } else if constexpr (kb + 1 < NB) {
+#pragma unroll
+          for (int a = 0; a < NA; ++a) xn[a * 32 + ty] = r[a][kb + 1];
+        }
+      }
+      TRF_CLOCK(2);
+      __syncthreads();
+      TRF_CLOCK(3);
+      // ---- every wave: v . p, w, the next column, its reflector ----
+      double vq[NQ], pq[NQ], vp = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = lane + 64 * q;
+        vq[q] = i < NV ? vw[i] : 0.0;
+        pq[q] = (i < NV && i > j) ? ps[i] : 0.0;
+        vp = fma(vq[q], pq[q], vp);
+      }
+      const double vtp = wave_sum_f64(vp);
+      const double beta = 0.5 * tt * tt * vtp;
+      const double vj1 = v0, ttj = tt, alphaj = alpha;
+      const double wj1 = fma(ttj, ps[j + 1], -beta * vj1);
+      double xi[NQ], s2p = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = lane + 64 * q;
+        xi[q] = 0.0;
+        if (i < NV) {
+          const double wi = fma(ttj, pq[q], -beta * vq[q]);
+          ww[i] = wi;
+          xi[q] = i > j + 1 ? fma(-wi, vj1, fma(-vq[q], wj1, xn[i])) : 0.0;
+          s2p = i > j + 2 ? fma(xi[q], xi[q], s2p) : s2p;
+          if (wave == 0 && i < n) Vh[(size_t)j * n + i] = vq[q];
+        }
+      }
+      if (t == 0) { ee[j] = alphaj; tau[j] = ttj; }
+      wave_sync();
+      TRF_CLOCK(4);
+      reflector(j + 1, xi, s2p);           // (in the same scheduling region as the update below)
+      // ---- A -= v w^T + w v^T (rows and columns up to j carry zeros in both vectors) ----
+      double vr[NA], wr[NA];
+#pragma unroll
+      for (int a = ka; a < NA; ++a) {
+        vr[a] = vw[a * 32 + ty];
+        wr[a] = ww[a * 32 + ty];
+      }
+#pragma unroll
+      for (int b = kb; b < NB; ++b) {
+        const double vcb = vw[b * 16 + tx], wcb = ww[b * 16 + tx];
+#pragma unroll
+        for (int a = ka; a < NA; ++a) r[a][b] = fma(-vr[a], wcb, fma(-wr[a], vcb, r[a][b]));
+      }
+      TRF_CLOCK(5);
+    }
+  };
+  tr16_blocks(block, std::make_integer_sequence<int, NB>{});
+#ifdef TRF_PROBE_END
+  TRF_PROBE_END
+#endif
+  // ---- the last 2 x 2 block ----
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = a * 32 + ty, j = b * 16 + tx;
+      const double v = r[a][b];
+      if (i == j && i < n && i >= n - 2) dd[i] = v;
+      if (n >= 2 && i == n - 1 && j == n - 2) ee[n - 2] = v;
+    }
+  if (t == 0) {
+    if (n >= 2) tau[n - 2] = 0.0;
+    tau[n - 1] = 0.0;
+    ee[n - 1] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // tridiagonalisation, rows dealt cyclically to W = ceil(n / 8) workgroups, n <= 2048 (above 1024 the row registers spill: correct, slow).  A row lives in the registers
 // of 32 lanes (element k in lane k % 32).  Step j, every workgroup: v, tau from column j (all hold it) ->
 // p_i = A_i . v for its rows -> publish p_i together with A[i][j+1] -> ONE all-gather -> w; column j+1 of the
@@ -1330,7 +1529,24 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   // else rows over ceil(n / 8) cooperating workgroups (PLDA_EIG_VARIANT=2 / 3 force one or the other)
   const bool reg_kernel = h->eig_variant == 2 ? n <= 256 : (h->eig_variant == 3 ? false : n <= 160);
   // round 3: the four-wave register kernel up to n = 224 (PLDA_SWEEP_VARIANT=1 or PLDA_EIG_VARIANT=2 / 3: the round-2 choice)
-  if (h->sweep_variant != 1 && h->eig_variant == 0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
+  if (h->sweep_variant == 0 && h->eig_variant == 0 && n > 32 && n <= 208) {   // full storage, one barrier per step (PLDA_SWEEP_VARIANT=2: the symmetric-storage kernel)
+    const int nb = (int)ceil_div(n, 16);
+#define TRF(NBB) tridiag_full_kernel<NBB, (NBB + 1) / 2><<<1, 512, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
+    switch (nb) {
+      case 3: TRF(3); break;
+      case 4: TRF(4); break;
+      case 5: TRF(5); break;
+      case 6: TRF(6); break;
+      case 7: TRF(7); break;
+      case 8: TRF(8); break;
+      case 9: TRF(9); break;
+      case 10: TRF(10); break;
+      case 11: TRF(11); break;
+      case 12: TRF(12); break;
+      default: TRF(13); break;
+    }
+#undef TRF
+  } else if (h->sweep_variant != 1 && h->eig_variant == 0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
     const int nb = (int)ceil_div(n, 16);
 #define TR16(NBB) tridiag_reg16_kernel<NBB><<<1, 256, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
     switch (nb) {
