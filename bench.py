@@ -453,8 +453,17 @@ def main():
                  "scores_per_rank_GB": round(out.numel() * 4 / 1e9, 2)}
     if world > 1 and not args.no_gather:
         try:   # the second leg must not cost the run its (already measured) main line
-            full = torch.empty((M1, Nt), dtype=torch.float32, device=dev)
-            el_g, _ = timed(True)
+            err_g = None
+            try:
+                full = torch.empty((M1, Nt), dtype=torch.float32, device=dev)
+                el_g, _ = timed(True)
+            except Exception as e:   # noqa: BLE001
+                err_g = "%s: %s" % (type(e).__name__, e)
+            # a rank that failed must not leave the others waiting in the object gathers below: agree first
+            okf = torch.tensor([0.0 if err_g else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if okf.item() == 0.0:
+                raise RuntimeError(err_g or "the gather leg failed on another rank")
             # after a gathered step every rank holds every row: bit patterns of the first block of every OTHER rank, as
             # this rank received them, against the owner's own copy
             def cks(a, b):
