@@ -203,6 +203,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_EIG_VARIANT")) h->eig_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EIG_DEBUG")) h->eig_debug = std::atoi(v);
     if (const char *v = std::getenv("PLDA_TRANSFORM_VARIANT")) h->transform_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_SORT_VARIANT")) h->sort_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_ZNORM_VARIANT")) h->znorm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
     if (const char *v = std::getenv("PLDA_HOST_VARIANT")) h->host_variant = std::atoi(v);

@@ -104,6 +104,7 @@ struct plda_handle {
 
   bool panel_attr_set[16] = {};
   int num_cus = 256;           // hipDeviceAttributeMultiprocessorCount (persistent grids)
+  int sort_variant = 0;        // PLDA_SORT_VARIANT=1: fit groups the rows by the radix sort always (0: by counting where the tables fit)
   int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass; 2: no tail launch (A/B arms)
   int gemm_variant = 0;
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)

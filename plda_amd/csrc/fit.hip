@@ -370,9 +370,118 @@ __global__ void dense_check_kernel(const int *__restrict__ offsets, int64_t K, i
   }
 }
 
+// ------------------------------------------------------------------------------------
+// The same grouping without a sort, for dense labels with K <= 8192 (round 3): the position of row r is
+//   offsets[l] + (rows of label l in the 1024-row chunks before r's) + (rows of label l before r inside its chunk),
+// all three from counting.  group_count_kernel: counts[l] and cnt[chunk][l] by atomics (sums: order does not matter);
+// scan: offsets; group_base_kernel: one thread per label walks down the chunks (cnt -> exclusive prefix + offsets[l])
+// and does the dense check; group_place_kernel: one WAVE per chunk ranks its rows in row order -- 64 at a time, the
+// lanes with the same label found by ballots over the label's bits, their common running count kept in the wave's own
+// LDS table (LDS operations of a wave execute in order) -- and writes perm.  Five launches and two memsets instead of
+// the two radix passes' eleven: 88 -> ~40 us at C2.  The result is the radix sort's, bit for bit.
+// ------------------------------------------------------------------------------------
+constexpr int GR_CHUNK = 1024;     // rows per chunk (one wave)
+constexpr int GR_KMAX = 8192;      // labels per LDS table: 4 waves x 8192 x 4 B = 128 KiB
+
+__global__ __launch_bounds__(256) void group_count_kernel(const uint64_t *__restrict__ labels, int64_t N, int64_t K,
+                                                          int *__restrict__ counts, int *__restrict__ cnt,
+                                                          int *__restrict__ bad) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  uint64_t l = labels[r];
+  if (l >= (uint64_t)K) { *bad = 1; l = 0; }          // (counted under label 0: every index downstream stays valid)
+  atomicAdd(counts + l, 1);
+  atomicAdd(cnt + (r / GR_CHUNK) * K + (int64_t)l, 1);
+}
+
+__global__ __launch_bounds__(256) void group_base_kernel(const int *__restrict__ offsets, int64_t K, int64_t nchunks,
+                                                         int *__restrict__ cnt, int *__restrict__ bad) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= K) return;
+  int run = offsets[l];
+  if (offsets[l + 1] == run) {
+    atomicOr(bad, 2);
+    atomicMin(bad + 1, (int)l);
+  }
+  int64_t c = 0;
+  for (; c + 8 <= nchunks; c += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = cnt[(c + u) * K + l];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { cnt[(c + u) * K + l] = run; run += v[u]; }
+  }
+  for (; c < nchunks; ++c) { const int v = cnt[c * K + l]; cnt[c * K + l] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void group_place_kernel(const uint64_t *__restrict__ labels, int64_t N, int64_t K,
+                                                          int nbits, const int *__restrict__ base, int64_t nchunks,
+                                                          uint32_t *__restrict__ perm) {
+  extern __shared__ int gr_table[];                   // [4 waves][K]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int *tab = gr_table + (size_t)wave * K;
+  for (int64_t q = lane; q < K; q += 64) tab[q] = 0;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wave;
+  if (chunk >= nchunks) return;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll 4
+  for (int it = 0; it < GR_CHUNK / 64; ++it) {
+    const int64_t r = chunk * GR_CHUNK + it * 64 + lane;
+    const bool valid = r < N;
+    uint64_t l64 = valid ? labels[r] : 0;
+    if (l64 >= (uint64_t)K) l64 = 0;
+    const int l = (int)l64;
+    unsigned long long peers = __ballot(valid);
+    for (int bit = 0; bit < nbits; ++bit) {
+      const bool one = (l >> bit) & 1;
+      const unsigned long long m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    const int rank = __popcll(peers & lt);
+    int before = 0;
+    if (valid && rank == 0) before = atomicAdd(tab + l, __popcll(peers));     // (LDS: in order inside the wave)
+    before = __shfl(before, valid ? (int)__builtin_ctzll(peers) : 0);
+    if (valid) perm[base[chunk * K + l] + before + rank] = (uint32_t)r;
+  }
+}
+
+static int group_by_counting(plda_handle *h, const uint64_t *dlabels, int64_t N, int64_t K, uint32_t **perm_out,
+                             int **offsets_out, int **defer_bad) {
+  const int64_t nchunks = ceil_div(N, (int64_t)GR_CHUNK);
+  PLDA_HIP(h, h->w[0].reserve((size_t)N * 4));                              // perm
+  PLDA_HIP(h, h->w[1].reserve((size_t)(K + 3) * 4 + 64));                   // counts -> offsets (+ bad flag, first unused label)
+  PLDA_HIP(h, h->w[2].reserve((size_t)nchunks * K * 4));                    // per-chunk counts -> bases
+  uint32_t *perm = h->w[0].as<uint32_t>();
+  int *offsets = h->w[1].as<int>(), *bad = offsets + K + 1, *cnt = h->w[2].as<int>();
+  PLDA_HIP(h, hipMemsetAsync(offsets, 0, (size_t)(K + 2) * 4, h->stream));
+  PLDA_HIP(h, hipMemsetAsync(bad + 1, 0x7f, 4, h->stream));
+  PLDA_HIP(h, hipMemsetAsync(cnt, 0, (size_t)nchunks * K * 4, h->stream));
+  group_count_kernel<<<(unsigned)ceil_div(N, 256), 256, 0, h->stream>>>(dlabels, N, K, offsets, cnt, bad);
+  scan_kernel<<<1, 1024, 0, h->stream>>>(offsets, K + 1);
+  group_base_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, h->stream>>>(offsets, K, nchunks, cnt, bad);
+  int nbits = 1;
+  while ((1ll << nbits) < K) nbits++;
+  const size_t lds = (size_t)4 * K * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&group_place_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GR_KMAX * (int)sizeof(int)));
+    attr_set = true;
+  }
+  group_place_kernel<<<(unsigned)ceil_div(nchunks, 4), 256, lds, h->stream>>>(dlabels, N, K, nbits, cnt, nchunks, perm);
+  PLDA_LAUNCH_CHECK(h);
+  *defer_bad = bad;
+  *perm_out = perm;
+  *offsets_out = offsets;
+  return PLDA_OK;
+}
+
 static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int64_t K, uint32_t **perm_out,
                          int **offsets_out, int **defer_bad = nullptr) {
   if (N >= (1ll << 31)) return fail(h, PLDA_E_INVAL, "fit: N too large");
+  // counting instead of sorting where its tables fit (PLDA_SORT_VARIANT=1: the radix sort always)
+  if (defer_bad && K <= GR_KMAX && ceil_div(N, (int64_t)GR_CHUNK) * K <= (64ll << 20) && h->sort_variant == 0)
+    return group_by_counting(h, dlabels, N, K, perm_out, offsets_out, defer_bad);
   const int nblocks = (int)ceil_div(N, RS_CHUNK);
   PLDA_HIP(h, h->w[0].reserve((size_t)N * 4 * 4));                  // keys a/b, vals a/b
   PLDA_HIP(h, h->w[1].reserve((size_t)(K + 3) * 4 + 64));          // counts -> offsets (+ bad flag, first unused label)

@@ -420,3 +420,28 @@ def test_fit_recovers_a_generating_two_covariance_model():
     T = m["transform"]
     assert np.abs(T @ Wt @ T.T - np.eye(d)).max() < 0.1
     assert np.abs(T @ Bt @ T.T - np.diag(ref_psi)).max() < 0.15 * ref_psi.max()
+
+
+@pytest.mark.gpu
+def test_grouping_by_counting_is_the_radix_sort(monkeypatch):
+    """fit groups the rows by label by counting (K <= 8192) or by the radix sort (PLDA_SORT_VARIANT=1, and any larger
+    K): the same permutation, so the same sums in the same order -- statistics and model bit for bit; ragged chunk
+    (N not a multiple of 1024), skewed counts, one label filling several chunks."""
+    from plda_amd import MPlda
+    rng = np.random.default_rng(21)
+    for (n, d, k) in ((5000, 24, 37), (70001, 16, 5000), (3000, 8, 2)):
+        y = rng.integers(0, k, n).astype(np.uint64)
+        y[:k] = np.arange(k, dtype=np.uint64)            # every label present
+        if k > 2:
+            y[rng.random(n) < 0.3] = 1                   # one label with ~30 % of the rows
+        x = rng.standard_normal((n, d)) + 0.3 * rng.standard_normal((k, d))[y.astype(np.int64)]
+        res = []
+        for variant in ("0", "1"):
+            monkeypatch.setenv("PLDA_SORT_VARIANT", variant)
+            eng = MPlda(0)
+            eng.fit(x, y, 2)
+            st = eng.fit_internals()
+            m = eng.get_model()
+            res.append((st["means"], st["counts"], st["scatter"], m["transform"], m["psi"]))
+        for a, b in zip(*res):
+            assert np.array_equal(a, b)
