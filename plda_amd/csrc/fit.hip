@@ -371,7 +371,7 @@ __global__ void dense_check_kernel(const int *__restrict__ offsets, int64_t K, i
 }
 
 // ------------------------------------------------------------------------------------
-// The same grouping without a sort, for dense labels with K <= 8192 (round 3): the position of row r is
+// The same grouping without a sort, for dense labels with K <= 32768 (round 3): the position of row r is
 //   offsets[l] + (rows of label l in the 1024-row chunks before r's) + (rows of label l before r inside its chunk),
 // all three from counting.  group_count_kernel: counts[l] and cnt[chunk][l] by atomics (sums: order does not matter);
 // scan: offsets; group_base_kernel: one thread per label walks down the chunks (cnt -> exclusive prefix + offsets[l])
@@ -381,7 +381,7 @@ __global__ void dense_check_kernel(const int *__restrict__ offsets, int64_t K, i
 // the two radix passes' eleven: 88 -> ~40 us at C2.  The result is the radix sort's, bit for bit.
 // ------------------------------------------------------------------------------------
 constexpr int GR_CHUNK = 1024;     // rows per chunk (one wave)
-constexpr int GR_KMAX = 8192;      // labels per LDS table: 4 waves x 8192 x 4 B = 128 KiB
+constexpr int GR_KMAX = 32768;     // labels per LDS table: 128 KiB hold 4 / 2 / 1 waves' tables at K <= 8192 / 16384 / 32768
 
 __global__ __launch_bounds__(256) void group_count_kernel(const uint64_t *__restrict__ labels, int64_t N, int64_t K,
                                                           int *__restrict__ counts, int *__restrict__ cnt,
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(256) void group_base_kernel(const int *__restrict__
 __global__ __launch_bounds__(256) void group_place_kernel(const uint64_t *__restrict__ labels, int64_t N, int64_t K,
                                                           int nbits, const int *__restrict__ base, int64_t nchunks,
                                                           uint32_t *__restrict__ perm) {
-  extern __shared__ int gr_table[];                   // [4 waves][K]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ int gr_table[];                   // [waves of the workgroup][K]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int *tab = gr_table + (size_t)wave * K;
   for (int64_t q = lane; q < K; q += 64) tab[q] = 0;
-  const int64_t chunk = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t chunk = (int64_t)blockIdx.x * nw + wave;
   if (chunk >= nchunks) return;
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll 4
@@ -461,14 +461,15 @@ static int group_by_counting(plda_handle *h, const uint64_t *dlabels, int64_t N,
   group_base_kernel<<<(unsigned)ceil_div(K, 256), 256, 0, h->stream>>>(offsets, K, nchunks, cnt, bad);
   int nbits = 1;
   while ((1ll << nbits) < K) nbits++;
-  const size_t lds = (size_t)4 * K * sizeof(int);
+  const int nw = K <= 8192 ? 4 : K <= 16384 ? 2 : 1;          // waves (chunks) per workgroup: their tables share 128 KiB
+  const size_t lds = (size_t)nw * K * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&group_place_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GR_KMAX * (int)sizeof(int)));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, GR_KMAX * (int)sizeof(int)));
     attr_set = true;
   }
-  group_place_kernel<<<(unsigned)ceil_div(nchunks, 4), 256, lds, h->stream>>>(dlabels, N, K, nbits, cnt, nchunks, perm);
+  group_place_kernel<<<(unsigned)ceil_div(nchunks, (int64_t)nw), 64 * nw, lds, h->stream>>>(dlabels, N, K, nbits, cnt, nchunks, perm);
   PLDA_LAUNCH_CHECK(h);
   *defer_bad = bad;
   *perm_out = perm;

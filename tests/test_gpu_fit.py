@@ -424,12 +424,12 @@ def test_fit_recovers_a_generating_two_covariance_model():
 
 @pytest.mark.gpu
 def test_grouping_by_counting_is_the_radix_sort(monkeypatch):
-    """fit groups the rows by label by counting (K <= 8192) or by the radix sort (PLDA_SORT_VARIANT=1, and any larger
+    """fit groups the rows by label by counting (K <= 32768: 4, 2 or 1 waves per workgroup) or by the radix sort (PLDA_SORT_VARIANT=1, and any larger
     K): the same permutation, so the same sums in the same order -- statistics and model bit for bit; ragged chunk
     (N not a multiple of 1024), skewed counts, one label filling several chunks."""
     from plda_amd import MPlda
     rng = np.random.default_rng(21)
-    for (n, d, k) in ((5000, 24, 37), (70001, 16, 5000), (3000, 8, 2)):
+    for (n, d, k) in ((5000, 24, 37), (70001, 16, 5000), (3000, 8, 2), (60000, 8, 12000), (70000, 8, 20000)):
         y = rng.integers(0, k, n).astype(np.uint64)
         y[:k] = np.arange(k, dtype=np.uint64)            # every label present
         if k > 2:
