@@ -198,6 +198,15 @@ int plda_trace_read(plda_handle *h, char *json, int64_t cap, int32_t reset);
  * method or PLDA_E_NUMERIC.  *method_used (nullable) reports 1 or 2. */
 int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, double *eigenvalues,
                  double *eigenvectors, int32_t *method_used);
+/* The fp64 GEMM behind fit and GetOutput on its own (diagnostics and tests; the reference reaches its counterpart,
+ * ATLAS dgemm, only through Kaldi inside pldamodule.cpp:76-106).  `batch` products C_b = alpha op(A_b) op(B_b) + beta C_b,
+ * host pointers, row-major: A_b is [M,K] (transA = 0) or [K,M] (transA = 1), B_b is [K,N] or [N,K], C_b [M,N]; operands
+ * are stored back to back.  kw (nullable, batch = 1 only): K weights folded into the contraction, sum_k w_k a_mk b_kn.
+ * The dispatch is the product's: one 16 x 16 tile per workgroup for M, N, K <= 256, the panel kernel for deeper
+ * small products, 64 x 64 / 128 x 128 tiles with split-K above. */
+int plda_gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int32_t transA,
+                  const double *B, int32_t transB, const double *kw, double beta, double *C, int32_t batch);
+
 /* The SPD inverse of the EM's E-step on its own (diagnostics and tests; the reference reaches it only through
  * PldaEstimator::GetStatsFromClassMeans, Kaldi ivector/plda.cc:436-447 -> SpMatrix::Invert).  A [D,D] row-major
  * symmetric positive definite, host pointers; inverse [D,D].  D <= 64: scalar sweep operator in registers,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "plda_profile_timeline": (C.c_int, [_vp, _vp, _i64]),
     "plda_sym_eig": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "plda_spd_inverse": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "plda_gemm_f64": (C.c_int, [_vp, _i64, _i64, _i64, C.c_double, _vp, _i32, _vp, _i32, _vp, C.c_double, _vp, _i32]),
     "plda_trace_enable": (C.c_int, [_vp, _i32]),
     "plda_trace_read": (C.c_int, [_vp, _vp, _i64, _i32]),
     "plda_score_last_shape": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),

@@ -804,6 +804,36 @@ int plda_profile_timeline(plda_handle *h, uint64_t *out, int64_t cap_words) {
   });
 }
 
+int plda_gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int32_t transA,
+                  const double *B, int32_t transB, const double *kw, double beta, double *C, int32_t batch) {
+  return guarded(h, "plda_gemm_f64", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || (kw && batch != 1))
+      return fail(h, PLDA_E_INVAL, "gemm_f64: bad argument");
+    PLDA_TRY(set_device(h));
+    const size_t nA = (size_t)M * K, nB = (size_t)K * N, nC = (size_t)M * N;
+    Tmp dA, dB, dC, dW;
+    PLDA_HIP(h, dA.alloc(nA * batch * 8));
+    PLDA_HIP(h, dB.alloc(nB * batch * 8));
+    PLDA_HIP(h, dC.alloc(nC * batch * 8));
+    PLDA_HIP(h, hipMemcpyAsync(dA.p, A, nA * batch * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dB.p, B, nB * batch * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dC.p, C, nC * batch * 8, hipMemcpyHostToDevice, h->stream));
+    if (kw) {
+      PLDA_HIP(h, dW.alloc((size_t)K * 8));
+      PLDA_HIP(h, hipMemcpyAsync(dW.p, kw, (size_t)K * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    // element (m, k) of op(A): m * sam + k * sak; element (k, n) of op(B): k * sbk + n * sbn
+    const int64_t sam = transA ? 1 : K, sak = transA ? M : 1, sbk = transB ? 1 : N, sbn = transB ? K : 1;
+    PLDA_TRY(gemm_f64_batched(h, M, N, K, alpha, dA.as<double>(), sam, sak, (int64_t)nA, dB.as<double>(), sbk, sbn, (int64_t)nB,
+                              kw ? dW.as<double>() : nullptr, beta, dC.as<double>(), N, (int64_t)nC, batch));
+    PLDA_HIP(h, hipMemcpyAsync(C, dC.p, nC * batch * 8, hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return PLDA_OK;
+  });
+}
+
 int plda_spd_inverse(plda_handle *h, const double *A, int32_t D, double *inverse) {
   return guarded(h, "plda_spd_inverse", [&]() -> int {
     if (!h) return PLDA_E_INVAL;

@@ -439,6 +439,22 @@ class MPlda(object):
         self._ck(self._lib.plda_sym_eig(self._h, _ptr(G), d, int(method), _ptr(lam), _ptr(vec), C.byref(used)))
         return lam, vec, used.value
 
+    def gemm_f64(self, A, B, alpha=1.0, beta=0.0, C_in=None, transA=False, transB=False, kw=None):
+        """alpha op(A) op(B) + beta C by the engine's fp64 GEMM (diagnostics / tests); A, B 2-D, or 3-D for a batch."""
+        A = np.ascontiguousarray(A, np.float64); B = np.ascontiguousarray(B, np.float64)
+        batch = A.shape[0] if A.ndim == 3 else 1
+        a2, b2 = A.shape[-2:], B.shape[-2:]
+        m, k = (a2[1], a2[0]) if transA else a2
+        k2, n = (b2[1], b2[0]) if transB else b2
+        if k != k2 or (B.ndim == 3) != (A.ndim == 3) or (B.ndim == 3 and B.shape[0] != batch):
+            raise ValueError("gemm_f64: shapes disagree")
+        shape = (batch, m, n) if A.ndim == 3 else (m, n)
+        out = np.zeros(shape) if C_in is None else np.ascontiguousarray(C_in, np.float64).reshape(shape).copy()
+        w = None if kw is None else np.ascontiguousarray(kw, np.float64)
+        self._ck(self._lib.plda_gemm_f64(self._h, m, n, k, float(alpha), _ptr(A), int(transA), _ptr(B), int(transB),
+                                         _ptr(w) if w is not None else None, float(beta), _ptr(out), batch))
+        return out
+
     def spd_inverse(self, A):
         """Inverse of a symmetric positive definite matrix by the E-step's kernels (diagnostics / tests)."""
         A = np.ascontiguousarray(A, dtype=np.float64)
