@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 template <int NB, int NA>
 __global__ __launch_bounds__(512) void tridiag_full_kernel(const double *__restrict__ G, int n,
-                                                           const double *__restrict__ scale, double *__restrict__ dd,
+                                                           double *__restrict__ scale, double *__restrict__ dd,
                                                            double *__restrict__ ee, double *__restrict__ Vh,
-                                                           double *__restrict__ tau) {
+                                                           double *__restrict__ tau, int *__restrict__ flag) {
   constexpr int NV = 16 * NB;                 // vector length, padded
   constexpr int NVP = NV + 16;                // (32 NA may exceed it by one 16-block)
   constexpr int NQ = (NV + 63) / 64;
@@ -467,11 +467,44 @@ __global__ __launch_bounds__(512) void tridiag_full_kernel(const double *__restr
   __shared__ double XN[2][NVP];               // column j + 1 before the step's update
   __shared__ double VW[8][3][NVP];            // every wave's own v (two, alternating) and w: the fragment reads need no fix-ups
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4, lane = t & 63, wave = t >> 6;
-  const double sc = scale[0];
+  __shared__ double amax_s[8];
+  __shared__ int bad_s;
   for (int q = t; q < NVP; q += 512) { PS[0][q] = PS[1][q] = 0.0; XN[0][q] = XN[1][q] = 0.0; }
   for (int q = t; q < 24 * NVP; q += 512) (&VW[0][0][0])[q] = 0.0;
   double *const ww = VW[wave][2];
+  if (t == 0) bad_s = 0;
   double r[NA][NB];
+  // the scaling of the input to [1, 2) (eig_absmax_kernel + eig_scale_kernel of the other paths) happens here, where
+  // the matrix is loaded anyway: two launches and a memset fewer in front of the kernel
+  double amax = 0.0;
+  bool nonfinite = false;
+  for (int q = t; q < n * n; q += 512) {      // (a pass of its own: with the maximum taken from the register copy the
+    const double x = fabs(G[q]);              //  loads and the scaling pull apart and the matrix spills, 612 bytes a lane)
+    if (!(x <= 1.7976931348623157e308)) nonfinite = true;   // NaN or inf
+    amax = fmax(amax, x);
+  }
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
+  __syncthreads();
+  if (lane == 0) amax_s[wave] = amax;
+  if (nonfinite) bad_s = 1;
+  __syncthreads();
+  double sc = 1.0;
+  {
+    double m = amax_s[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmax(m, amax_s[w]);
+    const bool bad = bad_s != 0 || *flag != 0;
+    if (m > 0.0 && !bad) {
+      int ex;
+      (void)frexp(m, &ex);          // m = f 2^ex, f in [0.5, 1)
+      sc = ldexp(1.0, 1 - ex);      // m sc in [1, 2)
+    }
+    if (t == 0) {
+      if (bad_s) atomicOr(flag, 4);
+      scale[0] = sc;
+      scale[1] = 1.0 / sc;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -1521,17 +1554,20 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   double *Tg = reinterpret_cast<double *>(rots + vec);   // compact-WY T blocks: ceil((n - 2) / 8) x 64 doubles
   PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
   TraceScope ts(h, "getoutput.eig.tridiagonalise", 4.0 / 3.0 * (double)n * n * n, 1);
-  PLDA_HIP(h, hipMemsetAsync(scale + 2, 0, 8, h->stream));   // running max |g_ij| (as bits)
-  eig_absmax_kernel<<<(unsigned)std::min<int64_t>(ceil_div((int64_t)DD, 1024), 128), 256, 0, h->stream>>>(
-      G, n, reinterpret_cast<unsigned long long *>(scale + 2), flag);
-  eig_scale_kernel<<<1, 1, 0, h->stream>>>(reinterpret_cast<unsigned long long *>(scale + 2), scale, flag);
+  const bool full_kernel = h->sweep_variant == 0 && h->eig_variant == 0 && n > 32 && n <= 208;   // (scales its input itself)
+  if (!full_kernel) {
+    PLDA_HIP(h, hipMemsetAsync(scale + 2, 0, 8, h->stream));   // running max |g_ij| (as bits)
+    eig_absmax_kernel<<<(unsigned)std::min<int64_t>(ceil_div((int64_t)DD, 1024), 128), 256, 0, h->stream>>>(
+        G, n, reinterpret_cast<unsigned long long *>(scale + 2), flag);
+    eig_scale_kernel<<<1, 1, 0, h->stream>>>(reinterpret_cast<unsigned long long *>(scale + 2), scale, flag);
+  }
   // tridiagonalisation: one workgroup with the matrix in registers while that fits without spilling (n <= 160),
   // else rows over ceil(n / 8) cooperating workgroups (PLDA_EIG_VARIANT=2 / 3 force one or the other)
   const bool reg_kernel = h->eig_variant == 2 ? n <= 256 : (h->eig_variant == 3 ? false : n <= 160);
   // round 3: the four-wave register kernel up to n = 224 (PLDA_SWEEP_VARIANT=1 or PLDA_EIG_VARIANT=2 / 3: the round-2 choice)
-  if (h->sweep_variant == 0 && h->eig_variant == 0 && n > 32 && n <= 208) {   // full storage, one barrier per step (PLDA_SWEEP_VARIANT=2: the symmetric-storage kernel)
+  if (full_kernel) {   // full storage, one barrier per step (PLDA_SWEEP_VARIANT=2: the symmetric-storage kernel)
     const int nb = (int)ceil_div(n, 16);
-#define TRF(NBB) tridiag_full_kernel<NBB, (NBB + 1) / 2><<<1, 512, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
+#define TRF(NBB) tridiag_full_kernel<NBB, (NBB + 1) / 2><<<1, 512, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau, flag)
     switch (nb) {
       case 3: TRF(3); break;
       case 4: TRF(4); break;

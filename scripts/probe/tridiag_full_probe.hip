@@ -35,7 +35,8 @@ int main() {
       const double x = ((s >> 11) * (1.0 / 9007199254740992.0)) - 0.5;
       A[(size_t)i * n + j] = A[(size_t)j * n + i] = x;
     }
-  double *dA, *dscale, *dd, *ee, *Vh, *tau; long long *dC;
+  double *dA, *dscale, *dd, *ee, *Vh, *tau; long long *dC; int *dflag;
+  hipMalloc(&dflag, 4); hipMemset(dflag, 0, 4);
   hipMalloc(&dA, A.size() * 8); hipMalloc(&dscale, 64); hipMalloc(&dd, n * 8); hipMalloc(&ee, n * 8);
   hipMalloc(&Vh, A.size() * 8); hipMalloc(&tau, n * 8); hipMalloc(&dC, 64 * 8);
   const double one = 1.0;
@@ -46,7 +47,7 @@ int main() {
   float best = 1e9;
   for (int rep = 0; rep < 10; ++rep) {
     hipEventRecord(e0);
-    tridiag_full_kernel<13, 7><<<1, 512>>>(dA, n, dscale, dd, ee, Vh, tau);
+    tridiag_full_kernel<13, 7><<<1, 512>>>(dA, n, dscale, dd, ee, Vh, tau, dflag);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
   }
