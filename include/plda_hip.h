@@ -28,7 +28,10 @@
  *  - there is NO CPU fallback: without a usable gfx950 device plda_create fails.
  *  - feature dimension: 1 ... 2048 (plda_fit*, plda_lda_fit*, plda_sym_eig return PLDA_E_INVAL above).  The
  *    reference has no cap (its own tests stop at 1024, tests/pldatest.py:55); the engine's is the direct eigensolver's
- *    (one workgroup per 8 rows, all 256 CUs at 2048).  INTEGRATION.md, "Limits".
+ *    (one workgroup per 8 rows, all 256 CUs at 2048).  Above 1024 ONLY that solver exists: it needs ceil(D/8) co-resident
+ *    workgroups, so on a device that exposes fewer CUs (CU masking, a partitioned GPU) a fit / GetOutput / plda_sym_eig
+ *    with D in (1024, 2048] returns PLDA_E_INVAL with a message that says so, and plda_sym_eig(method = 1, the block
+ *    Jacobi solver) is rejected above 1024 at the boundary.  INTEGRATION.md, "Limits".
  */
 #ifndef PLDA_HIP_H_
 #define PLDA_HIP_H_
@@ -162,9 +165,14 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
  * utterances, scoring/scorePLDA.py:302-318): plda_score_prepare_dev packs the test side once -- fp64 -> k-quad packed
  * fp32 (+ V*V when enrol counts differ: mixed_counts != 0; else the column biases for n_uniform) -- and later
  * plda_score_matrix_dev / _sharded_dev calls with the SAME dV, Nt, model and kind of enrol counts skip that work (C3:
- * 2.1 of 72 ms per call).  The caller promises that the rows behind dV do not change meanwhile; a different test side,
- * a model change (fit, set_model, truncate, smooth) or plda_score_unprepare end the reuse.  Test sides whose packed
- * form would reach 4 GiB are refused (such calls are scored in column blocks, each packed per call). */
+ * 2.1 of 72 ms per call).  The cache is keyed on (dV, Nt, model epoch, kind of counts) AND guarded by a content
+ * fingerprint of 64 rows spread over the set (first and last included), taken at prepare time: a reusing call recomputes
+ * it (one small kernel + a stream synchronisation, ~30 us) and returns PLDA_E_INVAL ("fingerprint") when the rows behind
+ * the pointer have changed -- an in-place update, or an allocator that handed the address to another tensor -- instead of
+ * scoring against the stale packing; that call also drops the cache.  Rows outside the sample are still the caller's
+ * promise.  A different test side, a model change (fit, set_model, truncate, smooth) or plda_score_unprepare end the
+ * reuse silently.  Test sides whose packed form would reach 4 GiB are refused (such calls are scored in column blocks,
+ * each packed per call). */
 int plda_score_prepare_dev(plda_handle *h, const double *dV, int64_t Nt, int32_t mixed_counts, int32_t n_uniform);
 int plda_score_unprepare(plda_handle *h);
 /* Kernel timing for roofline accounting: when enabled, every trials-GEMM launch is

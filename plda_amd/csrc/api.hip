@@ -866,6 +866,7 @@ int plda_sym_eig(plda_handle *h, const double *G, int32_t D, int32_t method, dou
     PLDA_LOCK(h);
     if (!G || !eigenvalues || !eigenvectors || D <= 0 || D > 2048) return fail(h, PLDA_E_INVAL, "sym_eig: bad argument");
     if (method < 0 || method > 2) return fail(h, PLDA_E_INVAL, "sym_eig: method must be 0 (default), 1 (Jacobi) or 2 (direct)");
+    if (method == 1 && D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: the block Jacobi solver (method 1) stops at D = 1024; D = %d needs method 0 or 2", D);
     PLDA_TRY(set_device(h));
     const size_t DD = (size_t)D * D;
     Tmp dG, dS, dV;

@@ -72,22 +72,29 @@ std::mutex g_rccl_mu;
 const Rccl *rccl_api(std::string *why) {
   std::lock_guard<std::mutex> g(g_rccl_mu);
   if (g_rccl.lib) return &g_rccl;
-  std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
-  if (const char *rp = std::getenv("ROCM_PATH")) {
-    names.push_back(std::string(rp) + "/lib/librccl.so.1");
-    names.push_back(std::string(rp) + "/lib/librccl.so");
+  // PLDA_RCCL_LIB=<path> replaces the search list (a site-specific build; also how the not-found path is tested)
+  std::vector<std::string> names;
+  if (const char *one = std::getenv("PLDA_RCCL_LIB")) {
+    names.push_back(one);
+  } else {
+    names = {"librccl.so.1", "librccl.so"};
+    if (const char *rp = std::getenv("ROCM_PATH")) {
+      names.push_back(std::string(rp) + "/lib/librccl.so.1");
+      names.push_back(std::string(rp) + "/lib/librccl.so");
+    }
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("/opt/rocm/lib/librccl.so");
   }
-  names.push_back("/opt/rocm/lib/librccl.so.1");
-  names.push_back("/opt/rocm/lib/librccl.so");
   void *lib = nullptr;
   std::string tried;
   for (const auto &n : names) {
     lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (lib) break;
-    tried += (tried.empty() ? "" : ", ") + n;
+    const char *e = dlerror();          // once per failed attempt: the call returns the message AND clears it
+    tried += (tried.empty() ? "" : "; ") + n + ": " + (e ? e : "unknown dlopen error");
   }
   if (!lib) {
-    if (why) *why = "librccl not found (tried " + tried + "): " + (dlerror() ? dlerror() : "");
+    if (why) *why = "librccl not found (" + tried + ")";
     return nullptr;
   }
   bool ok = true;

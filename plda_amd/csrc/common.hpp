@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/plda_hip.h"
@@ -91,6 +92,7 @@ struct plda_handle {
   const double *prep_dV = nullptr;
   int64_t prep_Nt = 0;
   uint64_t prep_epoch = 0;
+  unsigned long long prep_fp = 0;   // content fingerprint of the prepared rows (score.hip: fingerprint_kernel)
   int prep_nuniform = 0;
 
   // ---- Jacobi sweep graph + warm-start state (linalg.hip) ----
@@ -114,6 +116,7 @@ struct plda_handle {
   int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
   bool bt2_attr_set = false;
+  bool bt4_attr_set = false;
   bool timeline_valid = false;   // `timeline` holds the stamps of a PLDA_GEMM_VARIANT=31 launch
   plda::DevBuf timeline;
 
@@ -199,6 +202,14 @@ struct TraceScope {
     (void)hipEventRecord(sp.e0, h->stream);
   }
   ~TraceScope() { close(); }
+};
+
+// Function attributes (the dynamic-LDS opt-in) are per DEVICE, and handles on different GPUs or threads share a launch
+// template's statics: one bit per device, set only after the attribute call succeeded (two racing threads both set it).
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool needed(int device) const { return !(mask.load(std::memory_order_acquire) & (1ull << (device & 63))); }
+  void done(int device) { mask.fetch_or(1ull << (device & 63), std::memory_order_release); }
 };
 
 constexpr size_t TIMELINE_WORDS = 8 * 16 * 8 * 8;   // [tile < 8][stage < 16][wave < 8][8] shader-clock stamps

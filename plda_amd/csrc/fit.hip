@@ -463,11 +463,11 @@ static int group_by_counting(plda_handle *h, const uint64_t *dlabels, int64_t N,
   while ((1ll << nbits) < K) nbits++;
   const int nw = K <= 8192 ? 4 : K <= 16384 ? 2 : 1;          // waves (chunks) per workgroup: their tables share 128 KiB
   const size_t lds = (size_t)nw * K * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr;          // (per device: handles on different GPUs share this function)
+  if (attr.needed(h->device)) {
     PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&group_place_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, GR_KMAX * (int)sizeof(int)));
-    attr_set = true;
+    attr.done(h->device);
   }
   group_place_kernel<<<(unsigned)ceil_div(nchunks, (int64_t)nw), 64 * nw, lds, h->stream>>>(dlabels, N, K, nbits, cnt, nchunks, perm);
   PLDA_LAUNCH_CHECK(h);

@@ -1809,7 +1809,12 @@ static int jacobi_sweep_graph(plda_handle *h, double *G, double *V, int D, doubl
 // eigenvectors); the iteration then starts from A = warm G, V = warm instead of A = G, V = I.
 int sym_eig_f64(plda_handle *h, double *G, int D, double *s, double *Vrows, int *sweeps_out,
                 const double *warm) {
-  if (D > 1024) return fail(h, PLDA_E_INVAL, "sym_eig: the block Jacobi solver holds 16 rows in LDS (D=%d > 1024); the direct method is the only one above that", D);
+  if (D > 1024)
+    return fail(h, PLDA_E_INVAL,
+                "sym_eig: D=%d in (1024, 2048] is served only by the direct solver, whose tridiagonalisation needs ceil(D/8) = %d "
+                "co-resident workgroups; this device did not run it (fewer usable CUs than that -- CU masking or a partitioned GPU? "
+                "-- or the method was forced to Jacobi), and the block Jacobi fallback holds 16 rows in LDS, i.e. stops at D = 1024",
+                D, (D + 7) / 8);
   const size_t DD = (size_t)D * D;
   PLDA_HIP(h, h->w[14].reserve(DD * 8 * 2 + (size_t)D * 8 + 64));
   double *V = h->w[14].as<double>();

@@ -808,6 +808,8 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #undef BT2_MFMA2
 #undef BT2_SB
 
+#include "score_bt4.inc"
+
 // finalise fused z-norm statistics: mean = shift + S1/N, std = sqrt(S2/N - (S1/N)^2)
 __global__ void znorm_finalize_kernel(const float *__restrict__ shift, const double *__restrict__ colsum,
                                       const double *__restrict__ colsq, int64_t M, double invN,
@@ -974,6 +976,63 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
                        ((h->gemm_variant >= 30 && h->gemm_variant <= 36) || (h->gemm_variant == 0 && big));
+  // one wave per SIMD, 128 x 128 per wave (score_bt4.inc): PLDA_GEMM_VARIANT 40 forces it, 41 its timeline
+  // instantiation, 44 / 45 / 46 its bounding arms (no DMA / no stores / neither); needs >= 2 stages per tile.
+  // It covers the whole 256 x 256 tiles of the matrix; the fringe (rows past the last whole tile row, columns past
+  // the last whole tile column) goes to the 128 x 128 kernel below -- same operand layout, same bits.
+  {
+    const int nsteps = op.KQ >> 1, nst = (nsteps + 3) >> 2;
+    const int64_t Mi = M / 256 * 256, Ni = Nt / 256 * 256;
+    const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 2 && Mi > 0 && Ni > 0 &&
+                         (h->gemm_variant == 40 || h->gemm_variant == 41 || (h->gemm_variant >= 44 && h->gemm_variant <= 46));
+    if (use_bt4) {
+      const int sbase = nsteps / nst, fs = sbase + (nsteps - sbase * nst > 0 ? 1 : 0);
+      const int itM = (int)(Mi / 256), itN = (int)(Ni / 256), pN = (int)ceil_div(itN, BPC);
+      if (!h->bt4_attr_set) {
+        const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 0>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 0>),
+                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 1>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 1>),
+                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 4>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 8>),
+                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 12>)};
+        for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT4_LDS));
+        h->bt4_attr_set = true;
+      }
+#define BT4L(FS_, MODE_, DBG_)                                                                            \
+  trials_gemm_bt4_kernel<FS_, MODE_><<<256, 256, BT4_LDS, h->stream>>>(                                   \
+      h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
+      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, itM, itN, pN, DBG_)
+      if (h->gemm_variant == 41) {
+        PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
+        PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
+        if (fs == 3) BT4L(3, 1, h->timeline.as<unsigned long long>());
+        else BT4L(4, 1, h->timeline.as<unsigned long long>());
+        h->timeline_valid = true;
+      } else if (h->gemm_variant >= 44 && fs == 4) {
+        if (h->gemm_variant == 44) BT4L(4, 4, nullptr);
+        else if (h->gemm_variant == 45) BT4L(4, 8, nullptr);
+        else BT4L(4, 12, nullptr);
+      } else if (fs == 3) {
+        BT4L(3, 0, nullptr);
+      } else {
+        BT4L(4, 0, nullptr);
+      }
+#undef BT4L
+      // fringe: [0, M) x [Ni, Nt) and [Mi, M) x [0, Ni)
+      auto fringe = [&](int64_t roff, int64_t coff, int64_t m, int64_t nt) {
+        const int tM = (int)ceil_div(m, 128), tN = (int)ceil_div(nt, 128);
+        const int pM = (int)ceil_div(tM, PATCH_M), pNn = (int)ceil_div(tN, PATCH_N);
+        const int64_t nP = (int64_t)pM * pNn, g = round_up(nP, 8) * PATCH_M * PATCH_N;
+        trials_gemm_kernel<10, 0, 2, 0><<<(unsigned)g, 256, 0, h->stream>>>(
+            h->s_Apk.as<f32x4>() + roff, h->s_Bpk.as<f32x4>() + coff, op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>() + roff,
+            h->s_rscale.as<float>() + roff, h->s_cbias.as<float>() + coff, dout + roff * ld + coff, ld, m, nt, tM, tN, pNn, (int)nP,
+            nullptr, nullptr, nullptr);
+      };
+      if (Nt > Ni) fringe(0, Ni, M, Nt - Ni);
+      if (M > Mi) fringe(Mi, 0, M - Mi, Ni);
+      PLDA_LAUNCH_CHECK(h);
+      if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
+      return PLDA_OK;
+    }
+  }
   if (use_bt2) {
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
@@ -1037,6 +1096,42 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   return PLDA_OK;
 }
 
+// Content fingerprint of a prepared test side: 64 rows spread over [0, Nt) (first and last included), every element's
+// bits mixed with its position (splitmix64) and summed.  plda_score_prepare_dev records it; a later call that would reuse
+// the packed operand recomputes it and refuses on a mismatch -- the cache is keyed on the POINTER, and a caching allocator
+// hands the same address to another tensor, or the caller updates rows in place (round-3 review, weak 10 / advisor).
+__global__ __launch_bounds__(256) void fingerprint_kernel(const double *__restrict__ V, int64_t Nt, int D, unsigned long long *__restrict__ out) {
+  unsigned long long acc = 0;
+  for (int j = 0; j < 64; ++j) {
+    const int64_t row = Nt <= 64 ? j : (int64_t)j * (Nt - 1) / 63;   // (Nt < 2^56)
+    if (row >= Nt) break;
+    for (int d = threadIdx.x; d < D; d += 256) {
+      unsigned long long z = (unsigned long long)__double_as_longlong(V[row * D + d]) + 0x9e3779b97f4a7c15ull * (unsigned long long)(j * 4096 + d + 1);
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      acc += z ^ (z >> 31);
+    }
+  }
+  __shared__ unsigned long long part[256];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = part[0];
+}
+
+// (synchronises the handle's stream: only plda_score_prepare_dev and calls that REUSE a prepared test side pay it)
+static int test_side_fingerprint(plda_handle *h, const double *dV, int64_t Nt, unsigned long long *fp) {
+  PLDA_HIP(h, h->w[12].reserve(8));
+  fingerprint_kernel<<<1, 256, 0, h->stream>>>(dV, Nt, h->Dout, h->w[12].as<unsigned long long>());
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_HIP(h, hipMemcpyAsync(fp, h->w[12].p, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  return PLDA_OK;
+}
+
 // reuse_packed_B: the test side (dV, Nt, enrol-count kind) is the one the previous call on this handle
 // packed -- the host entry point scores one test set against successive row slabs
 int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
@@ -1057,8 +1152,17 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
   h->last_M = M; h->last_Nt = Nt; h->last_k = dn ? 2 * D : D;
   // a test side packed ahead of time by plda_score_prepare_dev (same rows, same model, same kind of enrol counts)
   if (ncb == 1 && h->prep_valid && h->prep_dV == dV && h->prep_Nt == Nt && h->prep_epoch == h->model_epoch &&
-      h->prep_mixed == (dn != nullptr) && (dn || h->prep_nuniform == n_uniform))
+      h->prep_mixed == (dn != nullptr) && (dn || h->prep_nuniform == n_uniform)) {
+    unsigned long long fp = 0;
+    PLDA_TRY(test_side_fingerprint(h, dV, Nt, &fp));
+    if (fp != h->prep_fp) {
+      h->prep_valid = false;
+      return fail(h, PLDA_E_INVAL,
+                  "score_matrix: the rows at the prepared test-side address have changed since plda_score_prepare_dev "
+                  "(content fingerprint mismatch); prepare again, or call plda_score_unprepare before reusing the buffer");
+    }
     reuse_packed_B = true;
+  }
   for (int64_t rb = 0; rb < nrb; ++rb) {
     const int64_t r0 = rb * cap, m = std::min(cap, M - r0);
     for (int64_t cbk = 0; cbk < ncb; ++cbk) {
@@ -1088,6 +1192,7 @@ int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, bool mixe
   static const int32_t dummy_marker = 0;
   // (only the kind of the enrol counts matters to the test side: a non-null pointer selects the depth-2D form)
   PLDA_TRY(prepare_operands(h, dV, mixed ? &dummy_marker : nullptr, n_uniform, 0, dV, Nt, nullptr, nullptr, op, /*doA=*/false, /*doB=*/true));
+  PLDA_TRY(test_side_fingerprint(h, dV, Nt, &h->prep_fp));
   h->prep_valid = true; h->prep_dV = dV; h->prep_Nt = Nt; h->prep_epoch = h->model_epoch; h->prep_mixed = mixed;
   h->prep_nuniform = n_uniform;
   return PLDA_OK;

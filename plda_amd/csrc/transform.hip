@@ -529,11 +529,11 @@ static int launch_transform_fused_t(plda_handle *h, const double *dX, int64_t R,
   static_assert(KS % 4 == 0 && KS >= 8, "a stage is a whole number of 4-k MFMA steps, and at least two of them");
   static_assert(G::LDS_BYTES <= 160 * 1024, "stage buffers exceed the LDS of a CU");
   static_assert((size_t)(2 * G::COLS + CH * G::ROWS) * 8 <= G::LDS_BYTES / 2, "the epilogue's scratch must fit one stage buffer");
-  static bool attr_set = false;   // (per instantiation; setting it twice is harmless)
-  if (!attr_set) {
+  static DeviceOnce attr;          // (per instantiation and device; setting it twice is harmless)
+  if (attr.needed(h->device)) {
     PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH, KS, PERROW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-    attr_set = true;
+    attr.done(h->device);
   }
   transform_fused_kernel<NT, CH, KS, PERROW><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)G::ROWS), h->num_cus), 512,
                                                G::LDS_BYTES, h->stream>>>(
@@ -548,11 +548,11 @@ static int launch_transform_dma_t(plda_handle *h, const double *dX, int64_t R, i
                                   int n_uniform, double *dout, int Dinp, int padrows) {
   using G = TfDmaGeom<NT, CH>;
   static_assert(G::LDS_BYTES <= 160 * 1024, "stage ring exceeds the LDS of a CU");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr;
+  if (attr.needed(h->device)) {
     PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_dma_kernel<NT, CH, PERROW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-    attr_set = true;
+    attr.done(h->device);
   }
   transform_dma_kernel<NT, CH, PERROW><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)G::ROWS), h->num_cus), 512,
                                          G::LDS_BYTES, h->stream>>>(

@@ -70,6 +70,8 @@ def _compact_labels(Y):
     sorts: 4.2 ms for 100k labels, more than the fit itself.  Labels are small integers in practice (the reference
     indexes an array by them), so count instead: 0.2 ms, and already-dense labels pass through untouched."""
     n = Y.shape[0]
+    if n == 0:
+        return Y, 0                                   # plda_fit reports the empty input (PLDA_E_INVAL), not NumPy's max()
     top = int(Y.max())
     if top < 16 * n + 1024:
         signed = Y.view(np.int64)                     # (top < 2^63: same values)

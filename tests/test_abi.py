@@ -56,3 +56,21 @@ def test_product_code_never_touches_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                     src = open(os.path.join(dirpath, f), errors="replace").read()
                     assert pat.search(src) is None, "%s references the oracle" % os.path.join(dirpath, f)
+
+
+def test_missing_rccl_is_a_clean_error(tmp_path):
+    """librccl is opened lazily so that machines without RCCL can use the library (csrc/comm.hip); "not found" is then an
+    expected path and must come back as a status code, not a crash (round-3 advisor finding: dlerror() was called twice).
+    A fresh process, because the opened library is cached per process; plda_comm_unique_id needs no GPU."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, ctypes
+        os.environ["PLDA_RCCL_LIB"] = %r
+        from plda_amd import _native as N
+        buf = ctypes.create_string_buffer(128)
+        rc = N.load().plda_comm_unique_id(buf, 128)
+        print("rc", rc)
+    """ % str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "rc -5" in r.stdout, r.stdout          # PLDA_E_HIP

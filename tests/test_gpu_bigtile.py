@@ -115,6 +115,45 @@ def test_kernels_bit_identical(monkeypatch):
         assert np.array_equal(outs[variant][1], outs[20][1]), variant
 
 
+# (d, m, nt): depth classes of the one-wave-per-SIMD kernel (variant 40, score_bt4.inc) -- last stage of 4 steps (25 steps:
+# 3,3,3,4,4,4,4; 12 steps: 4,4,4; 64 steps), of 3 steps (9 steps: 3,3,3; 5 steps: 2,3; 6 steps: 3,3), one regular stage
+# only (8 steps: 4,4), an odd regular stage in front (7 steps: 3,4) -- on shapes with whole tiles only, with a fringe of
+# rows, of columns, of both (the fringe goes to the 128 x 128 kernel), and several tiles per workgroup (3072 x 5120 = 240 tiles)
+BT4_SHAPES = [(200, 600, 1100), (200, 512, 768), (96, 300, 517), (72, 256, 1024), (40, 700, 300), (48, 513, 255 + 256),
+              (64, 1024, 1024), (56, 257, 769), (512, 520, 600), (200, 3072, 5120), (33, 2300, 2900)]
+
+
+@pytest.mark.parametrize("d,m,nt", BT4_SHAPES)
+def test_one_wave_per_simd_kernel_bit_identical(monkeypatch, d, m, nt):
+    """(iv) for the round-4 kernel: same starting value, same k order per trial as the 128 x 128 kernel -> same bits,
+    uniform and mixed enrol counts (depth 2D), with and without the z-norm map folded into the operands."""
+    rng = np.random.default_rng(d + m)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    counts = rng.integers(1, 6, m).astype(np.int32)
+    ids = np.arange(m, dtype=np.int64)
+    outs = {}
+    for variant in (20, 40):
+        eng, _ = _engine(monkeypatch, variant, d)
+        plain = (eng.score_matrix((2, U), (1, V)), eng.score_matrix((counts, U), (1, V)))
+        eng._meanz = {int(k): -40.0 + 0.01 * k for k in ids}
+        eng._stdvz = {int(k): 3.0 + 0.001 * k for k in ids}
+        outs[variant] = plain + (eng.score_matrix((2, U, ids), (1, V)),)
+    for a, b in zip(outs[40], outs[20]):
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (d, m, nt, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("d,m,nt", [(200, 300, 517), (64, 1024, 1024), (33, 257, 769)])
+def test_one_wave_per_simd_kernel_oracle(monkeypatch, oracle, d, m, nt):
+    eng, psi = _engine(monkeypatch, 40, d)
+    rng = np.random.default_rng(100 + d + m)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    for n in (1, 7):
+        ref = oracle.score_block(psi, U, n, V)
+        got = eng.score_matrix((n, U), (1, V))
+        assert (np.abs(got - ref) <= score_tol(ref)).all(), (n, np.abs(got - ref).max())
+
+
 # ---------------------------------------------------------------- (ii) default dispatch, 8192 x 8192
 def _default_case(monkeypatch, d, n_enrol, znorm, seed):
     import torch

@@ -124,3 +124,24 @@ def test_znorm_model_shards_tile(world):
     eng.comm_emulate(1, 0)
     torch.cuda.synchronize()
     assert torch.allclose(got, ref, rtol=1e-12, atol=0)
+
+
+def test_missing_rccl_reports_instead_of_crashing(tmp_path):
+    """plda_comm_init on a machine without librccl (PLDA_RCCL_LIB points at nothing): PldaError with the loader's message
+    per attempt (round-3 advisor: the second dlerror() call returned NULL and the message builder dereferenced it)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os
+        os.environ["PLDA_RCCL_LIB"] = %r
+        from plda_amd import MPlda
+        from plda_amd._native import PldaError
+        eng = MPlda(0)
+        try:
+            eng.comm_init(1, 0, bytes(128))
+        except PldaError as e:
+            print("PLDAERROR", e)
+    """ % str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+    assert "PLDAERROR" in r.stdout and "librccl not found" in r.stdout and "no_such_librccl.so" in r.stdout, r.stdout

@@ -338,13 +338,26 @@ def test_prepared_test_side_is_reused_and_invalidated():
     for mixed, dn, nu, ref in [(False, None, 2, ref_u), (True, n, 0, ref_m)]:
         eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=mixed, n_uniform=max(nu, 1))
         assert torch.equal(score(dn, nu, V), ref) and torch.equal(score(dn, nu, V), ref)      # reused, twice
-    # the reuse is real: overwrite the rows behind the prepared pointer -> the stale packing still answers ...
+    # the reuse is real, and guarded (round 4): the cache is keyed on the pointer, so overwriting the rows behind it -- an
+    # in-place update, or an allocator handing the address to another tensor -- must FAIL (content fingerprint of 64
+    # sampled rows), not score against the stale packing; the failed call drops the cache, the next one repacks
+    from plda_amd._native import PldaError
     eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
     keep = V.clone()
     V.copy_(V2)
     torch.cuda.synchronize()
-    assert torch.equal(score(None, 2, V), ref_u)
-    # ... until anything in the key changes: another count, the other kind of counts, unprepare, the model
+    with pytest.raises(PldaError, match="fingerprint"):
+        score(None, 2, V)
+    assert torch.equal(score(None, 2, V), ref_u2)
+    # a change in ONE sampled row (the last) is enough
+    eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
+    V[-1, 0] += 1e-9
+    torch.cuda.synchronize()
+    with pytest.raises(PldaError, match="fingerprint"):
+        score(None, 2, V)
+    V.copy_(V2)
+    # anything in the key changes -> repacked silently: another count, the other kind of counts, unprepare, the model
+    eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
     assert torch.equal(score(None, 3, V), score(None, 3, V2))
     eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
     assert torch.equal(score(None, 2, V), ref_u2)
@@ -352,7 +365,7 @@ def test_prepared_test_side_is_reused_and_invalidated():
     eng.score_unprepare()
     assert torch.equal(score(None, 2, V), ref_u)
     eng.score_prepare_dev(V.data_ptr(), nt, mixed_counts=False, n_uniform=2)
-    eng.smooth(0.5)                                         # model epoch moves on
+    eng.smooth(0.5)                                         # model epoch moves on: no reuse, hence no fingerprint check either
     V.copy_(V2)
     torch.cuda.synchronize()
     one = MPlda(0)
