@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 flop/clk
 PEAK_FP64_MFMA_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: half of that
+CURRENT_ROUND = 4               # profiles/rNN_* files a bench line may cite
 
 CONFIGS = {
     # name: fit rows, featdim, speakers, enrol models, enrol counts, test vectors
@@ -83,17 +84,34 @@ def cpu_best_effort(D, psi, side=12000):
             "sample": "%dx%d trials, fp64 GEMM form (oracle/plda_oracle_np.py), %.1f s" % (side, side, dt)}
 
 
+def host_stats(X, y):
+    """PldaStats::AddSamples with the wrapper's 1 / n_k weight (pldamodule.cpp:94-98) in NumPy fp64 (BLAS on the host
+    cores): what `oracle.stats` computes with scalar loops -- used for the shapes where those loops would take minutes
+    (C3: N D^2 = 2.6e11).  Returns the dict oracle.em_iter takes."""
+    c = np.bincount(y).astype(np.int64)
+    K = c.shape[0]
+    order = np.argsort(y, kind="stable")
+    m = np.add.reduceat(X[order], np.r_[0, np.cumsum(c)[:-1]], axis=0) / c[:, None]
+    del order
+    xs = X * np.sqrt(1.0 / c[y])[:, None]
+    S = xs.T @ xs - m.T @ m
+    del xs
+    return dict(means=m, counts=c, scatter=S, sum=(m / c[:, None]).sum(0), class_weight=float((1.0 / c).sum()), example_weight=float(K))
+
+
 def cpu_em_baseline(X, y, gpu_one_iter=None):
     """One Kaldi-style EM iteration (per-class loop, explicit inversions) of the oracle on
-    the SAME C2 statistics, single thread; its W, B are also the checker of the GPU's first
+    the SAME statistics, single thread; its W, B are also the checker of the GPU's first
     iteration (`gpu_one_iter` = the engine's means / scatter / W / B after a 1-iteration fit)."""
     from oracle import binding as ob
-    st = ob.stats(X, y)
     D = X.shape[1]
+    big = float(X.shape[0]) * D * D > 2e10
+    st = host_stats(X, y.astype(np.int64)) if big else ob.stats(X, y)
     t0 = time.perf_counter()
     W, B = ob.em_iter(st, np.eye(D), np.eye(D))
     dt = time.perf_counter() - t0
-    res = {"em_iters_per_s": 1.0 / dt, "sample": "1 EM iteration at N=%d D=%d K=%d, %.1f s" % (X.shape[0], D, int(y.max()) + 1, dt)}
+    res = {"em_iters_per_s": 1.0 / dt, "sample": "1 EM iteration at N=%d D=%d K=%d, %.1f s" % (X.shape[0], D, int(y.max()) + 1, dt),
+           "statistics_by": "NumPy fp64 restatement of AddSamples (host BLAS)" if big else "oracle/plda_oracle.c"}
     if gpu_one_iter is not None:
         rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())    # noqa: E731
         res["gpu_vs_oracle_after_one_iteration"] = {
@@ -147,7 +165,8 @@ def latest_traffic(M, Nt, dout):
     collect counters itself."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_trials_gemm.json"))):
+    # (files of the CURRENT round only: round 3's C3 line silently carried a round-2 counter file)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r%02d_*traffic_trials_gemm*.json" % CURRENT_ROUND))):
         try:
             j = json.load(open(f))
             if tuple(j.get("shape", (100000, 100000, 200))) == (M, Nt, dout):
@@ -275,10 +294,13 @@ def main():
     elif rank == 0:
         dX, dy = fit_rows()
         torch.cuda.synchronize(dev)
-        if X is not None and not args.no_cpu:
+        if not args.no_cpu:
             eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, 1)         # one EM iteration: checked against the oracle's below
             torch.cuda.synchronize(dev)
             gpu_one_iter = eng.fit_internals()
+            if X is None:                                                 # C3 / C4: the rows were drawn on the device
+                X = dX.cpu().numpy()
+                y = dy.cpu().numpy().astype(np.uint64)
         eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)   # warm (allocations, code load)
         t0 = time.perf_counter()
         eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, args.iters)
@@ -300,6 +322,11 @@ def main():
             if sp["unit"] == "flop" and sp["ms"] > 0:
                 st["TFLOPps"] = round(sp["work"] / sp["ms"] / 1e9, 2)
                 st["frac_fp64_mfma_78.6"] = round(sp["work"] / sp["ms"] / 1e9 / 78.6, 4)
+                if "(K2)" in sp["name"]:
+                    # K2 computes the lower triangle only: `work` is the EXECUTED count (N + K) D (D + 1); the same time
+                    # priced at the full-square 2 (N + K) D^2 of a plain GEMM is given beside it, labelled, never as the fraction
+                    st["flop_counted"] = "executed: lower triangle, (N+K) D (D+1)"
+                    st["frac_if_counted_as_full_square_2ND2"] = round(2.0 * (N + K) * D * D / sp["ms"] / 1e9 / 78.6, 4)
             stages.append(st)
         fit_info = {"stats_ms": round(ft["stats_ms"], 3), "em_ms": round(ft["em_ms"], 3),
                     "output_ms": round(ft["output_ms"], 3), "iters": ft["iters"],
@@ -420,7 +447,7 @@ def main():
     ref = eng.score_trials((nh, Uh), (1, Th), np.repeat(np.arange(ne), nt_), np.tile(np.arange(nt_), ne)).reshape(ne, nt_)
     spot = float(np.abs(got - ref).max())
     oracle_check = None
-    if not args.no_cpu:
+    if True:                 # (always: 4 096 trials of the per-trial oracle take milliseconds; --no-cpu only skips the timed CPU legs)
         try:
             from oracle import binding as ob
             ob.build()
@@ -498,9 +525,24 @@ def main():
         tz = time.perf_counter()
         eng.znorm_stats_dev(cohort.data_ptr(), zNb, zNb, D, dU.data_ptr(), zM, zmean.data_ptr(), zstd.data_ptr())
         torch.cuda.synchronize(dev)
-        zn = {"models": zM, "cohort": zNb, "ms": round((time.perf_counter() - tz) * 1e3, 3),
+        zms = (time.perf_counter() - tz) * 1e3
+        # roofline (round-3 review, weak 8): the stages' HIP-event spans of one more call.  Work as EXECUTED: the cohort's
+        # transform 2 Nb D Dout, the (D+1)-wide covariance as a lower triangle Nb (D+1)(D+2), the model GEMM 2 M D^2 -- all
+        # on the fp64 matrix cores (78.6 TFLOP/s); HBM floor: the cohort read once + the centred rows written and read
+        eng.trace_enable(True); eng.trace_read(reset=True)
+        eng.znorm_stats_dev(cohort.data_ptr(), zNb, zNb, D, dU.data_ptr(), zM, zmean.data_ptr(), zstd.data_ptr())
+        torch.cuda.synchronize(dev)
+        zsp = eng.trace_read(reset=True); eng.trace_enable(False)
+        d1 = dout + 1
+        zflop = 2.0 * zNb * D * dout + float(zNb) * d1 * (d1 + 1) + 2.0 * zM * dout * dout
+        zbytes = 8.0 * (zNb * D + 3.0 * zNb * d1 + 2.0 * zM * dout)
+        zn = {"models": zM, "cohort": zNb, "ms": round(zms, 3),
               "pairs_the_reference_scores": zM * zNb, "finite": bool(torch.isfinite(zmean).all() and torch.isfinite(zstd).all()),
-              "how": "cohort moments in fp64: (D+1)-wide SYRK over the cohort + one M x D x D GEMM (DESIGN.md, row a13)"}
+              "how": "cohort moments in fp64: (D+1)-wide SYRK over the cohort + one M x D x D GEMM (DESIGN.md, row a13)",
+              "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP64_MFMA_TFLOPS, "flop_executed": zflop,
+                           "achieved": round(zflop / zms / 1e9, 2), "frac": round(zflop / zms / 1e9 / PEAK_FP64_MFMA_TFLOPS, 4),
+                           "hbm_bytes_algorithmic": zbytes, "hbm_floor_ms": round(zbytes / 8e12 * 1e3, 4),
+                           "stages": [{"name": sp["name"], "ms": round(sp["ms"], 4)} for sp in zsp]}}
         del cohort, zmean, zstd
 
     # ---- transform (K4: rows -> PLDA space -> length norm, pldamodule.cpp:111-194) of the test side's rows, outside
@@ -606,7 +648,7 @@ def main():
                 if td:
                     eng.set_model(packed[:D], packed[D:D + D * D].reshape(D, D), psi)    # (the targetdim leg truncated it)
                 del out
-                res["end_to_end"] = end_to_end(eng, X, y, D, dout)
+                res["end_to_end"] = end_to_end(eng, X if args.config == "C2" else None, y, D, dout)
             except Exception as e:   # noqa: BLE001 -- informative leg
                 res["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(res), flush=True)

@@ -558,7 +558,9 @@ int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const u
   {
     // X^T diag(1 / n_label) X and - M^T M in one pass (D <= 208: one launch + one reduction; the centroids' term was a
     // launch pair of its own, 48 us at 0.10 of the fp64 peak at C2)
-    TraceScope ts(h, "fit.scatter_syrk (K2)", 2.0 * (double)(N + K) * D * D, 1);
+    // work = the flop of the lower TRIANGLE, (N + K) D (D + 1) ("N D (D+1) if only the triangle"):
+    // what the kernels execute.  (Rounds 1-3 credited the full 2 N D^2 here, which let the reported fraction pass 1.)
+    TraceScope ts(h, "fit.scatter_syrk (K2)", (double)(N + K) * D * (D + 1.0), 1);
     PLDA_TRY(syrk_pair_f64(h, D, N, dX, D, roww, K, means, D, -1.0, S, D));
   }
   // the label checks are read back only now, with the synchronisation the pass ends on anyway: a failed check

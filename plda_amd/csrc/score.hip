@@ -515,6 +515,12 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
   // bounding arms (timing only, the scores are garbage): MODE bit 2 = no operand DMA (the MFMA stream, fragment reads,
   // barriers and the epilogue as they are, operands "resident"), bit 3 = no output stores (the epilogue's cost)
   constexpr bool NODMA = (MODE & 4) != 0, NOSTORE = (MODE & 8) != 0;
+  // MODE bit 4: the product kernel + two stamp pairs of workgroup 0 (shader clock s_memtime, 100 MHz s_memrealtime) at
+  // its start and end and its tile count: dbg[0..4] -> the clock the chip SUSTAINS under this kernel and the kernel's
+  // cycles per tile (scripts/gemm_clock.py)
+  constexpr bool CLK = (MODE & 16) != 0;
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (CLK && threadIdx.x == 0) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;                        // 2 x 4 waves
@@ -797,6 +803,12 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
     have = (c_slot == 0 ? q_ok[0] : (c_slot == 1 ? q_ok[1] : q_ok[2])) != 0;
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // no DMA may land in LDS after the workgroup has gone
+  if (CLK && threadIdx.x == 0) {     // every workgroup: dbg[8 + 4 b ..] = start / end in shader cycles and in 100 MHz ticks
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long *p = dbg + 8 + 4 * (size_t)blockIdx.x;
+    p[0] = c1 - clk_c0; p[1] = clk_r0; p[2] = r1; p[3] = (unsigned long long)tseq;
+    if (blockIdx.x == 0) { dbg[0] = c1 - clk_c0; dbg[1] = r1 - clk_r0; dbg[2] = (unsigned long long)tseq; }
+  }
 }
 #undef BT2_STEP_LAST
 #undef BT2_STEP_SECOND
@@ -975,36 +987,39 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   // it needs 32-bit byte offsets into each packed operand and into a tile's output rows
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
-                       ((h->gemm_variant >= 30 && h->gemm_variant <= 36) || (h->gemm_variant == 0 && big));
+                       ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || (h->gemm_variant == 0 && big));
   // one wave per SIMD, 128 x 128 per wave (score_bt4.inc): PLDA_GEMM_VARIANT 40 forces it, 41 its timeline
   // instantiation, 44 / 45 / 46 its bounding arms (no DMA / no stores / neither); needs >= 2 stages per tile.
-  // It covers the whole 256 x 256 tiles of the matrix; the fringe (rows past the last whole tile row, columns past
-  // the last whole tile column) goes to the 128 x 128 kernel below -- same operand layout, same bits.
   {
     const int nsteps = op.KQ >> 1, nst = (nsteps + 3) >> 2;
-    const int64_t Mi = M / 256 * 256, Ni = Nt / 256 * 256;
-    const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 2 && Mi > 0 && Ni > 0 &&
-                         (h->gemm_variant == 40 || h->gemm_variant == 41 || (h->gemm_variant >= 44 && h->gemm_variant <= 46));
+    const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 2 &&
+                         (h->gemm_variant == 40 || h->gemm_variant == 41 || (h->gemm_variant >= 44 && h->gemm_variant <= 47));
     if (use_bt4) {
       const int sbase = nsteps / nst, fs = sbase + (nsteps - sbase * nst > 0 ? 1 : 0);
-      const int itM = (int)(Mi / 256), itN = (int)(Ni / 256), pN = (int)ceil_div(itN, BPC);
+      const int pN = (int)ceil_div(btN, BPC);
       if (!h->bt4_attr_set) {
         const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 0>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 0>),
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 1>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 1>),
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 4>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 8>),
-                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 12>)};
+                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 12>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 16>),
+                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 16>)};
         for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT4_LDS));
         h->bt4_attr_set = true;
       }
 #define BT4L(FS_, MODE_, DBG_)                                                                            \
   trials_gemm_bt4_kernel<FS_, MODE_><<<256, 256, BT4_LDS, h->stream>>>(                                   \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
-      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, itM, itN, pN, DBG_)
+      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, (int)M, (int)Nt, btM, btN, pN, DBG_)
       if (h->gemm_variant == 41) {
         PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
         PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
         if (fs == 3) BT4L(3, 1, h->timeline.as<unsigned long long>());
         else BT4L(4, 1, h->timeline.as<unsigned long long>());
+        h->timeline_valid = true;
+      } else if (h->gemm_variant == 47) {     // the product kernel + clock stamps of workgroup 0
+        PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
+        if (fs == 3) BT4L(3, 16, h->timeline.as<unsigned long long>());
+        else BT4L(4, 16, h->timeline.as<unsigned long long>());
         h->timeline_valid = true;
       } else if (h->gemm_variant >= 44 && fs == 4) {
         if (h->gemm_variant == 44) BT4L(4, 4, nullptr);
@@ -1016,18 +1031,6 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
         BT4L(4, 0, nullptr);
       }
 #undef BT4L
-      // fringe: [0, M) x [Ni, Nt) and [Mi, M) x [0, Ni)
-      auto fringe = [&](int64_t roff, int64_t coff, int64_t m, int64_t nt) {
-        const int tM = (int)ceil_div(m, 128), tN = (int)ceil_div(nt, 128);
-        const int pM = (int)ceil_div(tM, PATCH_M), pNn = (int)ceil_div(tN, PATCH_N);
-        const int64_t nP = (int64_t)pM * pNn, g = round_up(nP, 8) * PATCH_M * PATCH_N;
-        trials_gemm_kernel<10, 0, 2, 0><<<(unsigned)g, 256, 0, h->stream>>>(
-            h->s_Apk.as<f32x4>() + roff, h->s_Bpk.as<f32x4>() + coff, op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>() + roff,
-            h->s_rscale.as<float>() + roff, h->s_cbias.as<float>() + coff, dout + roff * ld + coff, ld, m, nt, tM, tN, pNn, (int)nP,
-            nullptr, nullptr, nullptr);
-      };
-      if (Nt > Ni) fringe(0, Ni, M, Nt - Ni);
-      if (M > Mi) fringe(Mi, 0, M - Mi, Ni);
       PLDA_LAUNCH_CHECK(h);
       if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
       return PLDA_OK;
@@ -1039,7 +1042,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
                            reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>),
                            reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<4>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<8>),
-                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<12>)};
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<12>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<16>)};
       for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
@@ -1053,6 +1056,10 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
       if (h->gemm_variant == 31) BT2L(1, h->timeline.as<unsigned long long>());
       else BT2L(3, h->timeline.as<unsigned long long>());
+      h->timeline_valid = true;
+    } else if (h->gemm_variant == 37) {       // the product kernel + clock stamps of workgroup 0
+      PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
+      BT2L(16, h->timeline.as<unsigned long long>());
       h->timeline_valid = true;
     } else if (h->gemm_variant == 32) {
       BT2L(2, nullptr);

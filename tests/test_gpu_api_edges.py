@@ -284,7 +284,7 @@ def test_trace_spans_cover_the_fit_stages():
                  "getoutput.eig.back_transform", "getoutput.transform"):
         assert name in spans and spans[name]["calls"] == 1 and spans[name]["ms"] > 0.0, name
     # (the scatter SYRK carries the centroids' term -M^T M in the same launch: N + K rows)
-    assert spans["fit.scatter_syrk (K2)"]["work"] == 2.0 * (600 + 60) * 40 * 40 and spans["fit.scatter_syrk (K2)"]["unit"] == "flop"
+    assert spans["fit.scatter_syrk (K2)"]["work"] == (600 + 60) * 40 * 41.0 and spans["fit.scatter_syrk (K2)"]["unit"] == "flop"
     assert eng.trace_read() == []          # reset by the first read
     eng.trace_enable(False)
     eng.fit(X, y, 1)
