@@ -615,7 +615,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": int(gemm_flop / max(launches, 1) / (2 * gemm_k) * 4),
-                         "kernel": "trials_gemm_bt2_kernel (rank 0's launches)",
+                         "kernel": "%s (rank 0's launches)" % eng.score_last_kernel(),
                          "flop_per_trial": 2 * gemm_k, "avg_kernel_ms": round(avg_gemm_s * 1e3, 4),
                          "launches": launches,
                          "hbm_write_GBps": round(gemm_flop / max(launches, 1) / (2 * gemm_k) * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None},

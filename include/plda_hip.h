@@ -224,6 +224,9 @@ int plda_spd_inverse(plda_handle *h, const double *A, int32_t D, double *inverse
 /* algorithmic work of the last score_matrix call: flop of the trials GEMM and
  * its depth, for roofline accounting */
 int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm_k);
+/* name of the trials-GEMM kernel the last plda_score_matrix* call launched (roofline accounting: bench.py names the
+ * kernel its `roofline` block prices); "" before the first call.  PLDA_E_CAPACITY when it does not fit name[cap]. */
+int plda_score_last_kernel(plda_handle *h, char *name, int64_t cap);
 
 /* ---- z-norm: replaces MPlda_norm (pldamodule.cpp:196-256) ----
  * Every cohort row is transformed with num_examples = Nb (:224) and scored as

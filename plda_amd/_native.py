@@ -74,6 +74,7 @@ SIGNATURES = {
     "plda_trace_enable": (C.c_int, [_vp, _i32]),
     "plda_trace_read": (C.c_int, [_vp, _vp, _i64, _i32]),
     "plda_score_last_shape": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "plda_score_last_kernel": (C.c_int, [_vp, C.c_char_p, _i64]),
     "plda_dvector_pool": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _i64, _i32, _i32, _vp]),
     "plda_dvector_pool_dev": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _i64, _i32, _i32, _vp]),
     "plda_eer_matrix_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

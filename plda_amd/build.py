@@ -12,9 +12,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libplda_hip.so")
 SOURCES = ["api.hip", "score.hip", "linalg.hip", "fit.hip", "frontend.hip", "eer.hip", "lda.hip", "comm.hip", "eig_dc.hip", "hostio.hip", "transform.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "hostio.hpp"), os.path.join(CSRC, "sweep_mfma.inc"), os.path.join(HERE, "..", "include", "plda_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "hostio.hpp"), os.path.join(CSRC, "sweep_mfma.inc"), os.path.join(CSRC, "score_bt4.inc"), os.path.join(CSRC, "syrk_blk.inc"), os.path.join(HERE, "..", "include", "plda_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+# score.hip: the one-lane queue atomic of trials_gemm_bt4_kernel must stay ONE asynchronous instruction -- the atomic optimizer
+# rewrites it into a wave reduction that reads the result back on the spot (a memory round trip in the MFMA stream); the
+# tile fetch's two values are deliberately defined on one path only (score_bt4.inc)
+EXTRA = {"score.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-Wno-uninitialized", "-Wno-sometimes-uninitialized"]}
 
 
 def _stale(target, deps):
@@ -34,7 +40,7 @@ def build(force=False, verbose=False):
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

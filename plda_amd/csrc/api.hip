@@ -814,11 +814,14 @@ int plda_gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha,
     PLDA_TRY(set_device(h));
     const size_t nA = (size_t)M * K, nB = (size_t)K * N, nC = (size_t)M * N;
     Tmp dA, dB, dC, dW;
+    // the same host array on both sides (X^T diag(w) X: the scatter's product) stays ONE device array, so that the
+    // dispatch sees what fit's statistics pass hands it and takes the symmetric kernels
+    const bool same = A == B && nA == nB && batch == 1;
     PLDA_HIP(h, dA.alloc(nA * batch * 8));
-    PLDA_HIP(h, dB.alloc(nB * batch * 8));
+    if (!same) PLDA_HIP(h, dB.alloc(nB * batch * 8));
     PLDA_HIP(h, dC.alloc(nC * batch * 8));
     PLDA_HIP(h, hipMemcpyAsync(dA.p, A, nA * batch * 8, hipMemcpyHostToDevice, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(dB.p, B, nB * batch * 8, hipMemcpyHostToDevice, h->stream));
+    if (!same) PLDA_HIP(h, hipMemcpyAsync(dB.p, B, nB * batch * 8, hipMemcpyHostToDevice, h->stream));
     PLDA_HIP(h, hipMemcpyAsync(dC.p, C, nC * batch * 8, hipMemcpyHostToDevice, h->stream));
     if (kw) {
       PLDA_HIP(h, dW.alloc((size_t)K * 8));
@@ -826,7 +829,7 @@ int plda_gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha,
     }
     // element (m, k) of op(A): m * sam + k * sak; element (k, n) of op(B): k * sbk + n * sbn
     const int64_t sam = transA ? 1 : K, sak = transA ? M : 1, sbk = transB ? 1 : N, sbn = transB ? K : 1;
-    PLDA_TRY(gemm_f64_batched(h, M, N, K, alpha, dA.as<double>(), sam, sak, (int64_t)nA, dB.as<double>(), sbk, sbn, (int64_t)nB,
+    PLDA_TRY(gemm_f64_batched(h, M, N, K, alpha, dA.as<double>(), sam, sak, (int64_t)nA, same ? dA.as<double>() : dB.as<double>(), sbk, sbn, (int64_t)nB,
                               kw ? dW.as<double>() : nullptr, beta, dC.as<double>(), N, (int64_t)nC, batch));
     PLDA_HIP(h, hipMemcpyAsync(C, dC.p, nC * batch * 8, hipMemcpyDeviceToHost, h->stream));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
@@ -907,6 +910,17 @@ int plda_score_last_shape(plda_handle *h, int64_t *M, int64_t *Nt, int32_t *gemm
     if (M) *M = h->last_M;
     if (Nt) *Nt = h->last_Nt;
     if (gemm_k) *gemm_k = h->last_k;
+    return PLDA_OK;
+  });
+}
+
+int plda_score_last_kernel(plda_handle *h, char *name, int64_t cap) {
+  return guarded(h, "plda_score_last_kernel", [&]() -> int {
+    if (!h || !name || cap <= 0) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    const char *k = h->last_kernel ? h->last_kernel : "";
+    if ((int64_t)std::strlen(k) + 1 > cap) return fail(h, PLDA_E_CAPACITY, "score_last_kernel: need %zu bytes", std::strlen(k) + 1);
+    std::memcpy(name, k, std::strlen(k) + 1);
     return PLDA_OK;
   });
 }

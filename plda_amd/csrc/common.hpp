@@ -86,6 +86,7 @@ struct plda_handle {
   uint64_t tf_pad_epoch = ~0ull;
   int tf_pad_rows = 0, tf_pad_dinp = 0;
   int64_t last_M = 0, last_Nt = 0;
+  const char *last_kernel = nullptr;   // the trials-GEMM kernel of the last score_matrix launch (static string)
   int last_k = 0;
   // a test side packed ahead of time (plda_score_prepare_dev): reused while pointer, size, model and count kind match
   bool prep_valid = false, prep_mixed = false;
@@ -117,6 +118,11 @@ struct plda_handle {
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
   bool bt2_attr_set = false;
   bool bt4_attr_set = false;
+  // tile schedule of the one-wave-per-SIMD trials GEMM (score.hip: bt4_schedule): per XCD a queue of tiles, consumed
+  // through one device-scope counter per queue; the table is rebuilt when the tile grid changes
+  plda::DevBuf bt4_tab, bt4_cnt, bt4_fringe;   // (bt4_fringe: 256 x 256 scratch slots of the tiles that cross the matrix edge)
+  int bt4_tab_m = -1, bt4_tab_n = -1;
+  int bt4_qbase[8] = {}, bt4_qlen[8] = {};
   bool timeline_valid = false;   // `timeline` holds the stamps of a PLDA_GEMM_VARIANT=31 launch
   plda::DevBuf timeline;
 

@@ -541,8 +541,15 @@ __global__ __launch_bounds__(256) void syrk_tri_reduce_kernel(const double *__re
   if (gr != gcol) *c2 = v2;
 }
 
+#include "syrk_blk.inc"
+
 int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, int64_t ldx, const double *kw,
              double beta, double *C, int64_t ldc) {
+  if (h->gemm64_variant == 0) {          // 208 < D <= 512: one read of full rows (syrk_blk.inc)
+    bool used = false;
+    PLDA_TRY(syrk_blk_pair(h, D, K, X, ldx, kw, 0, nullptr, 0, 0.0, alpha, beta, C, ldc, &used));
+    if (used) return PLDA_OK;
+  }
   if (D <= TRI_NT * 16 && h->gemm64_variant != 3) {   // PLDA_GEMM64_VARIANT=3: super-tile path always (A/B arm)
     const int nt = (int)ceil_div(D, 16), ntri = nt * (nt + 1) / 2;
     int splits = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(K, 128)));
@@ -594,6 +601,11 @@ int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ld
     syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
+  }
+  if (h->gemm64_variant == 0) {          // 208 < D <= 512: both products from one read of full rows (syrk_blk.inc)
+    bool used = false;
+    PLDA_TRY(syrk_blk_pair(h, D, K1, X, ldx, kw, K2, X2, ldx2, w2, 1.0, 0.0, C, ldc, &used));
+    if (used) return PLDA_OK;
   }
   PLDA_TRY(gemm_f64(h, D, D, K1, 1.0, X, 1, ldx, X, ldx, 1, kw, 0.0, C, ldc));
   return gemm_f64(h, D, D, K2, w2, X2, 1, ldx2, X2, ldx2, 1, nullptr, 1.0, C, ldc);

@@ -822,6 +822,44 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 
 #include "score_bt4.inc"
 
+// Tile schedule of trials_gemm_bt4_kernel for a btM x btN grid of 256 x 256 tiles: queue x (one per XCD) lists the tiles of
+// patches x, x + 8, ... (BPR x BPC tiles each, row-major inside a patch) -- the order the static walk of bt2 takes them in,
+// so that the 32 workgroups of an XCD still work inside one patch at a time and share its operand panels in their L2 --
+// but a workgroup takes "the next tile of the queue" through an atomic counter instead of a fixed position, and a
+// workgroup whose queue has run dry continues in the next XCD's.  Why: the XCDs of one chip do not run at one clock under
+// this load (measured per XCD with s_memtime / s_memrealtime stamps, scripts/gemm_clock.py: 2.30 against 2.35 GHz, odd
+// against even XCDs), and awkward grids leave up to 5 % more tiles with some XCDs than with others; with equal static
+// shares the kernel ends 1.4 - 2.4 ms after its average workgroup (of 28 ms at C2).
+static int bt4_schedule(plda_handle *h, int btM, int btN) {
+  PLDA_HIP(h, h->bt4_cnt.reserve(32 * sizeof(unsigned)));
+  if (h->bt4_tab_m == btM && h->bt4_tab_n == btN) return PLDA_OK;
+  const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
+  std::vector<int> tab;
+  tab.reserve((size_t)btM * btN * 2);
+  unsigned init[32] = {};
+  for (int x = 0; x < 8; ++x) {
+    h->bt4_qbase[x] = (int)(tab.size() / 2);
+    for (int64_t p = x; p < (int64_t)pM * pN; p += 8) {
+      const int pm = (int)(p / pN), pn = (int)(p % pN);
+      for (int lb = 0; lb < BPR * BPC; ++lb) {
+        const int tm = pm * BPR + lb / BPC, tn = pn * BPC + lb % BPC;
+        if (tm < btM && tn < btN) { tab.push_back(tm * 256); tab.push_back(tn * 256); }
+      }
+    }
+    h->bt4_qlen[x] = (int)(tab.size() / 2) - h->bt4_qbase[x];
+    // a workgroup's FIRST tile is its own position in its XCD's queue (no round trip before the first DMA): the
+    // counters start behind those
+    init[16 + x] = (unsigned)std::min(32, h->bt4_qlen[x]);
+  }
+  PLDA_HIP(h, h->bt4_tab.reserve(std::max<size_t>(tab.size(), 2) * sizeof(int)));
+  // (synchronous copies from stack / vector memory: once per tile grid)
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  PLDA_HIP(h, hipMemcpy(h->bt4_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+  PLDA_HIP(h, hipMemcpy(h->bt4_cnt.p, init, sizeof(init), hipMemcpyHostToDevice));
+  h->bt4_tab_m = btM; h->bt4_tab_n = btN;
+  return PLDA_OK;
+}
+
 // finalise fused z-norm statistics: mean = shift + S1/N, std = sqrt(S2/N - (S1/N)^2)
 __global__ void znorm_finalize_kernel(const float *__restrict__ shift, const double *__restrict__ colsum,
                                       const double *__restrict__ colsq, int64_t M, double invN,
@@ -988,15 +1026,25 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
                        ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || (h->gemm_variant == 0 && big));
-  // one wave per SIMD, 128 x 128 per wave (score_bt4.inc): PLDA_GEMM_VARIANT 40 forces it, 41 its timeline
-  // instantiation, 44 / 45 / 46 its bounding arms (no DMA / no stores / neither); needs >= 2 stages per tile.
+  // one wave per SIMD, 128 x 128 per wave (score_bt4.inc) -- the product path of every BASELINE configuration since round 4
+  // (>= 1024 tiles of 256 x 256 and K >= 104); PLDA_GEMM_VARIANT 40 forces it, 30 forces the round-2/3 kernel, 41 its timeline
+  // instantiation, 44 / 45 / 46 its bounding arms (no DMA / no stores / neither); needs >= 3 stages per tile (K >= 72).
   {
     const int nsteps = op.KQ >> 1, nst = (nsteps + 3) >> 2;
-    const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 2 &&
-                         (h->gemm_variant == 40 || h->gemm_variant == 41 || (h->gemm_variant >= 44 && h->gemm_variant <= 47));
+    const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 3 && M < (1ll << 31) && Nt < (1ll << 31) &&
+                         (h->gemm_variant == 40 || h->gemm_variant == 41 || (h->gemm_variant >= 44 && h->gemm_variant <= 47) || (h->gemm_variant == 0 && big));
     if (use_bt4) {
       const int sbase = nsteps / nst, fs = sbase + (nsteps - sbase * nst > 0 ? 1 : 0);
-      const int pN = (int)ceil_div(btN, BPC);
+      h->last_kernel = "trials_gemm_bt4_kernel";
+      PLDA_TRY(bt4_schedule(h, btM, btN));
+      // the queues' counters start behind every workgroup's first tile
+      PLDA_HIP(h, hipMemcpyAsync(h->bt4_cnt.p, h->bt4_cnt.as<unsigned>() + 16, 8 * sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
+      // tiles that cross the matrix edge are written whole into scratch slots and copied out behind the launch
+      const int rag_m = (M & 255) != 0, rag_n = (Nt & 255) != 0;
+      const int fslots = (rag_m || rag_n) ? btM + btN : 0;
+      PLDA_HIP(h, h->bt4_fringe.reserve(std::max<size_t>((size_t)fslots * 65536 * 4, 256)));
+      Bt4Queues qs;
+      for (int x = 0; x < 8; ++x) { qs.qbase[x] = h->bt4_qbase[x]; qs.qlen[x] = h->bt4_qlen[x]; }
       if (!h->bt4_attr_set) {
         const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 0>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 0>),
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 1>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 1>),
@@ -1009,7 +1057,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
 #define BT4L(FS_, MODE_, DBG_)                                                                            \
   trials_gemm_bt4_kernel<FS_, MODE_><<<256, 256, BT4_LDS, h->stream>>>(                                   \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
-      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, (int)M, (int)Nt, btM, btN, pN, DBG_)
+      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, (int)M, (int)Nt, h->bt4_fringe.as<float>(), h->bt4_tab.as<int2>(), h->bt4_cnt.as<unsigned>(), qs, DBG_)
       if (h->gemm_variant == 41) {
         PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
         PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
@@ -1031,12 +1079,15 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
         BT4L(4, 0, nullptr);
       }
 #undef BT4L
+      if (fslots)
+        fringe_copy_kernel<<<(unsigned)(fslots * 8), 256, 0, h->stream>>>(h->bt4_fringe.as<float>(), dout, ld, (int)M, (int)Nt, btM, btN, rag_m, rag_n);
       PLDA_LAUNCH_CHECK(h);
       if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
       return PLDA_OK;
     }
   }
   if (use_bt2) {
+    h->last_kernel = "trials_gemm_bt2_kernel";
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
       const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
@@ -1085,6 +1136,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), op.Mpad, op.Npad, op.KQ, h->s_rbias.as<float>(),      \
       h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout,                                           \
       ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq)
+  h->last_kernel = "trials_gemm_kernel";
   constexpr int EPI_NOSTORE = (EPI == 0) ? 2 : EPI;
   switch (h->gemm_variant) {
     case 1: TG(8, EPI, 2, 0); break;             // stage depth 32 k

@@ -504,6 +504,12 @@ class MPlda(object):
                                                    C.c_void_p(int(dn)) if dn else None, int(n_uniform),
                                                    C.c_void_p(int(dout))))
 
+    def score_last_kernel(self):
+        """Name of the trials-GEMM kernel the last score_matrix* call launched."""
+        buf = C.create_string_buffer(128)
+        self._ck(self._lib.plda_score_last_kernel(self._h, buf, 128))
+        return buf.value.decode()
+
     def score_matrix_dev(self, dU, dn, n_uniform, m, dV, nt, dout, ld, dzmean=None, dzstd=None):
         """Enqueue one trials block on HBM-resident operands (raw device addresses)."""
         self._ck(self._lib.plda_score_matrix_dev(

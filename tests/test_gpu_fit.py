@@ -445,3 +445,34 @@ def test_grouping_by_counting_is_the_radix_sort(monkeypatch):
             res.append((st["means"], st["counts"], st["scatter"], m["transform"], m["psi"]))
         for a, b in zip(*res):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("d,n,k", [(210, 3000, 40), (256, 5000, 70), (300, 2500, 30), (384, 4097, 64), (512, 6000, 100), (512, 700, 9)])
+def test_statistics_pass_block_scatter_kernel(oracle, d, n, k):
+    """The offset scatter X^T diag(1 / n_label) X - sum_k m_k m_k^T (PldaStats::AddSamples with the wrapper's class
+    weight, pldamodule.cpp:94-98) for 208 < D <= 512: both products in ONE launch of the round-4 block kernel
+    (csrc/syrk_blk.inc, two row phases over one accumulator set) against oracle/plda_oracle.c; speaker sizes differ,
+    rows and speakers not multiples of the 16-row stage."""
+    import torch
+    from plda_amd import MPlda
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(d + n)
+    y = rng.integers(0, k, n)
+    y[:k] = np.arange(k)
+    x = rng.random((n, d)) + 0.5 * rng.standard_normal((k, d))[y]
+    st = oracle.stats(x, y.astype(np.uint64))
+    eng = MPlda(0)
+    dX = torch.from_numpy(x).to(dev); dy = torch.from_numpy(y.astype(np.int64)).to(dev)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.fit_stats_dev(dX.data_ptr(), n, d, dy.data_ptr(), k)
+    means = torch.empty((k, d), dtype=torch.float64, device=dev)
+    counts = torch.empty((k,), dtype=torch.int64, device=dev)
+    scatter = torch.empty((d, d), dtype=torch.float64, device=dev)
+    eng.fit_get_stats_dev(means.data_ptr(), counts.data_ptr(), scatter.data_ptr())
+    torch.cuda.synchronize()
+    S = scatter.cpu().numpy()
+    assert np.array_equal(counts.cpu().numpy(), st["counts"])
+    assert np.abs(means.cpu().numpy() - st["means"]).max() <= 1e-13 * np.abs(st["means"]).max()
+    assert np.abs(S - st["scatter"]).max() <= 1e-11 * np.abs(st["scatter"]).max(), np.abs(S - st["scatter"]).max() / np.abs(st["scatter"]).max()
+    assert np.array_equal(S, S.T)
+    eng.set_stream(None)

@@ -59,3 +59,25 @@ def test_deep_and_large_products():
     _check(eng, rng, 130, 2000, 129, False, False, 1.0, 0.0)
     _check(eng, rng, 200, 200, 40000, True, False, 1.0, 0.0, kw=True)     # the scatter's weighted contraction
     _check(eng, rng, 260, 260, 3000, True, False, 1.0, 0.0, kw=True)
+
+
+@pytest.mark.parametrize("d", [210, 256, 300, 320, 384, 450, 512])
+def test_symmetric_products_one_read_kernel(d):
+    """X^T diag(w) X with both operands the SAME array (what fit's statistics pass computes, pldamodule.cpp:94-98): for
+    208 < D <= 512 the block kernel of round 4 (csrc/syrk_blk.inc: 64 x 64 blocks dealt to the waves of up to four
+    workgroups, full rows staged once by LDS DMA).  Row counts around the 16-row stage and the group split (fewer
+    stages than groups, ragged last stage, one row), with and without weights, alpha / beta; exactly symmetric output."""
+    from plda_amd import MPlda
+    eng = MPlda(0)
+    rng = np.random.default_rng(d)
+    for k in (2048, 2049, 2063, 5000, 40000):
+        for kw in (False, True):
+            X = rng.standard_normal((k, d))
+            w = rng.random(k) + 0.5 if kw else None
+            C0 = rng.standard_normal((d, d)); C0 = C0 + C0.T
+            alpha, beta = (1.0, 0.0) if k != 5000 else (-0.5, 2.0)
+            got = eng.gemm_f64(X, X, alpha, beta, C0, True, False, w)
+            want = alpha * ((X.T * w) @ X if kw else X.T @ X) + beta * C0
+            tol = 4e-16 * k * max(1.0, np.abs(X).max() ** 2) * abs(alpha) * 1.5 + 1e-15 * np.abs(beta * C0).max() + 1e-15
+            assert np.abs(got - want).max() <= tol, (d, k, kw, np.abs(got - want).max(), tol)
+            assert np.array_equal(got, got.T)

@@ -197,3 +197,140 @@ def test_extended_precision_em_agrees_with_the_fp64_oracles():
     m = onp.fit(x, dense, 4, return_wb=True)
     assert float(np.abs(W - m["W"]).max() / np.abs(m["W"]).max()) < 1e-13
     assert float(np.abs(B - m["B"]).max() / np.abs(m["B"]).max()) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: checks of the oracle that do NOT go through SURVEY.md Appendix A's formulas (the C oracle, the NumPy oracle and
+# the golden fixtures share one reading of Kaldi; these three share none of it).  They start from the two-covariance model
+# itself -- x_ki = mu + y_k + e_ki, y_k ~ N(0, B), e_ki ~ N(0, W) -- and generic Gaussian algebra on the FULL n D-dimensional
+# joint distribution of a class (big dense covariance matrices, NumPy / SciPy only).
+# ---------------------------------------------------------------------------------------------------------------------
+def _small_classes(seed, D, sizes):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((D, D)); Bt = A @ A.T / D + 0.3 * np.eye(D)
+    C = rng.standard_normal((D, D)); Wt = C @ C.T / D + 0.5 * np.eye(D)
+    mu = rng.standard_normal(D)
+    y = np.repeat(np.arange(len(sizes)), sizes)
+    cls = rng.multivariate_normal(np.zeros(D), Bt, len(sizes))
+    x = mu + cls[y] + rng.multivariate_normal(np.zeros(D), Wt, len(y))
+    return x, y.astype(np.uint64)
+
+
+def _em_step_from_the_joint_gaussian(x, y, mu, W, B):
+    """One EM iteration derived from the model alone.  E-step: for class k, (y_k, x_k1 .. x_kn) is jointly Gaussian;
+    condition y_k on the observations with the generic formula E[y|x] = S_yx S_xx^-1 (x - mu), Cov = B - S_yx S_xx^-1 S_xy
+    on the n D x n D covariance S_xx = I_n (x) W + 1 1^T (x) B.  M-step: B = sum_k w_k E[y y^T] / sum_k w_k,
+    W = sum_k w_k sum_i E[(x_ki - mu - y)(x_ki - mu - y)^T] / sum_k w_k n_k, with the wrapper's class weight
+    w_k = 1 / n_k (pldamodule.cpp:97)."""
+    D = x.shape[1]
+    Bs, Ws, bw, ww = np.zeros((D, D)), np.zeros((D, D)), 0.0, 0.0
+    for k in np.unique(y):
+        xk = x[y == k] - mu
+        n = xk.shape[0]
+        w = 1.0 / n
+        Sxx = np.kron(np.eye(n), W) + np.kron(np.ones((n, n)), B)
+        Syx = np.kron(np.ones((1, n)), B)                        # Cov(y, x_i) = B for every i
+        G = Syx @ np.linalg.inv(Sxx)
+        ey = G @ xk.reshape(-1)
+        cy = B - G @ Syx.T
+        Bs += w * (cy + np.outer(ey, ey)); bw += w
+        for i in range(n):
+            r = xk[i] - ey
+            Ws += w * (cy + np.outer(r, r))
+        ww += w * n
+    return Ws / ww, Bs / bw
+
+
+@pytest.mark.parametrize("sizes", [[4] * 12, [1, 2, 3, 5, 2, 7, 3, 3, 4, 6, 2, 5]])
+def test_em_iteration_equals_the_exact_posterior_update(oracle, sizes):
+    """oracle.em_iter (Kaldi's GetStatsFromIntraClass / GetStatsFromClassMeans / EstimateFromStats as restated) against
+    the EM update computed from the joint Gaussian of each class by brute force: same W, B to 1e-10, from several
+    starting points, balanced and unbalanced classes (the unbalanced ones exercise the 1 / n_k class weight and the
+    count conventions of the M-step)."""
+    D = 3
+    x, y = _small_classes(5, D, sizes)
+    st = oracle.stats(x, y)
+    mu = st["sum"] / st["class_weight"]
+    rng = np.random.default_rng(6)
+    W, B = np.eye(D), np.eye(D)
+    for it in range(4):
+        Wo, Bo = oracle.em_iter(st, W, B)
+        Wr, Br = _em_step_from_the_joint_gaussian(x, y, mu, W, B)
+        assert _rel(Wo, Wr) < 1e-10 and _rel(Bo, Br) < 1e-10, (it, _rel(Wo, Wr), _rel(Bo, Br))
+        # next starting point: the update, pushed off the EM path by a random SPD perturbation
+        P = rng.standard_normal((D, D)) * 0.2
+        W, B = Wo + P @ P.T, Bo + P.T @ P
+
+
+def test_em_fixed_point_is_a_stationary_point_of_the_likelihood(oracle):
+    """At the EM's fixed point the gradient of the (class-weighted) marginal log-likelihood sum_k w_k log p(x_k | mu, W, B)
+    vanishes.  The likelihood is evaluated from the model's definition only: scipy's multivariate normal on the
+    n D-dimensional covariance I (x) W + 1 1^T (x) B of every class; the gradient by central differences along symmetric
+    directions.  After ONE iteration the same gradient is orders of magnitude larger (the test has teeth)."""
+    from scipy.stats import multivariate_normal
+    D, sizes = 2, [3, 5, 2, 4, 6, 3, 2, 5, 4, 3, 6, 2, 4, 5, 3, 4]
+    x, y = _small_classes(9, D, sizes)
+    st = oracle.stats(x, y)
+    mu = st["sum"] / st["class_weight"]
+
+    def loglik(W, B):
+        tot = 0.0
+        for k in np.unique(y):
+            xk = x[y == k]
+            n = xk.shape[0]
+            S = np.kron(np.eye(n), W) + np.kron(np.ones((n, n)), B)
+            tot += (1.0 / n) * multivariate_normal(np.tile(mu, n), S).logpdf(xk.reshape(-1))
+        return tot
+
+    def grad_norm(W, B, h=1e-5):
+        g = []
+        for M, which in ((W, 0), (B, 1)):
+            for a in range(D):
+                for b in range(a, D):
+                    E = np.zeros((D, D)); E[a, b] = E[b, a] = 1.0
+                    if which == 0: g.append((loglik(W + h * E, B) - loglik(W - h * E, B)) / (2 * h))
+                    else: g.append((loglik(W, B + h * E) - loglik(W, B - h * E)) / (2 * h))
+        return np.abs(np.array(g)).max()
+
+    W, B = np.eye(D), np.eye(D)
+    W1, B1 = oracle.em_iter(st, W, B)
+    g_early = grad_norm(W1, B1)
+    W, B = W1, B1
+    for _ in range(30000):                    # (EM is slow on 16 small classes: ~10 000 iterations to 1e-14)
+        Wn, Bn = oracle.em_iter(st, W, B)
+        done = max(_rel(Wn, W), _rel(Bn, B)) < 1e-14
+        W, B = Wn, Bn
+        if done:
+            break
+    g_fixed = grad_norm(W, B)
+    assert g_fixed < 1e-6, g_fixed
+    assert g_early > 1e3 * g_fixed, (g_early, g_fixed)
+
+
+@pytest.mark.parametrize("n", [1, 3, 10])
+def test_length_normalisation_weights_are_the_models_variances(oracle, n):
+    """Plda::TransformIvector's length normalisation divides by sqrt(sum_d t_d^2 / (psi_d + 1/n) / D).  Independent
+    reading: in the model's own coordinates the mean of n utterances of a class is N(0, diag(psi + 1/n)), so that sum is a
+    chi-square with D degrees of freedom over D -- its AVERAGE over draws from the model must be 1 (here 1 +- 4 sigma of
+    the sampling error), for n = 1 and for n > 1 alike; a reading with the wrong variance (psi + 1, psi / n + 1, ...) fails
+    for n > 1.  The factor is recovered from the oracle's outputs alone: normalised / un-normalised vector."""
+    D, draws = 24, 4000
+    rng = np.random.default_rng(40 + n)
+    psi = np.sort(rng.random(D) * 3.0 + 0.05)[::-1].copy()
+    q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    T = q * (1.0 + rng.random(D))[:, None]
+    Tinv = np.linalg.inv(T)
+    mean = rng.standard_normal(D)
+    model = dict(mean=mean, transform=T, psi=psi, offset=-T @ mean)
+    # class means of n utterances drawn in the model's coordinates, mapped back to the input space
+    t = rng.standard_normal((draws, D)) * np.sqrt(psi + 1.0 / n)
+    xs = t @ Tinv.T + mean
+    inv_f2 = np.empty(draws)
+    for j in range(draws):
+        u = oracle.transform_ivector(model, xs[j], n, normalize_length=True)
+        v = oracle.transform_ivector(model, xs[j], n, normalize_length=False)
+        assert np.abs(v - t[j]).max() < 1e-9                     # the un-normalised transform is the model's coordinates
+        inv_f2[j] = (v @ v) / (u @ u)                            # 1 / factor^2
+        assert abs(np.sum(u * u / (psi + 1.0 / n)) - D) < 1e-9 * D
+    sigma = np.sqrt(2.0 / D / draws)                             # std of a chi2_D / D average over `draws` draws
+    assert abs(inv_f2.mean() - 1.0) < 4 * sigma, (inv_f2.mean(), sigma)
