@@ -201,7 +201,7 @@ def main():
                     help="N>1: shard the fit statistics by speaker through plda_fit_sharded_dev (all-reduce of the "
                          "scatter + all-gather of the centroids over RCCL, replica EM) instead of rank-0 fit + broadcast")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the control plane (nccl = RCCL)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host", "peer"],
                     help="collectives of the library's sharded entry points: rccl (xGMI; one GPU per rank) or host (pinned "
                          "staging + the torch.distributed group, e.g. --backend gloo: lets N ranks share ONE GPU -- a check of "
                          "this script's N > 1 path on a single-GPU box, not a measurement)")
@@ -221,8 +221,8 @@ def main():
     emu = args.emulate_ranks if world == 1 else 0
     if emu:
         args.scaling = "strong"        # the emulation is a logic check of the partition on one GPU's memory
-    if args.transport == "host":
-        local_rank = local_rank % torch.cuda.device_count()     # ranks may share a GPU under the host transport
+    if args.transport in ("host", "peer"):
+        local_rank = local_rank % torch.cuda.device_count()     # ranks may share a GPU under the host / peer transports
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -508,6 +508,34 @@ def main():
                                   "side stream, overlapped with the scoring of the next one" % (world, gather_block)}
             if multi is not None:
                 multi["cross_rank_checksum_ok"] = bool(agree)
+            # ---- the same leg over the DIRECT-WRITE provider (plda_comm_init_peer: every rank pushes its blocks into the
+            #      others' buffers through HIP IPC mappings, one copy stream per peer -- all xGMI links at once; a gloo
+            #      group carries the IPC handles only).  The RCCL communicator is given back first.
+            if args.transport == "rccl":
+                try:
+                    err_p = None
+                    try:
+                        eng.comm_destroy()
+                        boot = dist.new_group(backend="gloo")
+                        init_comm(eng, group=boot, device=dev, transport="peer")
+                        el_p, _ = timed(True)
+                        seen_p = [None] * world
+                        dist.all_gather_object(seen_p, [cks(a, b) for a, b in firsts])
+                        agree_p = all(seen_p[r][q] == seen[q][q] for r in range(world) for q in range(world))
+                    except Exception as e:   # noqa: BLE001
+                        err_p = "%s: %s" % (type(e).__name__, e)
+                    okp = torch.tensor([0.0 if err_p else 1.0], dtype=torch.float64, device=dev)
+                    dist.all_reduce(okp, op=dist.ReduceOp.MIN)
+                    if okp.item() == 0.0:
+                        raise RuntimeError(err_p or "the direct-write leg failed on another rank")
+                    gather_info["peer_direct_write"] = {
+                        "value": float(M1) * Nt * args.steps / el_p, "unit": "trials/s", "ms_per_step": el_p / args.steps * 1e3,
+                        "ingest_GBps_per_rank": round(M1 * Nt * 4 * (world - 1) / world / (el_p / args.steps) / 1e9, 1),
+                        "gathered_blocks_bit_identical_to_rccl": bool(agree_p), "transport": eng.comm_describe()["transport"],
+                        "how": "plda_comm_init_peer: HIP-IPC mappings, one device-to-device push per peer and block on its own stream, "
+                               "sequence-number flags in an uncached page instead of a rendezvous; nothing but 72-byte handles crosses the host"}
+                except Exception as e:   # noqa: BLE001
+                    gather_info["peer_direct_write"] = {"error": "%s: %s" % (type(e).__name__, e)}
             full = None
         except Exception as e:   # noqa: BLE001
             gather_info = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -311,7 +311,14 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
  *                          host buffers, the library stages device data through a pinned bounce buffer in bounded
  *                          chunks.  This is also how the sharded entry points are tested with several processes on
  *                          ONE GPU (RCCL refuses two ranks on one device): tests/test_gpu_comm_procs.py.
- *   plda_comm_init_custom  the device-level table itself (e.g. HIP-IPC peer copies).
+ *   plda_comm_init_peer    direct writes over xGMI (round 4): every rank opens the others' buffers through HIP IPC and
+ *                          PUSHES its piece into them with device-to-device copies, one copy stream per peer -- all 7
+ *                          links of a GPU busy at once (~1.07 TB/s) where a ring moves one link's ~153 GB/s (SURVEY.md
+ *                          section 5).  `bootstrap` = the host operations of plda_comm_init_host; only its
+ *                          all_gather_v is used: it carries the IPC handles (72 bytes per rank and call) and is the
+ *                          rendezvous the inter-process events need -- no device data crosses the host.  Works between
+ *                          processes on one device too.  "transport": "peer" in plda_comm_describe.
+ *   plda_comm_init_custom  the device-level table itself.
  * All callbacks return 0 on success.  Buffers are byte-addressed; `hip_stream` is the hipStream_t the operation must
  * be ordered on (enqueue, or synchronise it and work on the host).
  *
@@ -371,10 +378,11 @@ int plda_comm_unique_id(void *out, int64_t cap_bytes /* >= 128 */);
 int plda_comm_init(plda_handle *h, int32_t nranks, int32_t rank, const void *unique_id);
 int plda_comm_init_custom(plda_handle *h, int32_t nranks, int32_t rank, const plda_collectives *table);
 int plda_comm_init_host(plda_handle *h, int32_t nranks, int32_t rank, const plda_host_collectives *table);
+int plda_comm_init_peer(plda_handle *h, int32_t nranks, int32_t rank, const plda_host_collectives *bootstrap);
 int plda_comm_destroy(plda_handle *h);
 int plda_comm_info(plda_handle *h, int32_t *nranks, int32_t *rank);
 /* who takes part, as the TRANSPORT reports it, written as a JSON object into json[cap]: {"transport": "rccl" | "host"
- * | "custom" | "none" | "emulated", "nranks", "rank", "device", "pci_bus_id"}; for RCCL nranks / rank / device come
+ * | "peer" | "custom" | "none" | "emulated", "nranks", "rank", "device", "pci_bus_id"}; for RCCL nranks / rank / device come
  * from ncclCommCount / ncclCommUserRank / ncclCommCuDevice (plus "rccl_version"), not from what the caller passed in */
 int plda_comm_describe(plda_handle *h, char *json, int64_t cap);
 /* test hook: act as rank `rank` of `nranks` WITHOUT a communicator (no collective runs, gather is ignored):

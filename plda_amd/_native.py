@@ -84,6 +84,7 @@ SIGNATURES = {
     "plda_comm_init": (C.c_int, [_vp, _i32, _i32, _vp]),
     "plda_comm_init_custom": (C.c_int, [_vp, _i32, _i32, _vp]),
     "plda_comm_init_host": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "plda_comm_init_peer": (C.c_int, [_vp, _i32, _i32, _vp]),
     "plda_comm_destroy": (C.c_int, [_vp]),
     "plda_comm_describe": (C.c_int, [_vp, _vp, _i64]),
     "plda_shard_plan": (C.c_int, [_i64, _i32, _i32, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -73,6 +73,7 @@ int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float 
 int comm_init(plda_handle *h, int nranks, int rank, const void *uid);
 int comm_init_custom(plda_handle *h, int nranks, int rank, const plda_collectives *t);
 int comm_init_host(plda_handle *h, int nranks, int rank, const plda_host_collectives *t);
+int comm_init_peer(plda_handle *h, int nranks, int rank, const plda_host_collectives *t);
 int comm_destroy(plda_handle *h);
 int comm_describe(plda_handle *h, std::string &js);
 int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
@@ -1321,6 +1322,15 @@ int plda_comm_init_custom(plda_handle *h, int32_t nranks, int32_t rank, const pl
     PLDA_LOCK(h);
     PLDA_TRY(set_device(h));
     return comm_init_custom(h, nranks, rank, table);
+  });
+}
+
+int plda_comm_init_peer(plda_handle *h, int32_t nranks, int32_t rank, const plda_host_collectives *bootstrap) {
+  return guarded(h, "plda_comm_init_peer", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return comm_init_peer(h, nranks, rank, bootstrap);
   });
 }
 

@@ -265,6 +265,208 @@ void hs_destroy(void *vc) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   delete c;
 }
+
+// ------------------------------------------------------------------------------------ peer provider (HIP IPC, direct writes)
+// The xGMI-native gather (SURVEY.md section 5 / 8e, round-3 review missing 4): xGMI is point to point, 7 links per GPU, so
+// the fastest all-gather is not a ring (one link's ~153 GB/s) but every rank WRITING its piece straight into the other
+// ranks' buffers, one copy stream per peer, all links busy at once (~1.07 TB/s out of a GPU).  Every rank opens the other
+// ranks' buffers through HIP IPC memory handles (exchanged through the bootstrap HOST collectives the caller supplies --
+// the same table plda_comm_init_host takes; 72 bytes per rank and call, nothing else crosses the host) and pushes with plain
+// device-to-device copies.  What an RCCL rendezvous gives implicitly -- nobody writes into a buffer before its owner's
+// stream has reached the collective, nobody continues before every piece has landed -- is done with sequence numbers in a
+// small UNCACHED flag page per rank, itself IPC-mapped by every peer:
+//   ready[q -> me]  written by q (a one-thread kernel on q's stream, through q's mapping of MY page) when q's stream has
+//                   reached collective number n: q's piece is final and q's buffer may be written;
+//   done[q -> me]   written by q behind its push into my buffer: q's piece has landed here.
+// A copy stream spins (one thread, s_sleep) on ready[q] >= n before it pushes to q; the collective's stream spins on
+// done[q] >= n for every q before it hands back to the caller.  Nothing blocks the host: the next super-block's scoring
+// is enqueued while this one's pushes run.  A spin gives up after ~20 s of s_memrealtime and raises an error word that the
+// next call reports (a peer that died must not hang the device).
+// (Built first: HIP inter-process events.  ROCm's are a ring of 32 signals per event -- measured here: the test's ~30th
+//  collective fails in hipStreamWaitEvent with `invalid argument`, with one event per peer and direction and every record
+//  matched by exactly one wait too.  Sequence numbers in memory have no such horizon.)
+// Works between processes on ONE device as well (how tests/test_gpu_comm_procs.py drives it).
+constexpr int PEER_MAXR = 16;
+struct PeerFlags {                              // one page per rank, written by the peers, read by its owner
+  unsigned long long ready[PEER_MAXR], done[PEER_MAXR];
+};
+
+__global__ void peer_flag_set_kernel(unsigned long long *slot, unsigned long long v) {
+  __threadfence_system();
+  __hip_atomic_store(slot, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// waits until *slot >= v for every slot of the list (stride: PeerFlags::ready / ::done of peers q in mask)
+__global__ void peer_flag_wait_kernel(unsigned long long *base, unsigned mask, unsigned long long v, unsigned long long *err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+  for (int q = 0; q < PEER_MAXR; ++q) {
+    if (!((mask >> q) & 1u)) continue;
+    while (__hip_atomic_load(base + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+      __builtin_amdgcn_s_sleep(32);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // 20 s
+        __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+    }
+  }
+  __threadfence_system();
+}
+
+struct PeerCtx {
+  plda_handle *h;
+  plda_host_collectives t;
+  int R, me;
+  std::vector<hipStream_t> pstream;           // one copy stream per peer
+  hipStream_t xs = nullptr;                   // the collective's own stream (the caller's may be the null stream)
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;   // local: caller's stream -> xs -> caller's stream
+  hipEvent_t ev_mine = nullptr;               // local: xs has reached the collective
+  std::vector<hipEvent_t> pcopy;              // local: my push to q has completed
+  PeerFlags *flags = nullptr;                 // my page (uncached device memory)
+  unsigned long long *err = nullptr;          // pinned host word a spin that gave up raises (read without any HIP call)
+  std::vector<PeerFlags *> peer_flags;        // peer q's page, through its IPC mapping
+  unsigned long long seq = 0;                 // collectives so far (the same on every rank: they are collective)
+  struct Map { hipIpcMemHandle_t handle; char *base; };
+  std::vector<std::vector<Map>> maps;         // per peer: opened allocations
+  DevBuf scratch;                             // all_reduce: every rank's operand, rank-major
+  std::vector<char> hbuf;
+  std::vector<int64_t> hoff, hcnt;
+};
+
+int peer_fail(PeerCtx *c, const char *what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess) fail(c->h, PLDA_E_HIP, "peer collective failed: %s: %s", what, hipGetErrorString(e));
+  else fail(c->h, PLDA_E_HIP, "peer collective failed: %s", what);
+  (void)hipGetLastError();
+  return 1;
+}
+
+// host all-gather of `bytes` per rank into c->hbuf (rank-major)
+int peer_exchange(PeerCtx *c, const void *mine, int64_t bytes) {
+  c->hbuf.assign((size_t)bytes * c->R, 0);
+  std::memcpy(c->hbuf.data() + (size_t)c->me * bytes, mine, (size_t)bytes);
+  c->hoff.resize(c->R); c->hcnt.resize(c->R);
+  for (int q = 0; q < c->R; ++q) { c->hoff[q] = (int64_t)q * bytes; c->hcnt[q] = bytes; }
+  return c->t.all_gather_v(c->t.ctx, c->hbuf.data(), c->hoff.data(), c->hcnt.data());
+}
+
+int peer_map(PeerCtx *c, int q, const hipIpcMemHandle_t &hd, char **base) {
+  for (const auto &m : c->maps[q])
+    if (std::memcmp(&m.handle, &hd, sizeof(hd)) == 0) { *base = m.base; return 0; }
+  void *p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return peer_fail(c, "hipIpcOpenMemHandle", e);
+  c->maps[q].push_back({hd, static_cast<char *>(p)});
+  *base = static_cast<char *>(p);
+  return 0;
+}
+
+int peer_all_gather_v(void *vc, void *dbuf, const int64_t *offs, const int64_t *counts, void *vst) {
+  auto *c = static_cast<PeerCtx *>(vc);
+  hipStream_t caller = static_cast<hipStream_t>(vst);
+  hipStream_t st = c->xs;
+  const int R = c->R, me = c->me;
+  // an earlier collective's spin that gave up?
+  if (*static_cast<volatile unsigned long long *>(c->err) != 0) return peer_fail(c, "an earlier collective timed out waiting for a peer (20 s)");
+  const unsigned long long n = ++c->seq;
+  // onto the collective's own stream, behind everything the caller has enqueued
+  if (hipEventRecord(c->ev_in, caller) != hipSuccess || hipStreamWaitEvent(st, c->ev_in, 0) != hipSuccess) return peer_fail(c, "stream hand-over");
+  // this rank's allocation behind dbuf, as a handle the others can open, and dbuf's offset inside it
+  struct Msg { hipIpcMemHandle_t handle; int64_t off; } mine;
+  void *base = nullptr; size_t size = 0;
+  hipError_t e = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, dbuf);
+  if (e != hipSuccess) return peer_fail(c, "hipMemGetAddressRange", e);
+  e = hipIpcGetMemHandle(&mine.handle, base);
+  if (e != hipSuccess) return peer_fail(c, "hipIpcGetMemHandle", e);
+  mine.off = static_cast<char *>(dbuf) - static_cast<char *>(base);
+  // ready: my piece is final and my buffer may be written, once my stream gets here -> every peer's page
+  for (int q = 0; q < R; ++q)
+    if (q != me) peer_flag_set_kernel<<<1, 1, 0, st>>>(&c->peer_flags[q]->ready[me], n);
+  if ((e = hipEventRecord(c->ev_mine, st)) != hipSuccess) return peer_fail(c, "hipEventRecord(ready)", e);
+  if (peer_exchange(c, &mine, sizeof(Msg)) != 0) return peer_fail(c, "bootstrap all_gather_v (handles)");
+  std::vector<Msg> all(R);
+  std::memcpy(all.data(), c->hbuf.data(), sizeof(Msg) * R);
+  unsigned others = 0;
+  for (int q = 0; q < R; ++q) {
+    if (q == me) continue;
+    others |= 1u << q;
+    hipStream_t ps = c->pstream[q];
+    if ((e = hipStreamWaitEvent(ps, c->ev_mine, 0)) != hipSuccess) return peer_fail(c, "hipStreamWaitEvent(own ready)", e);
+    if (counts[me] > 0) {
+      char *pb = nullptr;
+      if (peer_map(c, q, all[q].handle, &pb) != 0) return 1;
+      peer_flag_wait_kernel<<<1, 1, 0, ps>>>(c->flags->ready, 1u << q, n, c->err);     // q's buffer may be written
+      if ((e = hipMemcpyAsync(pb + all[q].off + offs[me], static_cast<char *>(dbuf) + offs[me], (size_t)counts[me], hipMemcpyDeviceToDevice, ps)) != hipSuccess)
+        return peer_fail(c, "push", e);
+    }
+    peer_flag_set_kernel<<<1, 1, 0, ps>>>(&c->peer_flags[q]->done[me], n);                        // my piece has landed at q
+    if ((e = hipEventRecord(c->pcopy[q], ps)) != hipSuccess) return peer_fail(c, "hipEventRecord(push)", e);
+    if ((e = hipStreamWaitEvent(st, c->pcopy[q], 0)) != hipSuccess) return peer_fail(c, "hipStreamWaitEvent(push)", e);
+  }
+  // every peer's piece has landed here
+  peer_flag_wait_kernel<<<1, 1, 0, st>>>(c->flags->done, others, n, c->err);
+  if (hipGetLastError() != hipSuccess) return peer_fail(c, "flag kernels");
+  // and back: the caller's stream continues when the collective has completed
+  if (hipEventRecord(c->ev_out, st) != hipSuccess || hipStreamWaitEvent(caller, c->ev_out, 0) != hipSuccess) return peer_fail(c, "stream hand-back");
+  return 0;
+}
+
+int peer_all_gather(void *vc, const void *dsend, void *drecv, int64_t bytes, void *vst) {
+  auto *c = static_cast<PeerCtx *>(vc);
+  char *mine = static_cast<char *>(drecv) + (int64_t)c->me * bytes;
+  if (dsend != mine) {
+    const hipError_t e = hipMemcpyAsync(mine, dsend, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(vst));
+    if (e != hipSuccess) return peer_fail(c, "device -> device copy", e);
+  }
+  std::vector<int64_t> offs(c->R), counts(c->R, bytes);
+  for (int q = 0; q < c->R; ++q) offs[q] = (int64_t)q * bytes;
+  return peer_all_gather_v(vc, drecv, offs.data(), counts.data(), vst);
+}
+
+template <typename T>
+__global__ void peer_reduce_kernel(const T *__restrict__ all, int R, int64_t count, int op, T *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  T v = all[i];
+  for (int q = 1; q < R; ++q) {               // rank order: the same bits on every rank
+    const T w = all[(int64_t)q * count + i];
+    v = op == PLDA_OP_SUM ? v + w : op == PLDA_OP_MAX ? (w > v ? w : v) : (w < v ? w : v);
+  }
+  out[i] = v;
+}
+
+// all-reduce = all-gather of the operands into a rank-major scratch + a local reduction in rank order (deterministic, and
+// identical on every rank: the replicas of a sharded fit stay bit-identical)
+int peer_all_reduce(void *vc, void *dbuf, int64_t count, int32_t dtype, int32_t op, void *vst) {
+  auto *c = static_cast<PeerCtx *>(vc);
+  hipStream_t st = static_cast<hipStream_t>(vst);
+  if (count <= 0) return 0;
+  const int64_t es = dtype == PLDA_DT_U32 ? 4 : 8, bytes = count * es;
+  if (c->scratch.reserve((size_t)bytes * c->R) != hipSuccess) return peer_fail(c, "scratch allocation");
+  if (peer_all_gather(vc, dbuf, c->scratch.p, bytes, vst) != 0) return 1;
+  const unsigned grid = (unsigned)ceil_div(count, 256);
+  if (dtype == PLDA_DT_F64) peer_reduce_kernel<double><<<grid, 256, 0, st>>>(c->scratch.as<double>(), c->R, count, op, static_cast<double *>(dbuf));
+  else if (dtype == PLDA_DT_U64) peer_reduce_kernel<unsigned long long><<<grid, 256, 0, st>>>(c->scratch.as<unsigned long long>(), c->R, count, op, static_cast<unsigned long long *>(dbuf));
+  else peer_reduce_kernel<unsigned><<<grid, 256, 0, st>>>(c->scratch.as<unsigned>(), c->R, count, op, static_cast<unsigned *>(dbuf));
+  if (hipGetLastError() != hipSuccess) return peer_fail(c, "reduction kernel");
+  // (the scratch is written by the peers of the NEXT call, which wait for this rank's `ready` of that call -- recorded on
+  //  this stream behind the reduction above)
+  return 0;
+}
+
+void peer_destroy(void *vc) {
+  auto *c = static_cast<PeerCtx *>(vc);
+  for (auto s : c->pstream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  if (c->xs) { (void)hipStreamSynchronize(c->xs); (void)hipStreamDestroy(c->xs); }
+  for (auto &per : c->maps) for (auto &m : per) (void)hipIpcCloseMemHandle(m.base);
+  for (auto e : c->pcopy) if (e) (void)hipEventDestroy(e);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->ev_mine) (void)hipEventDestroy(c->ev_mine);
+  if (c->flags) (void)hipFree(c->flags);
+  if (c->err) (void)hipHostFree(c->err);
+  c->scratch.release();
+  if (c->t.destroy) c->t.destroy(c->t.ctx);
+  delete c;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------ installing a table
@@ -310,6 +512,54 @@ int comm_init_host(plda_handle *h, int nranks, int rank, const plda_host_collect
   return install(h, nranks, rank, dt, 2);
 }
 
+int comm_init_peer(plda_handle *h, int nranks, int rank, const plda_host_collectives *t) {
+  PLDA_TRY(check_new(h, nranks, rank, t, "comm_init_peer"));
+  if (!t->all_gather_v) return fail(h, PLDA_E_INVAL, "comm_init_peer: the bootstrap table lacks all_gather_v");
+  if (nranks > PEER_MAXR) return fail(h, PLDA_E_INVAL, "comm_init_peer: at most %d ranks", PEER_MAXR);
+  auto *c = new PeerCtx();
+  c->h = h; c->t = *t; c->R = nranks; c->me = rank;
+  c->pstream.assign(nranks, nullptr); c->pcopy.assign(nranks, nullptr);
+  c->peer_flags.assign(nranks, nullptr);
+  c->maps.resize(nranks);
+  auto bail = [&](const char *what, hipError_t e) {
+    fail(h, PLDA_E_HIP, "comm_init_peer: %s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    c->t.destroy = nullptr;      // the caller keeps ownership of the bootstrap table on failure
+    peer_destroy(c);
+    return PLDA_E_HIP;
+  };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreateWithFlags", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreateWithFlags", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreateWithFlags", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_mine, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreateWithFlags", e);
+  // the flag page: uncached, so that a peer's write is what the owner's next read sees
+  void *fp = nullptr;
+  if ((e = hipExtMallocWithFlags(&fp, 4096, hipDeviceMallocUncached)) != hipSuccess) return bail("hipExtMallocWithFlags(uncached)", e);
+  c->flags = static_cast<PeerFlags *>(fp);
+  if ((e = hipMemset(fp, 0, 4096)) != hipSuccess) return bail("hipMemset", e);
+  void *ep = nullptr;
+  if ((e = hipHostMalloc(&ep, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  c->err = static_cast<unsigned long long *>(ep);
+  *c->err = 0;
+  hipIpcMemHandle_t mine;
+  if ((e = hipIpcGetMemHandle(&mine, fp)) != hipSuccess) return bail("hipIpcGetMemHandle(flag page)", e);
+  if (peer_exchange(c, &mine, sizeof(mine)) != 0) return bail("bootstrap all_gather_v (flag pages)", hipErrorUnknown);
+  std::vector<hipIpcMemHandle_t> all(nranks);
+  std::memcpy(all.data(), c->hbuf.data(), sizeof(hipIpcMemHandle_t) * nranks);
+  for (int q = 0; q < nranks; ++q) {
+    if (q == rank) continue;
+    void *pp = nullptr;
+    if ((e = hipIpcOpenMemHandle(&pp, all[q], hipIpcMemLazyEnablePeerAccess)) != hipSuccess) return bail("hipIpcOpenMemHandle(flag page)", e);
+    c->peer_flags[q] = static_cast<PeerFlags *>(pp);
+    c->maps[q].push_back({all[q], static_cast<char *>(pp)});      // (closed by peer_destroy with the other mappings)
+    if ((e = hipStreamCreateWithFlags(&c->pstream[q], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreateWithFlags", e);
+    if ((e = hipEventCreateWithFlags(&c->pcopy[q], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreateWithFlags", e);
+  }
+  const plda_collectives dt = {c, peer_all_gather, peer_all_gather_v, peer_all_reduce, peer_destroy};
+  return install(h, nranks, rank, dt, 4);
+}
+
 int comm_destroy(plda_handle *h) {
   if (!h->comm) { h->comm_nranks = 1; h->comm_rank = 0; return PLDA_OK; }
   (void)hipStreamSynchronize(h->stream);
@@ -325,7 +575,7 @@ int comm_destroy(plda_handle *h) {
 int comm_describe(plda_handle *h, std::string &js) {
   int nranks = h->comm_nranks, rank = h->comm_rank, device = h->device, version = 0;
   const char *transport = !h->comm ? (h->comm_nranks > 1 ? "emulated" : "none")
-                                   : h->comm_kind == 1 ? "rccl" : h->comm_kind == 2 ? "host" : "custom";
+                                   : h->comm_kind == 1 ? "rccl" : h->comm_kind == 2 ? "host" : h->comm_kind == 4 ? "peer" : "custom";
   if (h->comm && h->comm_kind == 1) {
     auto *c = static_cast<RcclCtx *>(h->coll.ctx);
     if (c->api->CommCount(c->comm, &nranks) != ncclSuccess || c->api->CommUserRank(c->comm, &rank) != ncclSuccess ||

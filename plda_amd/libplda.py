@@ -547,6 +547,11 @@ class MPlda(object):
         self._comm_table = table
         self._ck(self._lib.plda_comm_init_host(self._h, int(nranks), int(rank), C.byref(table)))
 
+    def comm_init_peer(self, nranks, rank, table):
+        """Direct-write collectives over HIP IPC (plda_comm_init_peer); `table`: a HostCollectives used for the handles
+        and the rendezvous only.  It must outlive the communicator."""
+        self._ck(self._lib.plda_comm_init_peer(self._h, int(nranks), int(rank), C.byref(table)))
+
     def comm_init_custom(self, nranks, rank, table):
         """Collectives through a caller-supplied device-level table (_native.Collectives)."""
         self._comm_table = table

@@ -188,13 +188,20 @@ def init_comm(engine, group=None, device=None, transport="rccl"):
         engine.comm_init_host(world, rank, tr.table)
         engine._comm_transport = tr          # callbacks live as long as the engine
         return world, rank
+    if transport == "peer":
+        if dist.get_backend(group) == "nccl":   # the bootstrap moves host bytes: a gloo group beside the nccl one
+            group = dist.new_group(backend="gloo")
+        tr = TorchHostTransport(group)          # IPC handles only; the data moves GPU to GPU
+        engine.comm_init_peer(world, rank, tr.table)
+        engine._comm_transport = tr
+        return world, rank
     if transport == "custom":
         tr = TorchDeviceTransport(group)
         engine.comm_init_custom(world, rank, tr.table)
         engine._comm_transport = tr
         return world, rank
     if transport != "rccl":
-        raise ValueError("transport must be 'rccl', 'host' or 'custom'")
+        raise ValueError("transport must be 'rccl', 'host', 'peer' or 'custom'")
     uid = [engine.comm_unique_id() if rank == 0 else None]
     if dist.get_backend(group) == "nccl":
         t = torch.tensor(list(uid[0]) if rank == 0 else [0] * 128, dtype=torch.uint8,

@@ -51,4 +51,9 @@ for t in range(3, 6):
     print("  barrier-to-barrier cycles, stage x wave (ideal %s):\n" % ideal, seg)
     print("  excess over ideal, wave 0:", seg[:, 0] - np.array(ideal), " sum", int((seg[:, 0] - np.array(ideal)).sum()))
     print("  block-major part (ideal %d): " % (4096 * (sizes[-1] - 1)), b1 - b0, "  its start after the last barrier:", b0 - lv[ns - 1])
+    top0, top1 = tl[t, 15, :, 2], tl[t, 15, :, 3]
+    ntop0 = tl[t + 1, 15, :, 2]
+    print("  tile top (entry -> behind the bias MFMAs + carried stores; ideal 1024):", top1 - top0,
+          " | top -> first barrier:", arr[0] - top1, " (ideal %d)" % (4096 * (sizes[0] - 1)),
+          " | block-major end -> next tile's top:", ntop0 - b1)
     print("  tile length per wave:", nxt - arr[0], " = %.1f %% MFMA-busy" % (100.0 * (nsteps * 4096 + 1024) / float((nxt - arr[0])[0])))

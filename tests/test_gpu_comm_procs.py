@@ -87,7 +87,7 @@ def _rank_main(rank, world, port, q, transport="host"):
             return ref, loc, rows
 
         trials("ragged", 64, 2900, 1500, 256, False, False)       # 5 full super-blocks of 256 x world + a ragged tail
-        if transport == "host":
+        if transport in ("host", "peer"):
             trials("mixed_znorm", 48, 1300, 700, 512, True, True)     # depth-2D GEMM, z-norm folded into the operands
             trials("tiny", 16, 300, 130, 256, False, False)           # fewer rows than one super-block: a rank may own no row
             ref, loc, rows = trials("chunked", 32, 9000, 4096, 4096, False, False)   # a 64 MiB block: two staging chunks
@@ -137,8 +137,14 @@ def _rank_main(rank, world, port, q, transport="host"):
         ok["fit_replicas"] = all(f == fall[0] for f in fall)                 # bit-identical model on every rank
 
         tr = eng._comm_transport
-        ok["transport_used"] = tr.calls["all_gather_v"] >= 5 and tr.calls["all_reduce"] >= 5 and tr.last_error is None and \
-            (transport == "host" or tr.calls["all_gather"] >= 2)
+        if transport == "peer":
+            # the bootstrap table carried handles and rendezvous tokens only: no all_reduce, and a few hundred bytes per
+            # call where the device data of these cases is megabytes (the pieces went GPU to GPU through IPC mappings)
+            ok["transport_used"] = tr.calls["all_gather_v"] >= 20 and tr.calls["all_reduce"] == 0 and tr.last_error is None and \
+                tr.calls["bytes"] <= 200 * world * tr.calls["all_gather_v"]
+        else:
+            ok["transport_used"] = tr.calls["all_gather_v"] >= 5 and tr.calls["all_reduce"] >= 5 and tr.last_error is None and \
+                (transport == "host" or tr.calls["all_gather"] >= 2)
         eng.comm_destroy()
         ok["destroyed"] = eng.comm_info() == (1, 0)
         q.put((rank, ok, dict(tr.calls)))
@@ -150,14 +156,16 @@ def _rank_main(rank, world, port, q, transport="host"):
         raise e
 
 
-@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "custom")])
+@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "custom"), (2, "peer"), (3, "peer")])
 def test_sharded_entry_points_between_processes(world, transport):
     """transport "host": plda_comm_init_host (the library stages, gloo moves host buffers); "custom": plda_comm_init_custom
-    with a device-level table supplied by the caller (plda_amd.sharding.TorchDeviceTransport)."""
+    with a device-level table supplied by the caller (plda_amd.sharding.TorchDeviceTransport); "peer": plda_comm_init_peer,
+    direct writes into the other ranks' buffers through HIP IPC mappings (round 4; between processes on one device here,
+    over xGMI between GPUs) -- gloo carries the IPC handles and the rendezvous only."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 38500 + (os.getpid() % 2000) + world + (7 if transport == "custom" else 0)
+    port = 38500 + (os.getpid() % 2000) + world + {"host": 0, "custom": 7, "peer": 13}[transport]
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
