@@ -81,7 +81,10 @@ for label, pat in (("fetch", "*fetch*counter_collection.csv"), ("write", "*write
 
 
 # machine-readable HBM traffic of the dominant kernel, per launch (consumed by bench.py)
-traffic = {"shape": shape, "kernel": "trials_gemm_bt2_kernel", "round": tag}
+names = set()
+for f in find("*fetch*counter_collection.csv"):
+    names |= {short(r.get("Kernel_Name", "")) for r in csv.DictReader(open(f)) if "trials_gemm" in r.get("Kernel_Name", "")}
+traffic = {"shape": shape, "kernel": " + ".join(sorted(names)) or "?", "round": tag}
 for label, pat in (("FETCH_SIZE", "*fetch*counter_collection.csv"), ("WRITE_SIZE", "*write*counter_collection.csv")):
     for f in find(pat):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
