@@ -73,10 +73,10 @@ __device__ __forceinline__ double tf_rcp(double x) {   // hardware estimate + tw
 }
 
 // geometry of one instantiation, shared by the kernel and its launcher
-template <int NT, int CH, int KS>
+template <int NT, int CH, int KS, int RT = 1>
 struct TfGeom {
-  static constexpr int RG = 8 / CH;                    // row groups of 16
-  static constexpr int ROWS = 16 * RG;
+  static constexpr int RG = 8 / CH;                    // row groups of 16 RT rows
+  static constexpr int ROWS = 16 * RT * RG;
   static constexpr int COLS = 16 * NT * CH;
   static constexpr int RPP = 512 / KS;                 // rows one fetch pass of the 512 threads covers (KS k each)
   static constexpr int TP = (COLS + RPP - 1) / RPP;    // fetch passes over T's rows
@@ -97,14 +97,17 @@ struct TfGeom {
 // 70 % of the cycles at D = 256.)
 //
 // KS, the depth of a stage (a multiple of 4), is a parameter of the geometry; every class runs 16 (see the dispatch).
-template <int NT, int CH, int KS, bool PERROW>
+// RT (round 4, A/B arm only): row tiles per wave.  With one row tile a wave reads 1 + NT fragments per NT MFMAs (D = 200: 14
+// for 13) -- 67 bytes per clock of LDS fragment traffic per CU beside the stage writes; with RT = 2 and half the columns it
+// reads 2 + NT for 2 NT MFMAs (9 for 14), the same block of 128 rows.  Slower (see transform_class).
+template <int NT, int CH, int KS, bool PERROW, int RT = 1>
 __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__restrict__ X, int64_t R, int Din,
                                                               const double *__restrict__ Tpad, int Dinp, int Dout,
                                                               const double *__restrict__ offset,
                                                               const double *__restrict__ psi,
                                                               const int32_t *__restrict__ n_arr, int n_uniform,
                                                               double *__restrict__ out) {
-  using G = TfGeom<NT, CH, KS>;
+  using G = TfGeom<NT, CH, KS, RT>;
   constexpr int RG = G::RG, ROWS = G::ROWS, COLS = G::COLS, RPP = G::RPP, TP = G::TP, TR = G::TR, XP = G::XP;
   constexpr int LD = G::LD, STAGE = G::STAGE, KSTEPS = KS / 4;
   constexpr bool XPART = ROWS % RPP != 0;   // the last X pass covers rows beyond the block: no LDS row for them
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   const bool loader = lr < RPP;             // (512 is not a multiple of every KS: a few threads carry nothing)
   const double *tptr = Tpad + (int64_t)min(lr, RPP - 1) * Dinp + lk;
   const int64_t tstep = (int64_t)RPP * Dinp;
-  const int tfrag = (ch * NT * 16 + fi) * LD + fk, xfrag = (TR + rg * 16 + fi) * LD + fk;
+  const int tfrag = (ch * NT * 16 + fi) * LD + fk, xfrag = (TR + rg * 16 * RT + fi) * LD + fk;
   const bool early = wave >= 4;
   // Persistent: one workgroup per CU walks over the row blocks.  (One workgroup fills a CU -- registers -- so between
   // two of them the CU stood idle for the whole turnaround, ~17k cycles per 128-row block: wave launch, LDS
@@ -168,9 +171,11 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
   __syncthreads();
   for (;;) {
     const int64_t r0 = blk * ROWS;
-    f64x4s acc[NT];
+    f64x4s acc[RT][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = f64x4s{0.0, 0.0, 0.0, 0.0};
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[rt][i] = f64x4s{0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < Din; k0 += KS) {
       const bool more = k0 + KS < Din;
       if (early && more) stage(tf_lds + (cur ^ 1) * STAGE, k0 + KS);
@@ -181,11 +186,14 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
         if (kk < ksteps) {
-          const double a = Xs[kk * 4];
+          double a[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) a[rt] = Xs[rt * 16 * LD + kk * 4];
 #pragma unroll
           for (int tn = 0; tn < NT; ++tn) {
             const double b = Ts[tn * 16 * LD + kk * 4];
-            acc[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tn], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b, acc[rt][tn], 0, 0, 0);
           }
         }
         if (dofetch && kk < 2) fetch(kf, kk);
@@ -218,26 +226,32 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
       ep[c] = PERROW ? ps : tf_rcp(ps + inv_nu);
     }
     __syncthreads();
-    // accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row group
-    double part[4] = {0.0, 0.0, 0.0, 0.0};
-    int64_t grow[4];
+    // accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row tile
+    double part[RT][4];
+    int64_t grow[RT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) grow[r] = r0 + rg * 16 + fk + 4 * r;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { part[rt][r] = 0.0; grow[rt][r] = r0 + rg * 16 * RT + rt * 16 + fk + 4 * r; }
     if constexpr (PERROW) {
-      double inv_n[4];
+      double inv_n[RT][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) inv_n[r] = 1.0 / (double)n_arr[min(grow[r], R - 1)];
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) inv_n[rt][r] = 1.0 / (double)n_arr[min(grow[rt][r], R - 1)];
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) {
         const int col = (ch * NT + tn) * 16 + fi;
         const bool cok = col < Dout;
         const double off = eo[col], ps = ep[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double v = cok ? acc[tn][r] + off : 0.0;
-          acc[tn][r] = v;
-          part[r] = fma(v * v, tf_rcp(ps + inv_n[r]), part[r]);
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = cok ? acc[rt][tn][r] + off : 0.0;
+            acc[rt][tn][r] = v;
+            part[rt][r] = fma(v * v, tf_rcp(ps + inv_n[rt][r]), part[rt][r]);
+          }
       }
     } else {
 #pragma unroll
@@ -246,44 +260,54 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
         const bool cok = col < Dout;
         const double off = eo[col], w = ep[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double v = cok ? acc[tn][r] + off : 0.0;
-          acc[tn][r] = v;
-          part[r] = fma(v * v, w, part[r]);
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = cok ? acc[rt][tn][r] + off : 0.0;
+            acc[rt][tn][r] = v;
+            part[rt][r] = fma(v * v, w, part[rt][r]);
+          }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) part[r] += __shfl_xor(part[r], o);
-    }
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) part[rt][r] += __shfl_xor(part[rt][r], o);
+      }
     if (CH > 1) {     // the other column slices of the same rows live in waves (rg, ch'): exchange through LDS
       if (fi == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 + fk + 4 * r] = part[r];
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 * RT + rt * 16 + fk + 4 * r] = part[rt][r];
       }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double sum = 0.0;
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int c = 0; c < CH; ++c) sum += red[c * ROWS + rg * 16 + fk + 4 * r];   // fixed order: every slice gets the same sum
-        part[r] = sum;
-      }
+        for (int r = 0; r < 4; ++r) {
+          double sum = 0.0;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) sum += red[c * ROWS + rg * 16 * RT + rt * 16 + fk + 4 * r];   // fixed order: every slice gets the same sum
+          part[rt][r] = sum;
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double f = sqrt((double)Dout / part[r]);
-      if (grow[r] < R) {
-        double *o = out + grow[r] * (int64_t)Dout;
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int tn = 0; tn < NT; ++tn) {
-          const int col = (ch * NT + tn) * 16 + fi;
-          if (col < Dout) o[col] = f * acc[tn][r];
+      for (int r = 0; r < 4; ++r) {
+        const double f = sqrt((double)Dout / part[rt][r]);
+        if (grow[rt][r] < R) {
+          double *o = out + grow[rt][r] * (int64_t)Dout;
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) {
+            const int col = (ch * NT + tn) * 16 + fi;
+            if (col < Dout) o[col] = f * acc[rt][tn][r];
+          }
         }
       }
-    }
     if (!has_next) break;
     // (no barrier: the scratch above is in buffer cur ^ 1, which is next written behind the barrier below)
     stage(tf_lds + cur * STAGE, 0);
@@ -522,20 +546,20 @@ __global__ void pad_transform_kernel(const double *__restrict__ T, int Dout, int
   Tpad[idx] = (r < Dout && c < Din) ? T[(int64_t)r * Din + c] : 0.0;
 }
 
-template <int NT, int CH, int KS, bool PERROW>
+template <int NT, int CH, int KS, bool PERROW, int RT = 1>
 static int launch_transform_fused_t(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
                                     int n_uniform, double *dout, int Dinp) {
-  using G = TfGeom<NT, CH, KS>;
+  using G = TfGeom<NT, CH, KS, RT>;
   static_assert(KS % 4 == 0 && KS >= 8, "a stage is a whole number of 4-k MFMA steps, and at least two of them");
   static_assert(G::LDS_BYTES <= 160 * 1024, "stage buffers exceed the LDS of a CU");
   static_assert((size_t)(2 * G::COLS + CH * G::ROWS) * 8 <= G::LDS_BYTES / 2, "the epilogue's scratch must fit one stage buffer");
   static DeviceOnce attr;          // (per instantiation and device; setting it twice is harmless)
   if (attr.needed(h->device)) {
-    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH, KS, PERROW>),
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH, KS, PERROW, RT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
     attr.done(h->device);
   }
-  transform_fused_kernel<NT, CH, KS, PERROW><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)G::ROWS), h->num_cus), 512,
+  transform_fused_kernel<NT, CH, KS, PERROW, RT><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)G::ROWS), h->num_cus), 512,
                                                G::LDS_BYTES, h->stream>>>(
       dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn,
       n_uniform, dout);
@@ -564,9 +588,12 @@ static int launch_transform_dma_t(plda_handle *h, const double *dX, int64_t R, i
 
 // (the per-row-count epilogue is its own instantiation: as a run-time branch beside the uniform one it made every large
 // block shape spill, 92-372 bytes per lane)
-template <int NT, int CH, int KS>
+template <int NT, int CH, int KS, int RT = 1>
 static int launch_transform_fused(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
                                   int n_uniform, double *dout, int Dinp) {
+  if (RT > 1)
+    return dn ? launch_transform_fused_t<NT, CH, KS, true, RT>(h, dX, R, Din, dn, n_uniform, dout, Dinp)
+              : launch_transform_fused_t<NT, CH, KS, false, RT>(h, dX, R, Din, dn, n_uniform, dout, Dinp);
   // PLDA_TRANSFORM_VARIANT=7: the DMA-staged kernel (A/B arm; measured 2-6 % behind the register-staged one)
   if (KS == 16 && h->transform_variant == 7)
     return dn ? launch_transform_dma_t<NT, CH, true>(h, dX, R, Din, dn, n_uniform, dout, Dinp, h->tf_pad_rows)
@@ -579,12 +606,17 @@ template <int A, int B> constexpr int cmax() { return A > B ? A : B; }
 
 // the instantiations of one dimension class: the main block shape <NT0, CH0> (128 rows for CH0 = 1, 64 for CH0 = 2) and
 // the smaller tail blocks <NT1, 2> (64 rows; CH0 = 1 only), <NT2, 4> (32 rows), <NT3, 8> (16 rows); KS = stage depth
-template <int KS, int NT0, int CH0, int NT1, int NT2, int NT3>
+// <NTW, CHW>: round 4's A/B arm (PLDA_TRANSFORM_VARIANT=9) -- two row tiles per wave (RT = 2), CHW column slices of NTW
+// tiles: 9 fragment reads per 14 MFMAs at D = 200 instead of 14 per 13, the same 128-row block.  Measured SLOWER than the
+// one-row-tile shape (C2 0.216 against 0.200 ms = 0.47 / 0.51 of the fp64 peak, C4 0.737 / 0.752, interleaved,
+// gpurun_out/r4/k4_sweep.log): the LDS fragment traffic is not what bounds this kernel either.  Not the product path.
+template <int KS, int NT0, int CH0, int NT1, int NT2, int NT3, int NTW, int CHW>
 static int transform_class(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn, int n_uniform,
                            double *dout) {
   // the zero-padded copy of T ([rows >= every block shape's stage rows][Din rounded up to KS]), rebuilt only when the
   // model has changed (or another class's geometry was cached)
-  constexpr int PADROWS = cmax<cmax<TfGeom<NT0, CH0, KS>::TR, TfGeom<NT1, 2, KS>::TR>(),
+  constexpr int TRW = NTW > 0 ? TfGeom<(NTW > 0 ? NTW : 1), (NTW > 0 ? CHW : 1), KS, 2>::TR : 0;
+  constexpr int PADROWS = cmax<cmax<cmax<TfGeom<NT0, CH0, KS>::TR, TRW>(), TfGeom<NT1, 2, KS>::TR>(),
                                cmax<TfGeom<NT2, 4, KS>::TR, TfGeom<NT3, 8, KS>::TR>()>();
   const int Dinp = (int)round_up(Din, KS);
   if (h->tf_pad_epoch != h->model_epoch || h->tf_pad_rows != PADROWS || h->tf_pad_dinp != Dinp) {
@@ -594,12 +626,21 @@ static int transform_class(plda_handle *h, const double *dX, int64_t R, int Din,
     PLDA_LAUNCH_CHECK(h);
     h->tf_pad_epoch = h->model_epoch; h->tf_pad_rows = PADROWS; h->tf_pad_dinp = Dinp;
   }
-  constexpr int ROWS0 = 16 * (8 / CH0);
+  // (NTW = 0: no wide shape for this class -- above D = 256 two row tiles per wave spill; per-row counts with 8 tiles per
+  //  slice spill 68 bytes per lane: the round-3 shape there)
+  const bool wide = NTW > 0 && !(dn && NTW >= 8) && h->transform_variant == 9;
+  const int ROWS0 = wide ? 32 * (8 / (CHW > 0 ? CHW : 1)) : 16 * (8 / CH0);
   const int64_t G = h->num_cus;
   // main launch: a whole number of rounds of the persistent grid (PLDA_TRANSFORM_VARIANT=2: everything, as in round 2)
   const int64_t nb = ceil_div(R, (int64_t)ROWS0);
   const int64_t rows_main = h->transform_variant == 2 ? R : std::min(R, nb / G * G * ROWS0);
-  if (rows_main > 0) PLDA_TRY((launch_transform_fused<NT0, CH0, KS>(h, dX, rows_main, Din, dn, n_uniform, dout, Dinp)));
+  if (rows_main > 0) {
+    bool done = false;
+    if constexpr (NTW > 0) {
+      if (wide) { PLDA_TRY((launch_transform_fused<NTW, CHW, KS, 2>(h, dX, rows_main, Din, dn, n_uniform, dout, Dinp))); done = true; }
+    }
+    if (!done) PLDA_TRY((launch_transform_fused<NT0, CH0, KS>(h, dX, rows_main, Din, dn, n_uniform, dout, Dinp)));
+  }
   const int64_t Rt = R - rows_main;
   if (Rt <= 0) return PLDA_OK;
   // the rest: the smallest blocks that still give every CU at most one
@@ -628,11 +669,11 @@ int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, 
     // tail blocks>, NT * CH * 16 >= D in every shape.  Stage depth: 16 k everywhere -- deeper stages (20 ... 32 k, as
     // deep as the LDS allows per class) were measured and are no faster (C2 0.519 against 0.527 of the fp64 peak,
     // C4 0.728 against 0.757), so the 2.5 us a stage's data movement takes is not a latency a longer stage amortises.
-    if (D <= 128) return transform_class<16, 8, 1, 4, 2, 1>(h, dX, R, Din, dn, n_uniform, dout);
-    if (D <= 208) return transform_class<16, 13, 1, 7, 4, 2>(h, dX, R, Din, dn, n_uniform, dout);
-    if (D <= 256) return transform_class<16, 16, 1, 8, 4, 2>(h, dX, R, Din, dn, n_uniform, dout);
-    if (D <= 384) return transform_class<16, 12, 2, 12, 6, 3>(h, dX, R, Din, dn, n_uniform, dout);
-    return transform_class<16, 16, 2, 16, 8, 4>(h, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 128) return transform_class<16, 8, 1, 4, 2, 1, 4, 2>(h, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 208) return transform_class<16, 13, 1, 7, 4, 2, 7, 2>(h, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 256) return transform_class<16, 16, 1, 8, 4, 2, 8, 2>(h, dX, R, Din, dn, n_uniform, dout);
+    if (D <= 384) return transform_class<16, 12, 2, 12, 6, 3, 0, 0>(h, dX, R, Din, dn, n_uniform, dout);
+    return transform_class<16, 16, 2, 16, 8, 4, 0, 0>(h, dX, R, Din, dn, n_uniform, dout);
   }
   PLDA_TRY(gemm_f64(h, R, h->Dout, Din, 1.0, dX, Din, 1, h->d_transform.as<double>(), 1, Din,
                     nullptr, 0.0, dout, h->Dout));
