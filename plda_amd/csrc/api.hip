@@ -198,6 +198,7 @@ int plda_create(int device, plda_handle **out) {
     if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
     if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_PREP_VARIANT")) h->prep_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);

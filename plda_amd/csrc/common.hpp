@@ -110,6 +110,7 @@ struct plda_handle {
   int sort_variant = 0;        // PLDA_SORT_VARIANT=1: fit groups the rows by the radix sort always (0: by counting where the tables fit)
   int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass; 2: no tail launch (A/B arms)
   int gemm_variant = 0;
+  int prep_variant = 0;    // PLDA_PREP_VARIANT=1: scoring prep as separate bias / pack / pair kernels (A/B arm of prep_side_kernel)
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
   int sweep_variant = 0;  // PLDA_SWEEP_VARIANT=1: the 16-wave register kernels of round 2 (SPD inverse, tridiagonalisation); 2: the four-wave scalar sweep at every size (no matrix-core block sweep)

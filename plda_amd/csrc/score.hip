@@ -201,6 +201,113 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------
+// prep_side_kernel (round 4): weighted_sq_bias + pack + bias_pairs of ONE side in ONE pass over the
+// fp64 rows, for the uniform-count path (every BASELINE configuration but C4).  The three kernels above
+// read a side's rows twice (2 x R D 8 B) -- at C2 0.21 ms of a 28.5 ms step, more than the trials GEMM
+// has left to give.  A workgroup owns 64 rows; it walks the row in chunks of 64 dimensions: wave w
+// loads its 16 rows (one 512-byte piece per row and chunk, the next chunk's loads in flight under this
+// one's arithmetic), adds the lane's weighted square to the row's running sum -- lane l holds the
+// partial over d = l, l + 64, ... in increasing d, exactly the order of weighted_sq_bias_kernel, and the
+// same xor butterfly ends it: the biases are BIT-identical to the two-pass path (tests) -- and drops
+// the fp32 operand value into a 64 x 64 LDS tile, from which the k-quad planes leave as 1 KiB pieces.
+//   SIDE 0: enrol  A1 = c u / var (* s_i), r'_i, s_i, rpair        SIDE 1: test  V, q_j, cpair
+// HBM: R D 8 B read + R Kg 4 B written (Kg = D rounded up to 8).
+// ------------------------------------------------------------------------------------
+template <int SIDE>
+__global__ __launch_bounds__(256) void prep_side_kernel(const double *__restrict__ X, const double *__restrict__ w, const double *__restrict__ Lptr,
+                                                        int n_uniform, const double *__restrict__ psi, int D, int64_t R, int64_t Rpad, int KQ,
+                                                        const double *__restrict__ zmean, const double *__restrict__ zstd,
+                                                        float *__restrict__ P, float *__restrict__ bias, float *__restrict__ rscale,
+                                                        float2 *__restrict__ pair) {
+  __shared__ float tile[2][64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int64_t wrow0 = row0 + wave * 16;
+  const int nchunk = (KQ * 4 + 63) >> 6;
+  const bool zn = SIDE == 0 && zmean && zstd;
+  // per-row scale of the packed A operand (the z-norm map's 1 / zstd_i, rounded to fp32 as pack_kernel reads it)
+  float rsf[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    rsf[j] = 1.f;
+    if (zn && wrow0 + j < R) { const double sd = zstd[wrow0 + j]; rsf[j] = (float)(sd != 0.0 ? 1.0 / sd : 1.0); }
+  }
+  double acc[16], xc[16], xn[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { acc[j] = 0.0; xn[j] = 0.0; }
+  auto fetch = [&](int c, double (&x)[16]) {
+    const int d = c * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t row = wrow0 + j;
+      x[j] = (d < D && row < R) ? X[row * (int64_t)D + d] : 0.0;
+    }
+  };
+  fetch(0, xn);
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xc[j] = xn[j];
+    if (c + 1 < nchunk) fetch(c + 1, xn);
+    const int d = c * 64 + lane;
+    const bool dv = d < D;
+    const double wd = dv ? w[d] : 0.0;
+    double cc = 0.0, var = 1.0;
+    if (SIDE == 0 && dv) llr_coef((double)n_uniform, psi[d], cc, var);
+    float(*const tl)[65] = tile[c & 1];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double x = xc[j];
+      float val = 0.f;
+      if (dv && wrow0 + j < R) {
+        acc[j] += wd * x * x;
+        if (SIDE == 0) {
+          double v = cc * x / var;
+          if (zn) v *= (double)rsf[j];
+          val = (float)v;
+        } else {
+          val = (float)x;
+        }
+      }
+      tl[lane][wave * 16 + j] = val;
+    }
+    __syncthreads();
+    {
+      const int r = threadIdx.x & 63;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int q = (threadIdx.x >> 6) + pass * 4;   // k-quad of the chunk, 0..15
+        const int kq = c * 16 + q;
+        if (kq < KQ) {
+          f32x4 v;
+          v.x = tl[4 * q + 0][r];
+          v.y = tl[4 * q + 1][r];
+          v.z = tl[4 * q + 2][r];
+          v.w = tl[4 * q + 3][r];
+          reinterpret_cast<f32x4 *>(P)[(int64_t)kq * Rpad + row0 + r] = v;
+        }
+      }
+    }
+  }
+  const double Lc = SIDE == 0 ? *Lptr : 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double a = acc[j];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    const int64_t row = wrow0 + j;
+    if (lane == 0 && row < R) {
+      double r = -0.5 * (a + Lc), sc = 1.0;
+      if (zn) {
+        const double sd = zstd[row];
+        if (sd != 0.0) { sc = 1.0 / sd; r = (r - zmean[row]) * sc; }
+      }
+      bias[row] = (float)r;
+      if (SIDE == 0) { rscale[row] = (float)sc; pair[row] = make_float2((float)r, (float)sc); }
+      else pair[row] = make_float2(1.f, (float)r);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // K5 / K8: the trials GEMM, 128 x 128 form (small / medium problems and the fused z-norm
 // epilogue; large EPI-0 problems take the persistent 256 x 256 form further down).
 //   block  = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64
@@ -960,6 +1067,20 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
     PLDA_HIP(h, h->w[11].reserve((size_t)(2 * D + 1) * 8));
     double *coef = h->w[11].as<double>();
     uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
+    if (h->prep_variant == 0) {
+      // one pass per side: bias, bias pair and packed operand together (prep_side_kernel; PLDA_PREP_VARIANT=1: the
+      // separate kernels below, kept as the A/B arm and the reference the bit-identity test compares with)
+      if (doA)
+        prep_side_kernel<0><<<(unsigned)(op.Mpad / 64), 256, 0, h->stream>>>(
+            dU, coef, coef + 2 * D, n_uniform, psi, D, M, op.Mpad, op.KQ, dzmean, dzstd, h->s_Apk.as<float>(),
+            h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+      if (doB)
+        prep_side_kernel<1><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
+            dV, coef + D, coef + 2 * D, 0, psi, D, Nt, op.Npad, op.KQ, nullptr, nullptr, h->s_Bpk.as<float>(),
+            h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+      PLDA_LAUNCH_CHECK(h);
+      return PLDA_OK;
+    }
     if (doA)
       weighted_sq_bias_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(
           dU, coef, 1.0, coef + 2 * D, D, M, dzmean, dzstd, h->s_rbias.as<float>(), h->s_rscale.as<float>());

@@ -377,3 +377,36 @@ def test_prepared_test_side_is_reused_and_invalidated():
     torch.cuda.synchronize()
     assert torch.equal(score(None, 2, V), o1)
     eng.set_stream(None)
+
+
+@pytest.mark.parametrize("d,m,nt,n_enrol", [(200, 300, 517, 1), (200, 2049, 1100, 7), (7, 65, 64, 3), (1, 5, 700, 1), (129, 64, 1, 2),
+                                            (512, 130, 257, 100), (263, 1000, 129, 4)])
+@pytest.mark.parametrize("znorm", [False, True])
+def test_one_pass_prep_bit_identical(monkeypatch, d, m, nt, n_enrol, znorm):
+    """prep_side_kernel (one pass over a side's rows: bias, bias pair and packed operand) against the separate
+    weighted_sq_bias / pack / bias_pairs kernels (PLDA_PREP_VARIANT=1): same per-lane order of the weighted sum, same
+    butterfly, same operand arithmetic -- the trials matrix is BIT-identical, with and without the z-norm map folded into
+    the enrol side (a zero zstd leaves its row unscaled in both)."""
+    import torch
+    from plda_amd import MPlda
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7 * d + m)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    model = (rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy())
+    U = torch.from_numpy(rng.standard_normal((m, d))).to(dev)
+    V = torch.from_numpy(rng.standard_normal((nt, d))).to(dev)
+    zm = torch.from_numpy(rng.standard_normal(m)).to(dev)
+    zs = torch.from_numpy(rng.random(m) + 0.5).to(dev)
+    zs[m // 2] = 0.0
+    outs = []
+    for variant in ("0", "1"):
+        monkeypatch.setenv("PLDA_PREP_VARIANT", variant)
+        eng = MPlda(0)
+        eng.set_model(*model)
+        o = torch.full((m, nt + 3), -7.0, dtype=torch.float32, device=dev)
+        eng.score_matrix_dev(U.data_ptr(), None, n_enrol, m, V.data_ptr(), nt, o.data_ptr(), nt + 3,
+                             zm.data_ptr() if znorm else None, zs.data_ptr() if znorm else None)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    assert bool((outs[0][:, nt:] == -7.0).all()) and bool(torch.isfinite(outs[0][:, :nt]).all())
