@@ -231,12 +231,14 @@ int plda_destroy(plda_handle *h) {
     delete h->hostpipe;
     h->hostpipe = nullptr;
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
-                      &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
+                      &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->fit_flag, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
                       &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1]};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : h->w) b.release();
     if (h->one_host) (void)hipHostFree(h->one_host);
+    if (h->pin_model) (void)hipHostFree(h->pin_model);
+    for (hipEvent_t e : h->fit_ev) if (e) (void)hipEventDestroy(e);
     if (h->jac_exec) (void)hipGraphExecDestroy(h->jac_exec);
     for (auto &ev : h->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -54,12 +54,16 @@ struct plda_handle {
   int Dout = 0, Din = 0;
   std::vector<double> h_mean, h_transform, h_psi, h_offset;
   plda::DevBuf d_mean, d_transform, d_psi, d_offset;
+  void *pin_model = nullptr;     // pinned landing area of the model copies that end a fit (mean | transform | psi | offset)
+  size_t pin_model_cap = 0;
 
   // ---- fit state kept for plda_fit_get_stats ----
   int64_t fit_K = 0;
   int fit_D = 0;
   plda::DevBuf f_means, f_counts, f_scatter, f_sum, f_W, f_B;
+  plda::DevBuf fit_flag;         // the EM's factorisation flag (read by export_model_kernel at the end of a fit)
   double fit_ms[4] = {0, 0, 0, 0};
+  hipEvent_t fit_ev[2] = {nullptr, nullptr};   // EM start / end on the stream (fit_em_device)
 
   // ---- LDA model (lda.hip; /root/reference/python/liblda/lda.py) ----
   bool lda_fitted = false;
@@ -266,6 +270,9 @@ int simdiag_enqueue(plda_handle *h, const double *W, const double *B, int D, dou
                     bool *pending);
 int simdiag_finish(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
                    bool *redo);
+void simdiag_flags(plda_handle *h, int D, const int **chol_flag, const int **eig_flag);
+int simdiag_finish_with(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                        int chol_flag, int eig_status, bool *redo);
 // simultaneous diagonalisation of (W,B): T W T^T = I, T B T^T = diag(psi);
 // T [D,D], Tinv = T^{-1} (nullable), psi[D].  W,B are not modified.
 int simdiag_f64(plda_handle *h, const double *W, const double *B, int D, double *T,

@@ -493,14 +493,14 @@ __global__ __launch_bounds__(512) void tridiag_full_kernel(const double *__restr
     double m = amax_s[0];
 #pragma unroll
     for (int w = 1; w < 8; ++w) m = fmax(m, amax_s[w]);
-    const bool bad = bad_s != 0 || *flag != 0;
+    const bool bad = bad_s != 0;
     if (m > 0.0 && !bad) {
       int ex;
       (void)frexp(m, &ex);          // m = f 2^ex, f in [0.5, 1)
       sc = ldexp(1.0, 1 - ex);      // m sc in [1, 2)
     }
     if (t == 0) {
-      if (bad_s) atomicOr(flag, 4);
+      *flag = bad_s ? 4 : 0;        // (this kernel opens the decomposition: it sets the status word, no memset by the host)
       scale[0] = sc;
       scale[1] = 1.0 / sc;
     }
@@ -923,10 +923,15 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
       g = getd(mm) - dl + el * dc_rcp(g + (g >= 0.0 ? rr : -rr));
       double s = 1.0, c = 1.0, p = 0.0;
       bool underflow = false;
+      // eigenvector entries: column i + 1 of a rotation is the column i the previous one produced -- it stays in a
+      // register (z1; zc = the column it stands for) and column i is requested one rotation ahead, so that no LDS
+      // round trip sits in the rotation chain (round 4: the read-modify-write per rotation cost as much as the chain)
+      double z1 = 0.0, z0n = 0.0;
+      int zc = mm;
+      if (lane < m) { z1 = Z[lane][mm]; z0n = Z[lane][mm - 1]; }
       for (int i = mm - 1; i >= l; --i) {
-        // the eigenvector entries of this rotation are requested first: their LDS latency passes under the scalar chain
-        double z0 = 0.0, z1 = 0.0;
-        if (lane < m) { z0 = Z[lane][i]; z1 = Z[lane][i + 1]; }
+        const double z0 = z0n;
+        if (i - 1 >= l && lane < m) z0n = Z[lane][i - 1];
         const double ei = gete(i), di = getd(i), di1 = getd(i + 1);
         const double f = s * ei, b = c * ei;
         const double h2 = fma(f, f, g * g);
@@ -945,11 +950,11 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
         p = s * r2;
         if (lane == i + 1) d = g + p;
         g = fma(c, r2, -b);
-        if (lane < m) {
-          Z[lane][i + 1] = fma(s, z0, c * z1);
-          Z[lane][i] = fma(c, z0, -s * z1);
-        }
+        if (lane < m) Z[lane][i + 1] = fma(s, z0, c * z1);
+        z1 = fma(c, z0, -s * z1);
+        zc = i;
       }
+      if (lane < m) Z[lane][zc] = z1;
       if (underflow) continue;
       if (lane == l) { d -= p; e = g; }
       if (lane == mm) e = 0.0;
@@ -958,8 +963,9 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const double *__restrict__ 
   if (failed && lane == 0) atomicOr(flag, 1);
   if (lane < m) lam[off + lane] = d;
   // eigenvector i of the leaf = column i of Z -> row off + i of Qt (the rest of the row is zero: memset)
+  // (whole rows: zero outside the leaf's diagonal block -- no memset of Qt by the host)
   for (int i = 0; i < m; ++i)
-    if (lane < m) Qt[(size_t)(off + i) * n + off + lane] = Z[lane][i];
+    for (int c = lane; c < n; c += 64) Qt[(size_t)(off + i) * n + c] = (c >= off && c < off + m) ? Z[c - off][i] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1262,8 +1268,8 @@ __global__ __launch_bounds__(256) void dc_merge_roots_kernel(const double *__res
 // merge, part 2: grid (merges of the level, slices of DC_VS columns).  Every workgroup recomputes the Gu-Eisenstat
 // z (products of k ratios per entry, split over the threads in chunks of j and combined through LDS), then
 // normalises its own columns of the rank-one update's eigenvector matrix, one wave per column -> UmatT[out row]
-// [child row] of the level (the dense GEMM Qt_out = UmatT Qt_in forms the merged eigenvectors; UmatT is zeroed by
-// the host).  Slice 0 also applies the deflation rotations to the children's eigenvector rows and places the
+// [child row] of the level (the dense GEMM Qt_out = UmatT Qt_in forms the merged eigenvectors; every slice zeroes its own
+// rows of the block first).  Slice 0 also applies the deflation rotations to the children's eigenvector rows and places the
 // deflated columns.
 // ------------------------------------------------------------------------------------
 constexpr int DC_VS = 64;
@@ -1295,7 +1301,17 @@ __global__ __launch_bounds__(1024) void dc_merge_vectors_kernel(double *__restri
         rq[c] = fma(-rt.s, qp, rt.c * qq);
       }
     }
-    for (int i = t; i < nn - k; i += 1024) UmatT[(size_t)(off + k + i) * n + off + defl[off + i]] = 1.0;
+  }
+  // this slice's rows of UmatT start from zero over their whole length (round 4: the host's memset of the matrix per level
+  // is gone; a row belongs to exactly one merge of a level, so the rows' owners cover the matrix); deflated rows get
+  // their single 1.  The __syncthreads below orders the zeros in front of the column entries other waves write into
+  // the same rows.
+  {
+    const int r0 = slice * DC_VS, r1 = min(nn, r0 + DC_VS);
+    for (int e = t; e < (r1 - r0) * n; e += 1024) {
+      const int r = r0 + e / n, c = e % n - off;
+      UmatT[(size_t)(off + r) * n + off + c] = (r >= k && c == defl[off + r - k]) ? 1.0 : 0.0;
+    }
   }
   if (slice * DC_VS >= k) return;
   for (int i = t; i < k; i += 1024) { dk[i] = dkg[off + i]; kp[i] = keep[off + i]; zh[i] = 1.0; }
@@ -1445,59 +1461,73 @@ __global__ __launch_bounds__(256) void householder_rows_kernel(const double *__r
       y[r][q] = (row0 + r < n && c < n) ? Qt[(size_t)(row0 + r) * n + c] : 0.0;
     }
   const int ntiles = n >= 3 ? (n - 2 + HB - 1) / HB : 0;
-  double pre[PRE];
-  double tpre = 0.0;
-  auto prefetch = [&](int b) {
+  // The V blocks come from the tridiagonalisation's workgroup on another XCD: a load is ~2 us away while a block's
+  // arithmetic is ~0.4 us, so the blocks are requested DEPTH ahead (a ring of register sets, the loop unrolled over
+  // it so that every set has static register names).  One block ahead, the loop ran at the load latency: 25 blocks x
+  // 2.3 us = 59 us at n = 200.
+  constexpr int DEPTH = PRE <= 8 ? 6 : (PRE <= 16 ? 3 : 1);
+  double pre[DEPTH][PRE];
+  double tpre[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) tpre[s] = 0.0;
+  auto prefetch = [&](int b, double (&pr)[PRE], double &tp) {
 #pragma unroll
     for (int e = 0; e < PRE; ++e) {
       const int idx = t + 256 * e, i = idx / NP, k = idx % NP, j = b * HB + i;
-      pre[e] = (j <= n - 3 && k > j && k < n) ? Vh[(size_t)j * n + k] : 0.0;
+      pr[e] = (j <= n - 3 && k > j && k < n) ? Vh[(size_t)j * n + k] : 0.0;
     }
-    if (t < HB * HB) tpre = Tg[(size_t)b * HB * HB + t];
+    if (t < HB * HB) tp = Tg[(size_t)b * HB * HB + t];
   };
-  if (ntiles) prefetch(ntiles - 1);
-  for (int b = ntiles - 1; b >= 0; --b) {
-    __syncthreads();                         // the previous block has been applied
 #pragma unroll
-    for (int e = 0; e < PRE; ++e) vt[t + 256 * e] = pre[e];
-    if (t < HB * HB) Tt[t] = tpre;
-    __syncthreads();
-    if (b > 0) prefetch(b - 1);
-    double z[R][HB];
+  for (int s = 0; s < DEPTH; ++s)
+    if (ntiles - 1 - s >= 0) prefetch(ntiles - 1 - s, pre[s], tpre[s]);
+  for (int b0 = ntiles - 1; b0 >= 0; b0 -= DEPTH) {
 #pragma unroll
-    for (int i = 0; i < HB; ++i) {
-      double vv[E];
+    for (int s = 0; s < DEPTH; ++s) {
+      const int b = b0 - s;
+      if (b < 0) break;
+      __syncthreads();                         // the previous block has been applied
 #pragma unroll
-      for (int q = 0; q < E; ++q) vv[q] = vt[i * NP + lane + 64 * q];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        double d = 0.0;
-#pragma unroll
-        for (int q = 0; q < E; ++q) d = fma(vv[q], y[r][q], d);
-        z[r][i] = d;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int i = 0; i < HB; ++i) z[r][i] = wave_sum_f64(z[r][i]);
-    double u[R][HB];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
+      for (int e = 0; e < PRE; ++e) vt[t + 256 * e] = pre[s][e];
+      if (t < HB * HB) Tt[t] = tpre[s];
+      __syncthreads();
+      if (b - DEPTH >= 0) prefetch(b - DEPTH, pre[s], tpre[s]);
+      double z[R][HB];
 #pragma unroll
       for (int i = 0; i < HB; ++i) {
-        double sum = 0.0;
+        double vv[E];
 #pragma unroll
-        for (int c = i; c < HB; ++c) sum = fma(Tt[i * HB + c], z[r][c], sum);
-        u[r][i] = sum;
+        for (int q = 0; q < E; ++q) vv[q] = vt[i * NP + lane + 64 * q];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          double d = 0.0;
+#pragma unroll
+          for (int q = 0; q < E; ++q) d = fma(vv[q], y[r][q], d);
+          z[r][i] = d;
+        }
       }
 #pragma unroll
-    for (int i = 0; i < HB; ++i) {
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int q = 0; q < E; ++q) {
-        const double vq = vt[i * NP + lane + 64 * q];
+        for (int i = 0; i < HB; ++i) z[r][i] = wave_sum_f64(z[r][i]);
+      double u[R][HB];
 #pragma unroll
-        for (int r = 0; r < R; ++r) y[r][q] = fma(-u[r][i], vq, y[r][q]);
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+          double sum = 0.0;
+#pragma unroll
+          for (int c = i; c < HB; ++c) sum = fma(Tt[i * HB + c], z[r][c], sum);
+          u[r][i] = sum;
+        }
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const double vq = vt[i * NP + lane + 64 * q];
+#pragma unroll
+          for (int r = 0; r < R; ++r) y[r][q] = fma(-u[r][i], vq, y[r][q]);
+        }
       }
     }
   }
@@ -1510,6 +1540,135 @@ __global__ __launch_bounds__(256) void householder_rows_kernel(const double *__r
       if (c < n) Vout[(size_t)(row0 + r) * n + c] = y[r][q];
     }
     if (lane == 0) lam_out[row0 + r] = lam_in[row0 + r] * scale[1];
+  }
+}
+
+// Eight wave-wide sums at once (the eight dots of a compact-WY block).  Eight separate wave_sum_f64 are 8 x 4 DPP steps
+// plus 8 x 4 readlanes; here each exchange step also halves the number of live values: lanes whose bit b is 0 keep the
+// even member of a pair and send the odd one, and the other way round (quad_perm xor 1, xor 2, row_ror:4 -- a rotation
+// pairs every lane with one of the other bit-2 class, which is all the sum needs), so that after three steps a lane
+// holds ONE value, the partial sum of z[lane & 7]; row_ror:8 and the two row-swap instructions of gfx950
+// (v_permlane16_swap / v_permlane32_swap: 16- and 32-lane exchanges in the register file) finish it.  7 + 3 exchange
+// steps instead of 32; every lane ends with the total of z[lane & 7].
+__device__ __forceinline__ double wave_sum8_by_class(const double (&z)[8], int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  double w[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const double keep = b0 ? z[2 * p + 1] : z[2 * p], send = b0 ? z[2 * p] : z[2 * p + 1];
+    w[p] = keep + dpp_f64<0xB1>(send);          // quad_perm [1,0,3,2]
+  }
+  double x[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const double keep = b1 ? w[2 * p + 1] : w[2 * p], send = b1 ? w[2 * p] : w[2 * p + 1];
+    x[p] = keep + dpp_f64<0x4E>(send);          // quad_perm [2,3,0,1]
+  }
+  double y;
+  {
+    const double keep = b2 ? x[1] : x[0], send = b2 ? x[0] : x[1];
+    y = keep + dpp_f64<0x124>(send);            // row_ror:4
+  }
+  y += dpp_f64<0x128>(y);                       // row_ror:8
+  {
+    const unsigned lo = (unsigned)__double2loint(y), hi = (unsigned)__double2hiint(y);
+    const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    y = __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(y), hi = (unsigned)__double2hiint(y);
+    const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    y = __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
+  }
+  return y;
+}
+
+// householder_rows_kernel for n <= 512 (round 4): ONE row per wave.  The back-transformation is a chain of ceil((n - 2) / 8)
+// blocks, and with 256 CUs for n / 2 waves what counts is the length of a block in one wave's instruction stream, not the
+// number of waves: a row per wave halves the dots and updates, the eight dots end in wave_sum8_by_class (about 75
+// instructions instead of 370), and the block's V entries stay in registers between the dots and the update.
+// 58 -> about 30 us at n = 200.
+template <int E>
+__global__ __launch_bounds__(256) void householder_row1_kernel(const double *__restrict__ Qt, int n,
+                                                               const double *__restrict__ Vh,
+                                                               const double *__restrict__ Tg,
+                                                               const double *__restrict__ lam_in,
+                                                               const double *__restrict__ scale,
+                                                               double *__restrict__ Vout, double *__restrict__ lam_out) {
+  constexpr int NP = E * 64;                 // padded row length
+  constexpr int PRE = HB * NP / 256;         // V-block elements staged by one thread
+  extern __shared__ __attribute__((aligned(16))) double hh_sm[];
+  double *vt = hh_sm;                        // [HB][NP]
+  double *Tt = hh_sm + HB * NP;              // [HB][HB]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  double y[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const int c = lane + 64 * q;
+    y[q] = (row < n && c < n) ? Qt[(size_t)row * n + c] : 0.0;
+  }
+  const int ntiles = n >= 3 ? (n - 2 + HB - 1) / HB : 0;
+  constexpr int DEPTH = PRE <= 8 ? 6 : 3;
+  double pre[DEPTH][PRE];
+  double tpre[DEPTH];
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) tpre[s] = 0.0;
+  auto prefetch = [&](int b, double (&pr)[PRE], double &tp) {
+#pragma unroll
+    for (int e = 0; e < PRE; ++e) {
+      const int idx = t + 256 * e, i = idx / NP, k = idx % NP, j = b * HB + i;
+      pr[e] = (j <= n - 3 && k > j && k < n) ? Vh[(size_t)j * n + k] : 0.0;
+    }
+    if (t < HB * HB) tp = Tg[(size_t)b * HB * HB + t];
+  };
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s)
+    if (ntiles - 1 - s >= 0) prefetch(ntiles - 1 - s, pre[s], tpre[s]);
+  for (int b0 = ntiles - 1; b0 >= 0; b0 -= DEPTH) {
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+      const int b = b0 - s;
+      if (b < 0) break;
+      __syncthreads();                         // the previous block has been applied
+#pragma unroll
+      for (int e = 0; e < PRE; ++e) vt[t + 256 * e] = pre[s][e];
+      if (t < HB * HB) Tt[t] = tpre[s];
+      __syncthreads();
+      if (b - DEPTH >= 0) prefetch(b - DEPTH, pre[s], tpre[s]);
+      double vv[HB][E], z[HB];
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) vv[i][q] = vt[i * NP + lane + 64 * q];
+        double d = 0.0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) d = fma(vv[i][q], y[q], d);
+        z[i] = d;
+      }
+      const double zc = wave_sum8_by_class(z, lane);      // lane l: the total of z[l & 7]
+      double zt[HB];
+#pragma unroll
+      for (int i = 0; i < HB; ++i) zt[i] = readlane_f64(zc, i);
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+        double u = 0.0;
+#pragma unroll
+        for (int c = i; c < HB; ++c) u = fma(Tt[i * HB + c], zt[c], u);
+#pragma unroll
+        for (int q = 0; q < E; ++q) y[q] = fma(-u, vv[i][q], y[q]);
+      }
+    }
+  }
+  if (row < n) {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int c = lane + 64 * q;
+      if (c < n) Vout[(size_t)row * n + c] = y[q];
+    }
+    if (lane == 0) lam_out[row] = lam_in[row] * scale[1];
   }
 }
 
@@ -1552,10 +1711,11 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   int *defl = keep + vec, *meta = defl + vec, *flag = meta + vec;                      // meta: 4 ints per merge (<= 64 merges)
   DcRot *rots = reinterpret_cast<DcRot *>(flag + vec);
   double *Tg = reinterpret_cast<double *>(rots + vec);   // compact-WY T blocks: ceil((n - 2) / 8) x 64 doubles
-  PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
   TraceScope ts(h, "getoutput.eig.tridiagonalise", 4.0 / 3.0 * (double)n * n * n, 1);
-  const bool full_kernel = h->sweep_variant == 0 && h->eig_variant == 0 && n > 32 && n <= 208;   // (scales its input itself)
+  const bool ev0 = h->eig_variant == 0 || h->eig_variant == 4;   // (4: the default kernels with the two-row back-transformation)
+  const bool full_kernel = h->sweep_variant == 0 && ev0 && n > 32 && n <= 208;   // (scales its input and clears the status word itself)
   if (!full_kernel) {
+    PLDA_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
     PLDA_HIP(h, hipMemsetAsync(scale + 2, 0, 8, h->stream));   // running max |g_ij| (as bits)
     eig_absmax_kernel<<<(unsigned)std::min<int64_t>(ceil_div((int64_t)DD, 1024), 128), 256, 0, h->stream>>>(
         G, n, reinterpret_cast<unsigned long long *>(scale + 2), flag);
@@ -1582,7 +1742,7 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
       default: TRF(13); break;
     }
 #undef TRF
-  } else if (h->sweep_variant != 1 && h->eig_variant == 0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
+  } else if (h->sweep_variant != 1 && ev0 && n <= 224) {      // (NB = 15, 16 spill 380 / 680 bytes per lane)
     const int nb = (int)ceil_div(n, 16);
 #define TR16(NBB) tridiag_reg16_kernel<NBB><<<1, 256, 0, h->stream>>>(G, n, scale, dd, ee, Vh, tau)
     switch (nb) {
@@ -1661,7 +1821,6 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
   ts.next("getoutput.eig.divide_and_conquer");
   int depth = 0;
   while ((int)ceil_div(n, 1 << depth) > DC_LEAF) depth++;
-  PLDA_HIP(h, hipMemsetAsync(QtA, 0, DD * 8, h->stream));
   dc_leaf_kernel<<<1 << depth, 64, 0, h->stream>>>(dd, ee, n, depth, lamA, QtA, flag);
   PLDA_LAUNCH_CHECK(h);
   double *qin = QtA, *qout = QtB, *lin = lamA, *lout = lamB;
@@ -1669,7 +1828,6 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
     const int merges = 1 << dl;
     const int maxn = (int)ceil_div(n, merges);
     const int slices = (int)ceil_div(maxn, DC_RS);
-    PLDA_HIP(h, hipMemsetAsync(UmatT, 0, DD * 8, h->stream));
     dc_merge_roots_kernel<<<dim3(merges, slices), 256, 0, h->stream>>>(lin, qin, ee, n, dl, lout, deltaT, meta, keep,
                                                                         defl, dkg, zkg, rots, flag);
     dc_merge_vectors_kernel<<<dim3(merges, (unsigned)ceil_div(maxn, DC_VS)), 1024, 0, h->stream>>>(qin, n, dl, deltaT, meta, keep, defl,
@@ -1693,13 +1851,26 @@ int sym_eig_dc_f64(plda_handle *h, const double *G, int D, double *s, double *Vr
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
     householder_rows_kernel<E2><<<grid, 256, lds, h->stream>>>(qin, n, Vh, Tg, lin, scale, qout, lamU);               \
   } while (0)
-    if (EE == 1) HR(1);
+    // n <= 512: one row per wave, the eight dots of a block reduced together (PLDA_EIG_VARIANT=4: the two-row kernel)
+#define HR1(E2)                                                                                                        \
+  do {                                                                                                                 \
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&householder_row1_kernel<E2>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    householder_row1_kernel<E2><<<(unsigned)ceil_div(n, 4), 256, lds, h->stream>>>(qin, n, Vh, Tg, lin, scale, qout, lamU); \
+  } while (0)
+    const bool row1 = h->eig_variant != 4;
+    if (EE == 1 && row1) HR1(1);
+    else if (EE == 2 && row1) HR1(2);
+    else if (EE == 4 && row1) HR1(4);
+    else if (EE == 8 && row1) HR1(8);
+    else if (EE == 1) HR(1);
     else if (EE == 2) HR(2);
     else if (EE == 4) HR(4);
     else if (EE == 8) HR(8);
     else if (EE == 16) HR(16);
     else HR(32);
 #undef HR
+#undef HR1
   }
   PLDA_LAUNCH_CHECK(h);
   PLDA_TRY(eig_sort_rows(h, lamU, qout, n, s, Vrows));

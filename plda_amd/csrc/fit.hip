@@ -9,6 +9,7 @@
 //                                              (identical maths to A.2)
 //            GetOutput                 -> K6/K7 Cholesky + triangular inverse + Jacobi eig
 #include "common.hpp"
+#include <cstring>
 
 #include <algorithm>
 #include <chrono>
@@ -350,6 +351,29 @@ static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// The host mirror of a fitted model in ONE launch: mean | transform | psi | offset and the EM's factorisation flag,
+// written by the kernel itself into mapped pinned host memory (round 4).  Four hipMemcpyAsync to the host were four
+// blit launches with 25-45 us of host round trip between them -- 120 us behind GetOutput's last kernel at D = 200.
+__global__ void export_model_kernel(const double *__restrict__ mean, const double *__restrict__ T, const double *__restrict__ psi,
+                                    const double *__restrict__ off, int D, const int *__restrict__ em_flag,
+                                    const int *__restrict__ chol_flag, const int *__restrict__ eig_flag, double *__restrict__ out) {
+  const size_t DD = (size_t)D * D, total = 3 * (size_t)D + DD;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  double v;
+  if (e < (size_t)D) v = mean[e];
+  else if (e < D + DD) v = T[e - D];
+  else if (e < 2 * (size_t)D + DD) v = psi[e - D - DD];
+  else v = off[e - 2 * (size_t)D - DD];
+  out[e] = v;
+  if (e == 0) {      // flags: the EM's factorisations, GetOutput's Cholesky, the eigensolver's status (8: not taken)
+    int *f = reinterpret_cast<int *>(out + total);
+    f[0] = *em_flag;
+    f[1] = chol_flag ? *chol_flag : 0;
+    f[2] = eig_flag ? *eig_flag : 8;
+  }
+}
+
 int compute_offset_device(plda_handle *h) {
   offset_kernel<<<(unsigned)ceil_div(h->Dout, 4), 256, 0, h->stream>>>(
       h->d_transform.as<double>(), h->d_mean.as<double>(), h->Dout, h->Din, h->d_offset.as<double>());
@@ -602,6 +626,24 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   h->jac_total_sweeps = 0;
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t1 = now_ms();
+  // EM | GetOutput boundary of plda_fit_timings: a pair of events instead of a host synchronisation, so that GetOutput is
+  // enqueued while the EM still runs (the synchronisation left the GPU idle for the host's launch latency, 30-50 us)
+  if (!h->fit_ev[0]) { PLDA_HIP(h, hipEventCreate(&h->fit_ev[0])); PLDA_HIP(h, hipEventCreate(&h->fit_ev[1])); }
+  PLDA_HIP(h, hipEventRecord(h->fit_ev[0], h->stream));
+  // pinned landing area of everything this call reads back: the model (mean | transform | psi | offset) and the EM's
+  // factorisation flag -- copies into it are queued without blocking the host, one synchronisation ends the fit
+  const size_t pin_need = (3 * (size_t)D + DD) * 8 + 64;
+  if (h->pin_model_cap < pin_need) {
+    if (h->pin_model) (void)hipHostFree(h->pin_model);
+    h->pin_model = nullptr; h->pin_model_cap = 0;
+    PLDA_HIP(h, hipHostMalloc(&h->pin_model, pin_need, hipHostMallocMapped));
+    h->pin_model_cap = pin_need;
+  }
+  double *const pm = static_cast<double *>(h->pin_model);
+  int *const em_flag_host = reinterpret_cast<int *>(pm + 3 * (size_t)D + DD);
+  *em_flag_host = 0;
+  PLDA_HIP(h, h->fit_flag.reserve(64));
+  PLDA_HIP(h, hipMemsetAsync(h->fit_flag.p, 0, 4, h->stream));
   TraceScope ts_em(h, "fit.em (all iterations)");
   PLDA_HIP(h, h->f_sum.reserve((size_t)D * 8));
   PLDA_HIP(h, h->f_W.reserve(DD * 8));
@@ -675,11 +717,10 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     double *Cg = h->w[6].as<double>(), *b0 = Cg + (size_t)G * DD, *b1 = b0 + (size_t)G * DD,
            *b2 = b1 + (size_t)G * DD, *b3 = b2 + (size_t)G * DD, *Csum = b3 + (size_t)G * DD, *dgn = Csum + DD,
            *dgk = dgn + G;
-    int *dflag = reinterpret_cast<int *>(dgk + G);
+    int *dflag = h->fit_flag.as<int>();          // (its own buffer: the export kernel that ends the fit reads it)
     PLDA_HIP(h, hipMemcpyAsync(dcls, cls.data(), (size_t)K * 4, hipMemcpyHostToDevice, h->stream));
     PLDA_HIP(h, hipMemcpyAsync(dgn, gn.data(), (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
     PLDA_HIP(h, hipMemcpyAsync(dgk, gk.data(), (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
-    PLDA_HIP(h, hipMemsetAsync(dflag, 0, 4, h->stream));
     gather_center_kernel<<<gKD, 256, 0, h->stream>>>(means, mu, dcls, K, D, Mg);
     PLDA_LAUNCH_CHECK(h);
     for (int g = 0; g < G; ++g) {
@@ -725,10 +766,9 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
                                                         D <= 256 && it + 1 < iters);
       PLDA_LAUNCH_CHECK(h);
     }
-    int hflag = 0;
-    PLDA_HIP(h, hipMemcpyAsync(&hflag, dflag, 4, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    if (hflag) return fail(h, PLDA_E_NUMERIC, "fit: W + nB is not positive definite");
+    // the flag of the EM's factorisations travels with the model export that ends the fit (round 4: read here, the
+    // synchronisation left the GPU idle for ~45 us before GetOutput's first kernel).  A failed factorisation hands
+    // GetOutput non-finite matrices, which its kernels refuse at once; the error reported is this one.
   } else {
   PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3));   // Mc / P, Y1, Y2
   PLDA_HIP(h, h->w[6].reserve(DD * 8 * 7 + (size_t)D * 8));
@@ -757,8 +797,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   }
   }
   ts_em.close();
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  const double t2 = now_ms();
+  PLDA_HIP(h, hipEventRecord(h->fit_ev[1], h->stream));
 
   // ---------------- GetOutput ----------------
   PLDA_HIP(h, h->d_mean.reserve((size_t)D * 8));
@@ -777,24 +816,41 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   PLDA_HIP(h, hipMemcpyAsync(h->d_mean.p, mu, (size_t)D * 8, hipMemcpyDeviceToDevice, h->stream));
   h->Dout = D; h->Din = D;
   h->h_mean.resize(D); h->h_transform.resize(DD); h->h_psi.resize(D); h->h_offset.resize(D);
+  // the host mirror of the model: the four copies land in one pinned area (queued back to back, no staging through the
+  // runtime's bounce buffer: to the pageable vectors they were ~35 us each, a fifth of GetOutput at D = 200)
   for (int attempt = 0; attempt < 2; ++attempt) {
     PLDA_TRY(compute_offset_device(h));
-    PLDA_HIP(h, hipMemcpyAsync(h->h_mean.data(), h->d_mean.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(h->h_transform.data(), h->d_transform.p, DD * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(h->h_psi.data(), h->d_psi.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(h->h_offset.data(), h->d_offset.p, (size_t)D * 8, hipMemcpyDeviceToHost, h->stream));
+    {
+      double *pm_dev = nullptr;
+      PLDA_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&pm_dev), h->pin_model, 0));
+      const int *chol_dev = nullptr, *eig_dev = nullptr;
+      if (pending) simdiag_flags(h, D, &chol_dev, &eig_dev);
+      export_model_kernel<<<(unsigned)ceil_div((int64_t)(3 * (size_t)D + DD), 256), 256, 0, h->stream>>>(
+          h->d_mean.as<double>(), h->d_transform.as<double>(), h->d_psi.as<double>(), h->d_offset.as<double>(), D,
+          h->fit_flag.as<int>(), chol_dev, eig_dev, pm_dev);
+      PLDA_LAUNCH_CHECK(h);
+    }
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    if (*em_flag_host) return fail(h, PLDA_E_NUMERIC, "fit: W + nB is not positive definite");
+    std::memcpy(h->h_mean.data(), pm, (size_t)D * 8);
+    std::memcpy(h->h_transform.data(), pm + D, DD * 8);
+    std::memcpy(h->h_psi.data(), pm + D + DD, (size_t)D * 8);
+    std::memcpy(h->h_offset.data(), pm + 2 * (size_t)D + DD, (size_t)D * 8);
     if (!pending) break;
     pending = false;
     bool redo = false;
-    PLDA_TRY(simdiag_finish(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), &redo));
+    PLDA_TRY(simdiag_finish_with(h, W, B, D, h->d_transform.as<double>(), nullptr, h->d_psi.as<double>(), em_flag_host[1],
+                                 em_flag_host[2], &redo));
     if (!redo) break;
   }
   const double t3 = now_ms();
   h->fitted = true;
   ++h->model_epoch;
   h->fit_K = K; h->fit_D = D;
-  h->fit_ms[1] = t2 - t1; h->fit_ms[2] = t3 - t2; h->fit_ms[3] = (double)iters;
+  float em_span = 0.f;
+  PLDA_HIP(h, hipEventElapsedTime(&em_span, h->fit_ev[0], h->fit_ev[1]));
+  // em_ms: the EM's span on the stream; output_ms: the rest of the wall clock of this call (GetOutput, model copies)
+  h->fit_ms[1] = (double)em_span; h->fit_ms[2] = (t3 - t1) - (double)em_span; h->fit_ms[3] = (double)iters;
   return PLDA_OK;
 }
 

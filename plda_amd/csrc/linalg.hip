@@ -1893,6 +1893,9 @@ int sym_eig_auto_f64(plda_handle *h, double *G, int D, double *s, double *Vrows)
 //   simdiag_finish    reads the Cholesky and eigensolver flags (after a synchronisation the caller needs
 //                     anyway) and, if the direct method gave up, repeats the decomposition with block Jacobi.
 // simdiag_f64 = both, for callers that want the result at once.
+int simdiag_finish_with(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                        int chol_flag, int eig_status, bool *redo);
+
 static int simdiag_run(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
                        bool warm_start, bool allow_direct, bool defer, bool *pending) {
   const size_t DD = (size_t)D * D;
@@ -1973,9 +1976,21 @@ int simdiag_finish(plda_handle *h, const double *W, const double *B, int D, doub
   const int *dflag = reinterpret_cast<const int *>(h->w[13].as<double>() + 6 * DD);
   int hflag = 0, status = 0;
   PLDA_HIP(h, hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost));
-  if (hflag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
   PLDA_TRY(sym_eig_dc_status(h, &status));
-  if (status == 0) return PLDA_OK;
+  return simdiag_finish_with(h, W, B, D, T, Tinv, psi, hflag, status, redo);
+}
+
+// the two device flags simdiag_finish reads (for a caller that fetches them with its own copies: fit's model export)
+void simdiag_flags(plda_handle *h, int D, const int **chol_flag, const int **eig_flag) {
+  *chol_flag = reinterpret_cast<const int *>(h->w[13].as<double>() + 6 * (size_t)D * D);
+  *eig_flag = h->eigdc_flag;          // nullptr: the direct method did not take the problem (status 8)
+}
+
+int simdiag_finish_with(plda_handle *h, const double *W, const double *B, int D, double *T, double *Tinv, double *psi,
+                        int chol_flag, int eig_status, bool *redo) {
+  *redo = false;
+  if (chol_flag) return fail(h, PLDA_E_NUMERIC, "within-class covariance is not positive definite");
+  if (eig_status == 0) return PLDA_OK;
   *redo = true;
   return simdiag_run(h, W, B, D, T, Tinv, psi, false, false, false, nullptr);
 }

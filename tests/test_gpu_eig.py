@@ -78,6 +78,18 @@ def test_both_tridiagonalisation_kernels(variant, monkeypatch):
             _check(eng, name, G, method=2, expect_method=2)
 
 
+def test_back_transformation_two_row_arm(monkeypatch):
+    """PLDA_EIG_VARIANT=4: the default kernels with the two-rows-per-wave back-transformation of rounds 2-3 (the A/B arm of
+    the one-row kernel with the eight-sums-at-once reduction that n <= 512 takes since round 4)."""
+    monkeypatch.setenv("PLDA_EIG_VARIANT", "4")
+    from plda_amd import MPlda
+    eng = MPlda(0)
+    for n in (9, 64, 200, 257, 512):
+        rng = np.random.default_rng(2000 + n)
+        for name, G in _cases(n, rng):
+            _check(eng, name, G, method=2, expect_method=2, tol=2e-12)
+
+
 @pytest.mark.parametrize("n", [5, 64, 200])
 def test_jacobi_against_numpy(n):
     from plda_amd import MPlda
