@@ -538,6 +538,364 @@ __global__ __launch_bounds__(512) void transform_dma_kernel(const double *__rest
   }
 }
 
+// ------------------------------------------------------------------------------------
+// transform_treg_kernel (round 4; PLDA_TRANSFORM_VARIANT=6, an A/B arm: Dout in (192, 208], Din = 200, a uniform count --
+// the C2 shape) -- T NEVER LEAVES THE CU.  The kernels above re-stage all of T (333 KB at D = 200) for every 128 rows: 62 %
+// of what a block moves through the global -> LDS path.  A CU's four SIMDs hold 4 x 512 registers x 64 lanes x 4 B =
+// 512 KB -- T's MFMA B fragments (v_mfma_f64_16x16x4_f64: one double per lane; 13 column tiles x 50 k-steps = 650
+// doubles per lane over the CU) fit.  Eight waves, two per SIMD (256 registers each), in two roles:
+//   wave (s, 0): the column tiles s and s + 4, all 50 k-steps             -- 100 fragments, 100 MFMAs per row group
+//                (the last 16 of them in LDS: with 200 registers of fragments the allocator spilled 17 to scratch
+//                memory and reloaded them, a vmcnt(0) each, inside the MFMA loop)
+//   wave (s, 1): the tile s + 8 and k-steps [13 s, 13 s + 13) of the 13th  --  63 fragments,  63 MFMAs per row group
+// so that every SIMD carries 163 MFMAs of 64 cycles per 16 rows, loaded once per launch.  What streams is X alone, one
+// MFMA row group (16 rows, 25 KB) per step, brought in by LDS DMA three groups ahead (a ring of four slots): a 1 KiB
+// DMA piece is the A operands of two k-steps; lanes 4 m .. 4 m + 3 fetch the four 16-byte k-pairs of row m's 64-byte
+// sector (one request per quad at the address unit), XOR-swizzled by (m >> 2) & 3 so that a fragment read -- 16 rows x
+// one k-quad -- spreads over all 64 banks of the unpadded image.  Per group: MFMAs; the 13th tile's four partial
+// accumulators and every wave's part of the rows' weighted squares (four sums over the 16 column lanes reduced
+// TOGETHER: each DPP exchange halves the live values) -> LDS; ONE barrier (vmcnt(0) in front of it: the operands
+// requested in this step have landed); totals, one rsqrt + two Newton steps per row instead of a division and a
+// square root, stores through a range-checked descriptor (no row / column branches).
+// What was measured on the way (scripts/transform_stream_probe.py, profiles/r04_transform_treg_probe.txt):
+//   * ONE wave per SIMD holding a quarter of T (326 registers), epilogue behind the MFMAs: 0.24 ms at C2 against 0.19
+//     for the kernels above.  Its timing arms are exactly additive -- MFMAs 4.4 us per group (their ideal), everything
+//     else 2.8 us, together 7.1 -- also after the epilogue had been software-pipelined into the MFMA stream slice by
+//     slice (a few instructions behind every k-step, scheduling barriers between; sched_group_barrier pipelines gave up
+//     after five MFMAs): a wave's own vector instructions do not run in the shadow of its own MFMAs; the shadow belongs
+//     to the SIMD's other wave.  Hence two waves per SIMD.
+//   * __builtin_amdgcn_raw_ptr_buffer_load_lds makes the compiler's wait-count pass put s_waitcnt vmcnt(0) in front of
+//     every later ds_read (it cannot tell which LDS reads a DMA write may alias): a memory round trip per piece in the
+//     middle of the MFMA stream, ~1 700 cycles each.  The DMA is inline assembly here; the waits are the explicit ones.
+//   * all 25 pieces of a group issued together behind the barrier queue at the CU's one address unit (~150 cycles per
+//     piece with 64 separate 16-byte requests, fewer with the quad-contiguous mapping): they go out one per 8 k-steps.
+//   * both waves of a SIMD stopping for their epilogues at the same barrier leaves the matrix pipe idle for the
+//     epilogue's 1.2 us per group; the two roles therefore run their parts in different orders around it (below).
+// Result: C2 (100k rows) 0.21 ms against 0.19, 800k rows 1.26 against 1.24 ms -- level with the kernels above, not
+// ahead: a group takes 6.2 us where its MFMAs are 4.4 (at 2.4 GHz), with or without the reordering.  Not the product
+// path; kept with its timing arms because the four findings above are what the next attempt starts from.
+// Same sums per output as the kernels above for the columns of full tiles (k ascending in one accumulator); the
+// thirteenth tile's columns add four partial sums, the row's norm adds its terms in another order and takes its
+// square root by Newton steps: last-ulp differences (tests: 1e-12 against the fp64 oracle).
+// ------------------------------------------------------------------------------------
+template <int NT, int KSTEPS>
+struct TregGeom {
+  static_assert(NT == 13, "roles: tiles s, s + 4 | tile s + 8 and a quarter of tile 12");
+  static constexpr int QS = (KSTEPS + 3) / 4;              // k-steps of the split tile per SIMD
+  static constexpr int NPAIR = KSTEPS / 2;                 // DMA pieces (two k-steps of 16 rows) per row group
+  static constexpr int PW = (NPAIR + 7) / 8;               // DMA pieces per wave and group (a ragged split's last ones go to a dump)
+  static constexpr int GB = NPAIR * 1024;                  // bytes of a row group's slot in LDS
+  static constexpr int NBUF = 4;                           // ring of row-group slots
+  // scratch per parity: partial tiles [simd][lane] x 4 doubles | row sums [wave][16] | a dump for the lanes that hold no row sum
+  static constexpr int SCR = 4 * 64 * 32 + 8 * 16 * 8 + 8 * 64 * 8;
+  // the two-tile waves keep the last LK k-steps of their second tile's fragments in LDS, not in registers: 100 fragments
+  // (200 registers) beside accumulators and epilogue spilled 17 of them to scratch memory, reloaded with a vmcnt(0)
+  // each in the middle of the MFMA stream (3.5 us per group: measured)
+  static constexpr int LK = 16;
+  static constexpr int TL = 4 * LK * 512;                  // [simd][LK][64 lanes] doubles
+  static constexpr int DUMP = 1024;                        // where the DMA pieces that do not exist land
+  static constexpr size_t LDS_BYTES = (size_t)NBUF * GB + 2 * SCR + TL + DUMP;
+};
+
+// four sums over the 16 lanes of a DPP row at once: after the two merging exchanges (quad_perm xor 1, xor 2) a lane holds
+// the partial sum of p[lane & 3]; row_ror:4 and row_ror:8 add the other three lanes of its class
+__device__ __forceinline__ double row_sum4_by_class(const double (&p)[4], int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  const double k0 = b0 ? p[1] : p[0], s0 = b0 ? p[0] : p[1];
+  const double k1 = b0 ? p[3] : p[2], s1 = b0 ? p[2] : p[3];
+  const double w0 = k0 + dpp_f64<0xB1>(s0), w1 = k1 + dpp_f64<0xB1>(s1);
+  const double k = b1 ? w1 : w0, sd = b1 ? w0 : w1;
+  double y = k + dpp_f64<0x4E>(sd);
+  y += dpp_f64<0x124>(y);     // row_ror:4
+  y += dpp_f64<0x128>(y);     // row_ror:8
+  return y;
+}
+
+struct TregArgs {
+  const double *X; int64_t R; int Din; const double *Tpad; int Dinp; int Dout;
+  const double *offset; const double *psi; int n_uniform; double *out;
+};
+
+// one wave's loop.  FTW full tiles (tile index simd + 4 f + TB), SPL: also k-steps [simd QS, +QS) of tile NT - 1
+template <int NT, int KSTEPS, int MODE, int FTW, int TB, bool SPL>
+__device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *const lds, const int lane, const int wave, const int simd) {
+  using G = TregGeom<NT, KSTEPS>;
+  constexpr int QS = G::QS, NPAIR = G::NPAIR, PW = G::PW, GB = G::GB, NBUF = G::NBUF, SCR = G::SCR;
+  constexpr int NA = FTW + (SPL ? 1 : 0);
+  constexpr int LK = FTW == 2 ? G::LK : 0;                    // trailing k-steps of the last full tile whose fragments live in LDS
+  constexpr int KR = KSTEPS - LK;                             // ... and the k-steps of it held in registers
+  typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+  const int fi = lane & 15, fk = lane >> 4;
+  const int64_t R = A.R;
+  const int Din = A.Din, Dout = A.Dout, Dinp = A.Dinp;
+  const int64_t ng = (R + 15) >> 4;
+
+  // ---- T: this wave's B fragments, once ----
+  double tb[FTW][KSTEPS];                                      // (of the last tile only [0, KR) is ever used: the rest is dead code)
+  TF_LDS_AS double *const tl = (TF_LDS_AS double *)(lds + NBUF * GB + 2 * SCR) + (simd * G::LK) * 64 + lane;
+#pragma unroll
+  for (int f = 0; f < FTW; ++f) {
+    const double *tp_ = A.Tpad + (int64_t)((simd + 4 * f + TB) * 16 + fi) * Dinp + fk;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (f == FTW - 1 && ks >= KR) tl[(ks - KR) * 64] = tp_[4 * ks];
+      else tb[f][ks] = tp_[4 * ks];
+    }
+  }
+  const int q0 = simd * QS;                                   // first k-step of this SIMD's share of the split tile
+  const int qvalid = SPL ? max(0, min(QS, KSTEPS - q0)) : 0;
+  double tq[SPL ? QS : 1];
+  if (SPL) {
+    const double *tp_ = A.Tpad + (int64_t)((NT - 1) * 16 + fi) * Dinp + fk;
+#pragma unroll
+    for (int j = 0; j < QS; ++j) tq[j] = j < qvalid ? tp_[4 * (q0 + j)] : 0.0;   // (a share that runs past the last k-step: zero fragments)
+  }
+  // ---- per-column constants of the epilogue (uniform count: the length-norm weight is 1 / (psi + 1/n)) ----
+  const double inv_nu = 1.0 / (double)A.n_uniform;
+  double offs[FTW], wts[FTW], offq = 0.0, wq = 0.0;
+#pragma unroll
+  for (int f = 0; f < FTW; ++f) {
+    const int col = (simd + 4 * f + TB) * 16 + fi;
+    offs[f] = col < Dout ? A.offset[col] : 0.0;
+    wts[f] = col < Dout ? tf_rcp(A.psi[col] + inv_nu) : 0.0;
+  }
+  if (SPL) {
+    const int col = (NT - 1) * 16 + fi;
+    offq = col < Dout ? A.offset[col] : 0.0;
+    wq = col < Dout ? tf_rcp(A.psi[col] + inv_nu) : 0.0;
+  }
+  const double sqrt_dout = sqrt((double)Dout);
+
+  // ---- X by LDS DMA, fragment order.  Piece j of a group = k-steps 2 j and 2 j + 1: lane l = (ks_sel = l >> 5,
+  //      p = (l >> 4) & 1, r = l & 15) fetches X[row r][8 j + 4 ks_sel + 2 p .. + 1] to byte 16 l of the piece.
+  //      The whole address rides on the vector offset: it is what the descriptor range-checks (rows past R, pieces that
+  //      do not exist and groups past the end land as zeros -- no branch).
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.X), 0, (int)(unsigned)(R * Din * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(unsigned)(R * (int64_t)Dout * 8), 0x00020000);
+  // (lanes 4 m .. 4 m + 3 fetch the four 16-byte k-pairs of row m's 64-byte sector -- one request per quad at the address
+  //  unit, not four -- in the order c ^ ((m >> 2) & 3): the piece's LDS image is row-major with 64 bytes per row, and the
+  //  swizzle spreads the 16 rows of a fragment read over all 64 banks)
+  const unsigned lane_voff = (unsigned)((lane >> 2) * Din + ((lane & 3) ^ ((lane >> 4) & 3)) * 2) * 8u;
+  auto dma_piece = [&](int64_t g, int slot, bool live, int p) {
+    if (MODE & 1) return;
+    const int j = wave + 8 * p;
+    const unsigned voff = (live && j < NPAIR) ? lane_voff + (unsigned)((g * 16 * Din + 8 * j) * 8) : 0xfffffff0u;
+    // (inline assembly, not __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler's wait-count pass cannot tell which LDS
+    //  reads a DMA write may alias and puts s_waitcnt vmcnt(0) in front of EVERY later ds_read -- a memory round trip per
+    //  piece in the middle of the MFMA stream, 1 700 cycles each (measured).  The waits this kernel needs are the two
+    //  explicit ones in front of its barriers.)
+    const unsigned ldsaddr = (unsigned)(uintptr_t)(j < NPAIR ? lds + slot * GB + j * 1024 : lds + NBUF * GB + 2 * SCR + G::TL);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsaddr), "v"(voff), "s"(rsX) : "memory");
+  };
+  auto dma_group = [&](int64_t g, int slot, bool live) {
+#pragma unroll
+    for (int p = 0; p < PW; ++p) dma_piece(g, slot, live, p);
+  };
+  // fragment k-step ks of the group in slot s, lane i = (kk = i >> 4, r = i & 15): k-pair 2 (ks & 1) + (kk >> 1) of row r
+  // sits at 16-byte position pair ^ ((r >> 2) & 3) of the row's 64 bytes in piece ks >> 1
+  const unsigned fr = (unsigned)(lane & 15), fkk = (unsigned)(lane >> 4);
+  const unsigned aoff0 = fr * 64u + (((0u + (fkk >> 1)) ^ ((fr >> 2) & 3u)) * 16u) + (fkk & 1u) * 8u;
+  const unsigned aoff1 = fr * 64u + (((2u + (fkk >> 1)) ^ ((fr >> 2) & 3u)) * 16u) + (fkk & 1u) * 8u;
+
+  const int64_t gstep = gridDim.x;
+  int64_t gi = blockIdx.x;
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s) dma_group(gi + s * gstep, s, gi + s * gstep < ng);
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+
+  // ---- the three parts of a group's work (m: its index in this workgroup's sequence, g: its global index) ----
+  // MFMAs of k-steps [K0, K1) of group m into ac; with DMA: the pieces of the group `ahead` further on, one every 8 k-steps
+  // (issued together behind a barrier, the 25 pieces of a group queue at the CU's one address unit and every wave stands
+  // in its load issue with nobody feeding the matrix pipe)
+  auto mfma_range = [&](f64x4s (&ac)[NA], int m, int64_t g, int K0, int K1, int ahead) {
+    if (MODE & 2) return;
+    const int slot = m & (NBUF - 1);
+    const TF_LDS_AS char *const xb0 = lds + slot * GB + aoff0, *const xb1 = lds + slot * GB + aoff1;
+    auto frag = [&](int ks) { return *(const TF_LDS_AS double *)(((ks & 1) ? xb1 : xb0) + (ks >> 1) * 1024); };
+    double a0 = frag(K0), a1 = frag(K0 + 1);                  // fragments two k-steps ahead of their MFMAs
+    double t0 = 0.0, t1 = 0.0;                                // ... and the LDS-resident B fragments likewise
+    if (LK > 0 && K1 > KR) { t0 = tl[(max(K0, KR) - KR) * 64]; t1 = tl[(max(K0, KR) + 1 - KR) * 64]; }
+#pragma unroll
+    for (int ks = K0; ks < K1; ++ks) {
+      const double a = a0;
+      a0 = a1;
+      if (ks + 2 < K1) a1 = frag(ks + 2);
+#pragma unroll
+      for (int f = 0; f < FTW; ++f) {
+        if (LK > 0 && f == FTW - 1 && ks >= KR) {
+          const double bb = t0;
+          t0 = t1;
+          if (ks + 2 < KSTEPS) t1 = tl[(ks + 2 - KR) * 64];
+          ac[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, ac[f], 0, 0, 0);
+        } else {
+          ac[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[f][ks], ac[f], 0, 0, 0);
+        }
+      }
+      if (ahead > 0 && ks % 8 == 2 && ks / 8 < PW)
+        dma_piece(g + ahead * gstep, (m + ahead) & (NBUF - 1), g + ahead * gstep < ng, ks / 8);
+      if (SPL && ks >= KSTEPS - QS) {                          // the split tile's k-steps ride along with the last QS steps
+        const int j = ks - (KSTEPS - QS);
+        const int kq = q0 + min(j, max(qvalid - 1, 0));        // (past the share's end: a valid fragment against zeros)
+        const double aq = *(const TF_LDS_AS double *)(((kq & 1) ? xb1 : xb0) + (unsigned)((kq >> 1) * 1024));
+        ac[FTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, tq[j], ac[FTW], 0, 0, 0);
+      }
+    }
+  };
+  // epilogue, part 1 (in front of the group's barrier): the split tile's partial sums and this wave's part of the rows'
+  // weighted squares -> LDS.  Accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row group.
+  auto epi1 = [&](f64x4s (&ac)[NA], int m) {
+    TF_LDS_AS char *const scr = lds + NBUF * GB + (m & 1) * SCR;
+    if (SPL) ((TF_LDS_AS f64x4s *)scr)[simd * 64 + lane] = ac[FTW];
+    double pz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double z = 0.0;
+#pragma unroll
+      for (int f = 0; f < FTW; ++f) {
+        const double v = ac[f][r] + offs[f];
+        ac[f][r] = v;
+        z = fma(v * v, wts[f], z);
+      }
+      pz[r] = z;
+    }
+    const double ysum = row_sum4_by_class(pz, lane);          // lane: the sum for reg (lane & 3) of its fk
+    ((TF_LDS_AS double *)(scr + 4 * 64 * 32))[fi < 4 ? wave * 16 + fk + 4 * fi : 128 + wave * 64 + lane] = ysum;
+  };
+  // part 2 (behind the barrier): totals, normalisation, output
+  auto epi2 = [&](f64x4s (&ac)[NA], int m, int64_t g) {
+    TF_LDS_AS char *const scr = lds + NBUF * GB + (m & 1) * SCR;
+    const TF_LDS_AS f64x4s *const P = (const TF_LDS_AS f64x4s *)scr;
+    const TF_LDS_AS double *const red = (const TF_LDS_AS double *)(scr + 4 * 64 * 32);
+    double vq[4] = {0.0, 0.0, 0.0, 0.0}, tq4[4];
+    {
+      const f64x4s sq = (P[0 * 64 + lane] + P[1 * 64 + lane]) + (P[2 * 64 + lane] + P[3 * 64 + lane]);
+      double pq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { vq[r] = sq[r] + offq; pq[r] = vq[r] * vq[r] * wq; }
+      if (!SPL) {   // (the waves without a share of the split tile still need its row sums: same constants)
+        const int col = (NT - 1) * 16 + fi;
+        const double oq = col < Dout ? A.offset[col] : 0.0, wq2 = col < Dout ? tf_rcp(A.psi[col] + inv_nu) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const double v = sq[r] + oq; pq[r] = v * v * wq2; }
+      }
+      const double yq = row_sum4_by_class(pq, lane);           // class lane & 3 -> every lane needs all four: quad broadcasts
+      tq4[0] = dpp_f64<0x00>(yq); tq4[1] = dpp_f64<0x55>(yq); tq4[2] = dpp_f64<0xAA>(yq); tq4[3] = dpp_f64<0xFF>(yq);
+    }
+    double fq = 0.0, vsel = 0.0;
+    unsigned qrow = 0xfffffff0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = fk + 4 * r;
+      double tot = tq4[r];
+#pragma unroll
+      for (int w = 0; w < 8; w += 2) tot += red[w * 16 + rr] + red[(w + 1) * 16 + rr];
+      // sqrt(Dout / tot) = sqrt(Dout) * rsqrt(tot): hardware estimate + two Newton steps (full precision)
+      double y = __builtin_amdgcn_rsq(tot);
+      y = y * fma(-0.5 * tot * y, y, 1.5);
+      y = y * fma(-0.5 * tot * y, y, 1.5);
+      const double fnorm = sqrt_dout * y;
+      // stores through a descriptor over `out` (R Dout 8 bytes): a row past R is beyond its range and dropped; no branch
+      const unsigned rowoff = (unsigned)((int)(g * 16 + rr) * Dout) * 8u;
+#pragma unroll
+      for (int f = 0; f < FTW; ++f) {
+        const unsigned col = (unsigned)((simd + 4 * f + TB) * 16 + fi);
+        const double val = fnorm * ac[f][r];
+        if (!(MODE & 4) || val == 123.456)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, val), rsO, (int)(((int)col < Dout) ? rowoff + col * 8u : 0xfffffff0u), 0, 0);
+      }
+      if (SPL && simd == r) { fq = fnorm; vsel = vq[r]; qrow = rowoff; }
+    }
+    if (SPL) {                                                 // the split tile's four regs: one per SIMD
+      const unsigned col = (unsigned)((NT - 1) * 16 + fi);
+      const double val = fq * vsel;
+      if (!(MODE & 4) || val == 123.456)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, val), rsO, (int)(((int)col < Dout) ? qrow + col * 8u : 0xfffffff0u), 0, 0);
+    }
+  };
+  auto zero = [&](f64x4s (&ac)[NA]) {
+#pragma unroll
+    for (int f = 0; f < NA; ++f) ac[f] = f64x4s{0.0, 0.0, 0.0, 0.0};
+  };
+
+  // ---- the two waves of a SIMD run the parts in DIFFERENT orders around the group's one barrier B(m), so that one's
+  //      epilogue falls under the other's MFMAs (both stopping for their epilogues at the same time left the matrix pipe
+  //      idle for 1.2 of a group's 6.2 us: measured):
+  //        two-tile wave:   MFMA(m)  epi1(m)  B(m)  epi2(m)            | MFMA(m+1) ...
+  //        tile + share:    ...  B(m)  MFMA(m+1)[first part]  epi2(m)  MFMA(m+1)[rest]  epi1(m+1)  B(m+1) ...
+  //      The DMA pieces of a group are shared by all eight waves; a two-tile wave issues its pieces of group m + 3 under
+  //      MFMA(m), a tile + share wave its pieces of group m + 2 under MFMA(m) -- both in front of B(m), into the slot all
+  //      waves left at B(m - 1) / B(m - 2).
+  constexpr int KSPLIT = 16;      // (tile + share) k-steps of the next group in front of its part 2 of this one: the stores get the rest of the MFMAs to retire before vmcnt(0)
+  if (!SPL) {
+    for (int m = 0;; ++m) {
+      f64x4s acc[NA];
+      zero(acc);
+      mfma_range(acc, m, gi, 0, KSTEPS, NBUF - 1);
+      epi1(acc, m);
+      __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): the operands requested in this step are in LDS
+      __builtin_amdgcn_s_barrier();
+      epi2(acc, m, gi);
+      gi += gstep;
+      if (gi >= ng) break;
+    }
+  } else {
+    f64x4s acc[NA];
+    zero(acc);
+    mfma_range(acc, 0, gi, 0, KSTEPS, 0);     // (group 2's pieces came with the prologue)
+    epi1(acc, 0);
+    for (int m = 0;; ++m) {
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __builtin_amdgcn_s_barrier();           // B(m)
+      const int64_t gn = gi + gstep;
+      if (gn >= ng) { epi2(acc, m, gi); break; }
+      f64x4s accn[NA];
+      zero(accn);
+      mfma_range(accn, m + 1, gn, 0, KSPLIT, NBUF - 2);
+      epi2(acc, m, gi);
+      mfma_range(accn, m + 1, gn, KSPLIT, KSTEPS, NBUF - 2);
+#pragma unroll
+      for (int f = 0; f < NA; ++f) acc[f] = accn[f];
+      epi1(acc, m + 1);
+      gi = gn;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+}
+
+// MODE (timing arms, garbage results): 1 no X DMA, 2 no MFMAs, 4 no output stores
+template <int NT, int KSTEPS, int MODE = 0>
+__global__ __launch_bounds__(512) void transform_treg_kernel(
+    const double *__restrict__ X, int64_t R, int Din, const double *__restrict__ Tpad, int Dinp, int Dout,
+    const double *__restrict__ offset, const double *__restrict__ psi, int n_uniform, double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double tf_lds[];
+  TF_LDS_AS char *const lds = (TF_LDS_AS char *)tf_lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if ((int64_t)blockIdx.x >= ((R + 15) >> 4)) return;
+  const TregArgs A{X, R, Din, Tpad, Dinp, Dout, offset, psi, n_uniform, out};
+  // wave w runs on SIMD w & 3 (waves of a workgroup are dealt to the SIMDs round robin): waves 0-3 take the two-tile
+  // role, waves 4-7 the tile + split-share role of the same SIMD
+  if (wave < 4) treg_wave<NT, KSTEPS, MODE, 2, 0, false>(A, lds, lane, wave, wave);
+  else treg_wave<NT, KSTEPS, MODE, 1, 8, true>(A, lds, lane, wave, wave - 4);
+}
+
+template <int NT, int KSTEPS, int MODE = 0>
+static int launch_transform_treg(plda_handle *h, const double *dX, int64_t R, int Din, int n_uniform, double *dout, int Dinp) {
+  using G = TregGeom<NT, KSTEPS>;
+  static_assert(G::LDS_BYTES <= 160 * 1024, "batch buffers exceed the LDS of a CU");
+  static DeviceOnce attr;
+  if (attr.needed(h->device)) {
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_treg_kernel<NT, KSTEPS, MODE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+    attr.done(h->device);
+  }
+  transform_treg_kernel<NT, KSTEPS, MODE><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)16), h->num_cus), 512, G::LDS_BYTES, h->stream>>>(
+      dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), n_uniform, dout);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
+}
+
 __global__ void pad_transform_kernel(const double *__restrict__ T, int Dout, int Din, double *__restrict__ Tpad, int rows,
                                      int Dinp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -625,6 +983,21 @@ static int transform_class(plda_handle *h, const double *dX, int64_t R, int Din,
         h->d_transform.as<double>(), h->Dout, Din, h->tf_pad.as<double>(), PADROWS, Dinp);
     PLDA_LAUNCH_CHECK(h);
     h->tf_pad_epoch = h->model_epoch; h->tf_pad_rows = PADROWS; h->tf_pad_dinp = Dinp;
+  }
+  // round 4, A/B arm (PLDA_TRANSFORM_VARIANT=6; 10-13: its timing arms): T resident in registers, X streamed
+  // (transform_treg_kernel) -- the C2 shape: 13 column tiles, Din = 200, a uniform count, at least eight row groups per
+  // CU, 32-bit byte offsets and 16-byte aligned rows for the DMA.  Measured level with the kernels below, not ahead of
+  // them (C2 0.21 against 0.19 ms, 800k rows 1.26 against 1.24 ms): not the product path.
+  if constexpr (NT0 == 13 && CH0 == 1) {
+    const int tv = h->transform_variant;
+    if (!dn && (tv == 6 || (tv >= 10 && tv <= 13)) && Din == 200 && h->Dout > 192 && R >= (int64_t)128 * h->num_cus &&
+        (reinterpret_cast<uintptr_t>(dX) & 15) == 0 && R * (int64_t)Din * 8 < ((int64_t)1 << 32) - (1 << 20)) {
+      if (tv == 10) return launch_transform_treg<13, 50, 1>(h, dX, R, Din, n_uniform, dout, Dinp);   // timing arms
+      if (tv == 11) return launch_transform_treg<13, 50, 2>(h, dX, R, Din, n_uniform, dout, Dinp);
+      if (tv == 12) return launch_transform_treg<13, 50, 4>(h, dX, R, Din, n_uniform, dout, Dinp);
+      if (tv == 13) return launch_transform_treg<13, 50, 7>(h, dX, R, Din, n_uniform, dout, Dinp);
+      return launch_transform_treg<13, 50>(h, dX, R, Din, n_uniform, dout, Dinp);
+    }
   }
   // (NTW = 0: no wide shape for this class -- above D = 256 two row tiles per wave spill; per-row counts with 8 tiles per
   //  slice spill 68 bytes per lane: the round-3 shape there)

@@ -410,3 +410,35 @@ def test_one_pass_prep_bit_identical(monkeypatch, d, m, nt, n_enrol, znorm):
         outs.append(o)
     assert torch.equal(outs[0], outs[1])
     assert bool((outs[0][:, nt:] == -7.0).all()) and bool(torch.isfinite(outs[0][:, :nt]).all())
+
+
+@pytest.mark.parametrize("dout", [200, 197, 193])
+def test_transform_with_the_matrix_resident_in_registers(dout, monkeypatch):
+    """transform_treg_kernel (round 4, PLDA_TRANSFORM_VARIANT=6: an A/B arm -- measured level with the product kernels, not
+    ahead; the C2 shape: Din = 200, 193 <= Dout <= 208, a uniform count, >= 32 768 rows): T's MFMA fragments stay in the
+    registers of the eight waves of a workgroup, X streams through LDS by DMA one 16-row group at a time -- against the
+    NumPy restatement of TransformIvector and against the product kernels on the same rows: whole groups, a ragged last
+    group, more groups than two rounds of the grid; truncated models put the edge of the output inside the thirteenth
+    (k-split) column tile."""
+    from oracle import plda_oracle_np as onp
+    from plda_amd import MPlda
+    din = 200
+    rng = np.random.default_rng(900 + dout)
+    q, _ = np.linalg.qr(rng.standard_normal((din, din)))
+    T = (q * (0.5 + rng.random(din))[:, None])[:dout]
+    mean = rng.random(din)
+    psi = np.sort(rng.random(dout) * 3.0 + 0.01)[::-1].copy()
+    model = dict(mean=mean, transform=T, psi=psi, offset=-T @ mean)
+    engs = {}
+    for variant in ("6", "0"):
+        monkeypatch.setenv("PLDA_TRANSFORM_VARIANT", variant)
+        engs[variant] = MPlda(0)
+        engs[variant].set_model(mean, T, psi)
+    for r, ne in ((32768, 1), (40011, 7), (100000, 3)):
+        x = rng.standard_normal((r, din))
+        x[r // 3] *= 1e3                                   # one row of another magnitude: the norm is per row
+        got = engs["6"].transform_array(x, ne)
+        old = engs["0"].transform_array(x, ne)
+        ref = onp.transform_ivector(model, x, ne)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(got, old, rtol=1e-13, atol=1e-14)
