@@ -632,7 +632,10 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   PLDA_HIP(h, hipEventRecord(h->fit_ev[0], h->stream));
   // pinned landing area of everything this call reads back: the model (mean | transform | psi | offset) and the EM's
   // factorisation flag -- copies into it are queued without blocking the host, one synchronisation ends the fit
-  const size_t pin_need = (3 * (size_t)D + DD) * 8 + 64;
+  // (+ the EM's planning traffic: class counts, count check and class weight coming back, the classes' order by count and
+  //  the groups' counts going out -- pageable, each of those six copies was a blocking 20-40 us)
+  const size_t pin_model_bytes = (3 * (size_t)D + DD) * 8 + 64;
+  const size_t pin_need = pin_model_bytes + (size_t)K * (8 + 4 + 8 + 8) + 64;
   if (h->pin_model_cap < pin_need) {
     if (h->pin_model) (void)hipHostFree(h->pin_model);
     h->pin_model = nullptr; h->pin_model_cap = 0;
@@ -673,12 +676,19 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     class_sum_final_kernel<<<(unsigned)ceil_div(D, 256), 256, 0, h->stream>>>(partial, wpart, D, sum, mu, scalars);
   }
   PLDA_LAUNCH_CHECK(h);
-  double class_weight = 0.0;
-  std::vector<int64_t> hcounts((size_t)K);
-  PLDA_HIP(h, hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(&class_weight, scalars, 8, hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipMemcpyAsync(hcounts.data(), h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToHost, h->stream));
+  char *const pin_plan = static_cast<char *>(h->pin_model) + pin_model_bytes;
+  int64_t *const hcounts = reinterpret_cast<int64_t *>(pin_plan);                      // [K]
+  double *const pin_gn = reinterpret_cast<double *>(pin_plan + (size_t)K * 8);         // [<= K]
+  double *const pin_gk = pin_gn + K;                                                   // [<= K]
+  double *const pin_cw = pin_gk + K;                                                   // class weight, then the count check
+  int *const pin_bad = reinterpret_cast<int *>(pin_cw + 1);
+  int *const pin_cls = reinterpret_cast<int *>(pin_cw + 2);                            // [K]
+  PLDA_HIP(h, hipMemcpyAsync(pin_bad, bad, 4, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(pin_cw, scalars, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipMemcpyAsync(hcounts, h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  hbad = *pin_bad;
+  const double class_weight = *pin_cw;
   if (hbad) return fail(h, PLDA_E_INVAL, "fit: class counts must be positive");
   const double example_weight = (double)K;  // sum_k w_k n_k with w_k = 1/n_k
 
@@ -690,9 +700,9 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   // One iteration is then D x D work only -- per group one Cholesky, one triangular inverse and five
   // GEMMs, all batched over the groups -- with no inverse of W or B (B may be singular) and no
   // eigendecomposition.  Same estimator as SURVEY.md A.2, different association of the sums.
-  std::vector<int> cls((size_t)K);
+  int *const cls = pin_cls;
   for (int64_t k = 0; k < K; ++k) cls[k] = (int)k;
-  std::stable_sort(cls.begin(), cls.end(), [&](int a, int b) { return hcounts[a] < hcounts[b]; });
+  std::stable_sort(cls, cls + K, [&](int a, int b) { return hcounts[a] < hcounts[b]; });
   std::vector<int64_t> goff;   // group g = sorted positions goff[g] .. goff[g+1]
   std::vector<double> gn, gk;
   for (int64_t r = 0; r < K; ++r)
@@ -718,9 +728,11 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
            *b2 = b1 + (size_t)G * DD, *b3 = b2 + (size_t)G * DD, *Csum = b3 + (size_t)G * DD, *dgn = Csum + DD,
            *dgk = dgn + G;
     int *dflag = h->fit_flag.as<int>();          // (its own buffer: the export kernel that ends the fit reads it)
-    PLDA_HIP(h, hipMemcpyAsync(dcls, cls.data(), (size_t)K * 4, hipMemcpyHostToDevice, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(dgn, gn.data(), (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
-    PLDA_HIP(h, hipMemcpyAsync(dgk, gk.data(), (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
+    std::copy(gn.begin(), gn.end(), pin_gn);
+    std::copy(gk.begin(), gk.end(), pin_gk);
+    PLDA_HIP(h, hipMemcpyAsync(dcls, cls, (size_t)K * 4, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dgn, pin_gn, (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dgk, pin_gk, (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
     gather_center_kernel<<<gKD, 256, 0, h->stream>>>(means, mu, dcls, K, D, Mg);
     PLDA_LAUNCH_CHECK(h);
     for (int g = 0; g < G; ++g) {
