@@ -569,8 +569,9 @@ __global__ __launch_bounds__(512) void transform_dma_kernel(const double *__rest
 //     middle of the MFMA stream, ~1 700 cycles each.  The DMA is inline assembly here; the waits are the explicit ones.
 //   * all 25 pieces of a group issued together behind the barrier queue at the CU's one address unit (~150 cycles per
 //     piece with 64 separate 16-byte requests, fewer with the quad-contiguous mapping): they go out one per 8 k-steps.
-//   * both waves of a SIMD stopping for their epilogues at the same barrier leaves the matrix pipe idle for the
-//     epilogue's 1.2 us per group; the two roles therefore run their parts in different orders around it (below).
+//   * both waves of a SIMD stopping for their epilogues at the same barrier leaves the matrix pipe idle; run in different
+//     orders around it (below), one wave's epilogue under the other's MFMAs takes three times as long as alone: the step
+//     stays at 15 400 cycles for 10 400 of MFMAs (phase stamps, PLDA_TRANSFORM_VARIANT=14).
 // Result: C2 (100k rows) 0.21 ms against 0.19, 800k rows 1.26 against 1.24 ms -- level with the kernels above, not
 // ahead: a group takes 6.2 us where its MFMAs are 4.4 (at 2.4 GHz), with or without the reordering.  Not the product
 // path; kept with its timing arms because the four findings above are what the next attempt starts from.
@@ -613,7 +614,7 @@ __device__ __forceinline__ double row_sum4_by_class(const double (&p)[4], int la
 
 struct TregArgs {
   const double *X; int64_t R; int Din; const double *Tpad; int Dinp; int Dout;
-  const double *offset; const double *psi; int n_uniform; double *out;
+  const double *offset; const double *psi; int n_uniform; double *out; unsigned long long *dbg;
 };
 
 // one wave's loop.  FTW full tiles (tile index simd + 4 f + TB), SPL: also k-steps [simd QS, +QS) of tile NT - 1
@@ -684,7 +685,7 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
     //  reads a DMA write may alias and puts s_waitcnt vmcnt(0) in front of EVERY later ds_read -- a memory round trip per
     //  piece in the middle of the MFMA stream, 1 700 cycles each (measured).  The waits this kernel needs are the two
     //  explicit ones in front of its barriers.)
-    const unsigned ldsaddr = (unsigned)(uintptr_t)(j < NPAIR ? lds + slot * GB + j * 1024 : lds + NBUF * GB + 2 * SCR + G::TL);
+    const unsigned ldsaddr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(j < NPAIR ? lds + slot * GB + j * 1024 : lds + NBUF * GB + 2 * SCR + G::TL));
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsaddr), "v"(voff), "s"(rsX) : "memory");
   };
   auto dma_group = [&](int64_t g, int slot, bool live) {
@@ -813,29 +814,49 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, val), rsO, (int)(((int)col < Dout) ? qrow + col * 8u : 0xfffffff0u), 0, 0);
     }
   };
+  // MODE bit 3: shader-clock stamps of workgroup 0 ([group 8 .. 23][wave][8]: the phases of a step, see the two loops)
+  auto stamp = [&](int m, int k) {
+    if (!(MODE & 8)) return;
+    const unsigned long long ts = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && lane == 0 && m >= 8 && m < 24) A.dbg[((m - 8) * 8 + wave) * 8 + k] = ts;
+  };
   auto zero = [&](f64x4s (&ac)[NA]) {
 #pragma unroll
     for (int f = 0; f < NA; ++f) ac[f] = f64x4s{0.0, 0.0, 0.0, 0.0};
   };
 
   // ---- the two waves of a SIMD run the parts in DIFFERENT orders around the group's one barrier B(m), so that one's
-  //      epilogue falls under the other's MFMAs (both stopping for their epilogues at the same time left the matrix pipe
-  //      idle for 1.2 of a group's 6.2 us: measured):
+  //      epilogue falls under the other's MFMAs:
   //        two-tile wave:   MFMA(m)  epi1(m)  B(m)  epi2(m)            | MFMA(m+1) ...
-  //        tile + share:    ...  B(m)  MFMA(m+1)[first part]  epi2(m)  MFMA(m+1)[rest]  epi1(m+1)  B(m+1) ...
+  //        tile + share:    ...  B(m)  MFMA(m+1)[k-steps < KSPLIT]  epi2(m)  MFMA(m+1)[rest]  epi1(m+1)  B(m+1) ...
+  //      Phase stamps (PLDA_TRANSFORM_VARIANT=14, scripts/transform_timeline.py, profiles/r04_transform_treg_timeline.txt):
+  //      a step is 15 400 cycles whatever KSPLIT is, against 10 400 of MFMAs.  With KSPLIT = 16 the two-tile wave's 100
+  //      MFMAs run at their full rate (66 cycles each) while the other wave's epilogue part 2 beside them takes 8 700
+  //      cycles instead of the 1 600 - 2 900 it takes alone -- fp64 MFMAs and the other wave's vector instructions do
+  //      share the SIMD, the MFMAs win and the vector stream gets about a third of its speed -- and that wave's remaining
+  //      47 MFMAs then run alone behind it; with KSPLIT = 50 the two waves' MFMAs interleave (163 in 12 500 cycles: 77
+  //      each, the tile + share wave being ONE dependent accumulator chain) and both epilogues are exposed.  Either way
+  //      10 400 + ~5 000: on this part the fp64 matrix rate equals the fp64 vector rate, and a transform whose epilogue
+  //      is ~7 000 vector-unit cycles per SIMD and row group cannot hide it -- it has to get shorter (section 8).
   //      The DMA pieces of a group are shared by all eight waves; a two-tile wave issues its pieces of group m + 3 under
   //      MFMA(m), a tile + share wave its pieces of group m + 2 under MFMA(m) -- both in front of B(m), into the slot all
   //      waves left at B(m - 1) / B(m - 2).
-  constexpr int KSPLIT = 16;      // (tile + share) k-steps of the next group in front of its part 2 of this one: the stores get the rest of the MFMAs to retire before vmcnt(0)
+  constexpr int KSPLIT = KSTEPS;
   if (!SPL) {
     for (int m = 0;; ++m) {
       f64x4s acc[NA];
       zero(acc);
+      stamp(m, 0);
       mfma_range(acc, m, gi, 0, KSTEPS, NBUF - 1);
+      stamp(m, 1);
       epi1(acc, m);
+      stamp(m, 2);
       __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): the operands requested in this step are in LDS
+      stamp(m, 3);
       __builtin_amdgcn_s_barrier();
+      stamp(m, 4);
       epi2(acc, m, gi);
+      stamp(m, 5);
       gi += gstep;
       if (gi >= ng) break;
     }
@@ -845,18 +866,25 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
     mfma_range(acc, 0, gi, 0, KSTEPS, 0);     // (group 2's pieces came with the prologue)
     epi1(acc, 0);
     for (int m = 0;; ++m) {
+      stamp(m, 6);
       __builtin_amdgcn_s_waitcnt(0x0070);
+      stamp(m, 7);
       __builtin_amdgcn_s_barrier();           // B(m)
+      stamp(m, 0);
       const int64_t gn = gi + gstep;
       if (gn >= ng) { epi2(acc, m, gi); break; }
       f64x4s accn[NA];
       zero(accn);
       mfma_range(accn, m + 1, gn, 0, KSPLIT, NBUF - 2);
+      stamp(m, 1);
       epi2(acc, m, gi);
+      stamp(m, 2);
       mfma_range(accn, m + 1, gn, KSPLIT, KSTEPS, NBUF - 2);
+      stamp(m, 3);
 #pragma unroll
       for (int f = 0; f < NA; ++f) acc[f] = accn[f];
       epi1(acc, m + 1);
+      stamp(m, 4);
       gi = gn;
     }
   }
@@ -867,13 +895,13 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
 template <int NT, int KSTEPS, int MODE = 0>
 __global__ __launch_bounds__(512) void transform_treg_kernel(
     const double *__restrict__ X, int64_t R, int Din, const double *__restrict__ Tpad, int Dinp, int Dout,
-    const double *__restrict__ offset, const double *__restrict__ psi, int n_uniform, double *__restrict__ out) {
+    const double *__restrict__ offset, const double *__restrict__ psi, int n_uniform, double *__restrict__ out, unsigned long long *__restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) double tf_lds[];
   TF_LDS_AS char *const lds = (TF_LDS_AS char *)tf_lds;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if ((int64_t)blockIdx.x >= ((R + 15) >> 4)) return;
-  const TregArgs A{X, R, Din, Tpad, Dinp, Dout, offset, psi, n_uniform, out};
+  const TregArgs A{X, R, Din, Tpad, Dinp, Dout, offset, psi, n_uniform, out, dbg};
   // wave w runs on SIMD w & 3 (waves of a workgroup are dealt to the SIMDs round robin): waves 0-3 take the two-tile
   // role, waves 4-7 the tile + split-share role of the same SIMD
   if (wave < 4) treg_wave<NT, KSTEPS, MODE, 2, 0, false>(A, lds, lane, wave, wave);
@@ -884,6 +912,7 @@ template <int NT, int KSTEPS, int MODE = 0>
 static int launch_transform_treg(plda_handle *h, const double *dX, int64_t R, int Din, int n_uniform, double *dout, int Dinp) {
   using G = TregGeom<NT, KSTEPS>;
   static_assert(G::LDS_BYTES <= 160 * 1024, "batch buffers exceed the LDS of a CU");
+  if (MODE & 8) PLDA_HIP(h, h->timeline.reserve((size_t)8 * 16 * 8 * 8 * 8));
   static DeviceOnce attr;
   if (attr.needed(h->device)) {
     PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_treg_kernel<NT, KSTEPS, MODE>),
@@ -891,8 +920,10 @@ static int launch_transform_treg(plda_handle *h, const double *dX, int64_t R, in
     attr.done(h->device);
   }
   transform_treg_kernel<NT, KSTEPS, MODE><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)16), h->num_cus), 512, G::LDS_BYTES, h->stream>>>(
-      dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), n_uniform, dout);
+      dX, R, Din, h->tf_pad.as<double>(), Dinp, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), n_uniform, dout,
+      (MODE & 8) ? h->timeline.as<unsigned long long>() : nullptr);
   PLDA_LAUNCH_CHECK(h);
+  if (MODE & 8) h->timeline_valid = true;
   return PLDA_OK;
 }
 
@@ -990,12 +1021,13 @@ static int transform_class(plda_handle *h, const double *dX, int64_t R, int Din,
   // them (C2 0.21 against 0.19 ms, 800k rows 1.26 against 1.24 ms): not the product path.
   if constexpr (NT0 == 13 && CH0 == 1) {
     const int tv = h->transform_variant;
-    if (!dn && (tv == 6 || (tv >= 10 && tv <= 13)) && Din == 200 && h->Dout > 192 && R >= (int64_t)128 * h->num_cus &&
+    if (!dn && (tv == 6 || (tv >= 10 && tv <= 14)) && Din == 200 && h->Dout > 192 && R >= (int64_t)128 * h->num_cus &&
         (reinterpret_cast<uintptr_t>(dX) & 15) == 0 && R * (int64_t)Din * 8 < ((int64_t)1 << 32) - (1 << 20)) {
       if (tv == 10) return launch_transform_treg<13, 50, 1>(h, dX, R, Din, n_uniform, dout, Dinp);   // timing arms
       if (tv == 11) return launch_transform_treg<13, 50, 2>(h, dX, R, Din, n_uniform, dout, Dinp);
       if (tv == 12) return launch_transform_treg<13, 50, 4>(h, dX, R, Din, n_uniform, dout, Dinp);
       if (tv == 13) return launch_transform_treg<13, 50, 7>(h, dX, R, Din, n_uniform, dout, Dinp);
+      if (tv == 14) return launch_transform_treg<13, 50, 8>(h, dX, R, Din, n_uniform, dout, Dinp);   // phase stamps of workgroup 0
       return launch_transform_treg<13, 50>(h, dX, R, Din, n_uniform, dout, Dinp);
     }
   }
