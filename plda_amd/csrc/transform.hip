@@ -269,12 +269,19 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
           }
       }
     }
+    // the sum over the 16 column lanes of a row: four DPP steps in the register file (round 4; __shfl_xor of a double is
+    // two ds_bpermute round trips per step -- on a part whose fp64 MFMAs share the SIMD with every vector instruction,
+    // the epilogue's cycles are not hidden by anything)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) part[rt][r] += __shfl_xor(part[rt][r], o);
+        double pz = part[rt][r];
+        pz += dpp_f64<0xB1>(pz);     // quad_perm [1,0,3,2]
+        pz += dpp_f64<0x4E>(pz);     // quad_perm [2,3,0,1]
+        pz += dpp_f64<0x141>(pz);    // row_half_mirror
+        pz += dpp_f64<0x140>(pz);    // row_mirror: every lane of the row holds the row's sum
+        part[rt][r] = pz;
       }
     if (CH > 1) {     // the other column slices of the same rows live in waves (rg, ch'): exchange through LDS
       if (fi == 0) {
@@ -294,11 +301,18 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
           part[rt][r] = sum;
         }
     }
+    const double sqrt_dout = sqrt((double)Dout);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double f = sqrt((double)Dout / part[rt][r]);
+        // sqrt(Dout / sum) = sqrt(Dout) * rsqrt(sum): hardware estimate + two Newton steps (a division and a square root
+        // were ~70 instructions per row)
+        const double tot = part[rt][r];
+        double y = __builtin_amdgcn_rsq(tot);
+        y = y * fma(-0.5 * tot * y, y, 1.5);
+        y = y * fma(-0.5 * tot * y, y, 1.5);
+        const double f = sqrt_dout * y;
         if (grow[rt][r] < R) {
           double *o = out + grow[rt][r] * (int64_t)Dout;
 #pragma unroll
