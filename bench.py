@@ -609,6 +609,52 @@ def main():
               "GBps_in_plus_out": round(8.0 * Nt * (D + dout) / tsec / 1e9, 1)}
         del Xt, Yt
 
+    # ---- where the wall-clock fraction comes from (round 4): the product kernel with two stamp pairs per workgroup
+    #      (PLDA_GEMM_VARIANT=47: s_memtime against the 100 MHz s_memrealtime) on the same operands -- the shader clock
+    #      this box holds under the load, and workgroup 0's cycles per tile against the tile's MFMA cycles.  The
+    #      fraction of the peak is (MFMA-busy in cycles) x (clock / 2.4 GHz) x (1 - tail); the clock differs between the
+    #      boxes of a pool by 1-4 %, the cycles do not.  Outside the timed region, on a second handle. ----
+    clock_info = None
+    if rank == 0 and world == 1 and not emu and not args.no_extra and not args.targetdim and "bt4" in eng.score_last_kernel():
+        try:
+            import ctypes as C
+            old_env = os.environ.get("PLDA_GEMM_VARIANT")
+            os.environ["PLDA_GEMM_VARIANT"] = "47"
+            e2 = MPlda(local_rank)
+            if old_env is None:
+                del os.environ["PLDA_GEMM_VARIANT"]
+            else:
+                os.environ["PLDA_GEMM_VARIANT"] = old_env
+            mdl = eng.get_model()
+            e2.set_model(mdl["mean"], mdl["transform"], mdl["psi"])
+            e2.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            dnp2 = dn.data_ptr() if dn is not None else None
+            for _ in range(3):
+                e2.score_matrix_dev(dU.data_ptr(), dnp2, n_uniform, M, dT.data_ptr(), Nt, out.data_ptr(), Nt)
+            torch.cuda.synchronize(dev)
+            raw = np.zeros(8 * 16 * 8 * 8, np.uint64)
+            e2._ck(e2._lib.plda_profile_timeline(e2._h, C.c_void_p(raw.ctypes.data), raw.size))
+            cyc, real, tiles = int(raw[0]), int(raw[1]), int(raw[2])
+            kg = max((((2 if dn is not None else 1) * ((dout + 7) // 8 * 8)) + 7) // 8 * 8, 16)
+            ideal_tile = kg // 8 * 4096 + 1024          # MFMA cycles of a 256 x 256 tile per SIMD (k steps + the bias MFMAs)
+            mhz = cyc / (real / 100.0)
+            wg = raw[8:8 + 4 * 256].reshape(256, 4).astype(np.int64)       # per workgroup: cycles, start, end (100 MHz ticks), tiles
+            end_spread_us = float((wg[:, 2].max() - wg[:, 2].min()) / 100.0)
+            cpt = wg[:, 0] / np.maximum(wg[:, 3], 1)
+            wmhz = wg[:, 0] / np.maximum((wg[:, 2] - wg[:, 1]) / 100.0, 1e-9)
+            clock_info = {"shader_clock_MHz": round(float(np.median(wmhz)), 1), "clock_over_2400": round(float(np.median(wmhz)) / 2400.0, 4),
+                          "clock_MHz_min_max_over_workgroups": [round(float(wmhz.min()), 1), round(float(wmhz.max()), 1)],
+                          "tiles_per_workgroup_min_max": [int(wg[:, 3].min()), int(wg[:, 3].max())],
+                          "cycles_per_tile": round(float(np.median(cpt)), 1), "mfma_cycles_per_tile": ideal_tile,
+                          "mfma_busy_in_cycles": round(float(ideal_tile / np.median(cpt)), 4),
+                          "workgroup0": {"cycles": cyc, "ticks_100MHz": real, "tiles": tiles, "MHz": round(mhz, 1)},
+                          "end_spread_of_workgroups_us": round(end_spread_us, 1),
+                          "how": "PLDA_GEMM_VARIANT=47 (the product kernel + s_memtime / s_memrealtime stamps per workgroup), last of 3 launches on the timed operands"}
+            e2.set_stream(None)
+            del e2
+        except Exception as ex:      # a diagnostic: never fails the bench line
+            clock_info = {"error": str(ex)[:200]}
+
     # ---- build extension named by BASELINE configs[1]: targetdim = 150 (top-psi dims), same trials ----
     td = None
     if rank == 0 and world == 1 and args.config == "C2" and not args.targetdim and dout > 150 and not args.no_extra:
@@ -657,7 +703,8 @@ def main():
                          "kernel": "%s (rank 0's launches)" % eng.score_last_kernel(),
                          "flop_per_trial": 2 * gemm_k, "avg_kernel_ms": round(avg_gemm_s * 1e3, 4),
                          "launches": launches,
-                         "hbm_write_GBps": round(gemm_flop / max(launches, 1) / (2 * gemm_k) * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None},
+                         "hbm_write_GBps": round(gemm_flop / max(launches, 1) / (2 * gemm_k) * 4 / avg_gemm_s / 1e9, 1) if avg_gemm_s > 0 else None,
+                         **({"clock": clock_info} if clock_info else {})},
             "fit": fit_info, "spot_check_max_abs_err": spot, "oracle_check": oracle_check,
         }
         if multi:
