@@ -674,7 +674,7 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
     offs[f] = col < Dout ? A.offset[col] : 0.0;
     wts[f] = col < Dout ? tf_rcp(A.psi[col] + inv_nu) : 0.0;
   }
-  if (SPL) {
+  {   // (both roles: every wave forms the split tile's row sums)
     const int col = (NT - 1) * 16 + fi;
     offq = col < Dout ? A.offset[col] : 0.0;
     wq = col < Dout ? tf_rcp(A.psi[col] + inv_nu) : 0.0;
@@ -788,12 +788,6 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
       double pq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { vq[r] = sq[r] + offq; pq[r] = vq[r] * vq[r] * wq; }
-      if (!SPL) {   // (the waves without a share of the split tile still need its row sums: same constants)
-        const int col = (NT - 1) * 16 + fi;
-        const double oq = col < Dout ? A.offset[col] : 0.0, wq2 = col < Dout ? tf_rcp(A.psi[col] + inv_nu) : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const double v = sq[r] + oq; pq[r] = v * v * wq2; }
-      }
       const double yq = row_sum4_by_class(pq, lane);           // class lane & 3 -> every lane needs all four: quad broadcasts
       tq4[0] = dpp_f64<0x00>(yq); tq4[1] = dpp_f64<0x55>(yq); tq4[2] = dpp_f64<0xAA>(yq); tq4[3] = dpp_f64<0xFF>(yq);
     }
