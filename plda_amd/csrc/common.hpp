@@ -254,6 +254,8 @@ int gemm_f64_pair(plda_handle *h, int64_t M, int64_t N, int64_t K, const double 
                   int64_t strideC1, int batch);
 int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
                     int *dflag, int batch);
+int spd_inverse_via_whitening_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T,
+                                  double *out, int *dflag, int batch);
 // [batch] SPD inverses of any size (A^-1 = T^T T, T = blocked whitening); out may be A itself; scr: 3 n^2 doubles each
 int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
                         int64_t so, double *scr, int64_t sscr, int *dflag, int batch);

@@ -746,7 +746,9 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       // inv = A^-1 ; Q = B A^-1 ; b1 = Mx = W Q^T ; QC = Q C_g (over inv) ; b3 = QCQ = QC Q^T
       double *inv = b2, *Q = b0;
       if (D <= 256) {
-        PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, inv, dflag, G));                    // registers, one CU per group
+        // registers, one CU per group (PLDA_EM_VARIANT=2: the full sweep instead of whitening + T^T T)
+        if (h->em_variant == 2) PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, inv, dflag, G));
+        else PLDA_TRY(spd_inverse_via_whitening_f64(h, W, B, dgn, D, Q, inv, dflag, G));   // (Q is free until the next line)
       } else {
         // A^-1 = T^T T from the blocked whitening; A is dead once T exists, so the inverse replaces it in b0,
         // and b1 .. b3 (contiguous) are the 3 D^2 doubles of scratch per group
