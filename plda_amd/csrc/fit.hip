@@ -701,8 +701,22 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   // GEMMs, all batched over the groups -- with no inverse of W or B (B may be singular) and no
   // eigendecomposition.  Same estimator as SURVEY.md A.2, different association of the sums.
   int *const cls = pin_cls;
-  for (int64_t k = 0; k < K; ++k) cls[k] = (int)k;
-  std::stable_sort(cls, cls + K, [&](int a, int b) { return hcounts[a] < hcounts[b]; });
+  {
+    // classes in ascending order of their count, ties in class order: by counting when the counts span a small range (a
+    // comparison sort of 5 000 classes through an index array was 100+ us of host time with the GPU idle), else by sorting
+    int64_t cmin = hcounts[0], cmax = hcounts[0];
+    for (int64_t k = 1; k < K; ++k) { cmin = std::min(cmin, hcounts[k]); cmax = std::max(cmax, hcounts[k]); }
+    const int64_t span = cmax - cmin + 1;
+    if (span <= 65536) {
+      std::vector<int> start((size_t)span + 1, 0);
+      for (int64_t k = 0; k < K; ++k) ++start[(size_t)(hcounts[k] - cmin) + 1];
+      for (int64_t v = 0; v < span; ++v) start[(size_t)v + 1] += start[(size_t)v];
+      for (int64_t k = 0; k < K; ++k) cls[start[(size_t)(hcounts[k] - cmin)]++] = (int)k;
+    } else {
+      for (int64_t k = 0; k < K; ++k) cls[k] = (int)k;
+      std::stable_sort(cls, cls + K, [&](int a, int b) { return hcounts[a] < hcounts[b]; });
+    }
+  }
   std::vector<int64_t> goff;   // group g = sorted positions goff[g] .. goff[g+1]
   std::vector<double> gn, gk;
   for (int64_t r = 0; r < K; ++r)
