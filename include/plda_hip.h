@@ -88,11 +88,12 @@ int plda_fit_stats_dev(plda_handle *h, const double *dX, int64_t N, int32_t D,
 int plda_fit_get_stats_dev(plda_handle *h, double *dmeans, int64_t *dcounts, double *dscatter);
 int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts, int64_t K,
                     const double *dscatter, int32_t D, int32_t iters);
-/* timings of the last fit, milliseconds: [0] statistics pass (sort+centroid+scatter), host wall clock;
+/* timings of the last fit, milliseconds: [0] statistics pass (sort+centroid+scatter): host wall clock of
+ * plda_fit_stats*, its span on the stream inside plda_fit (which does not synchronise between the two halves);
  * [1] EM loop (all iterations): its span on the stream between two events (planning of the count groups
  * on the host included); [2] GetOutput: the rest of the call's wall clock behind the EM (its kernels, the
  * export of the model and status words to the host mirror, the one synchronisation); [3] = iterations run.
- * [1] + [2] = wall clock of plda_fit_em_dev. */
+ * [1] + [2] = wall clock of plda_fit_em_dev; [0] + [1] + [2] = wall clock of plda_fit. */
 int plda_fit_timings(plda_handle *h, double out_ms[4]);
 /* staged access to the fit internals (parity tests of SURVEY.md rows a3-a7):
  * any pointer may be NULL.  means[K*D] in label order, counts[K], scatter[D*D],

@@ -731,7 +731,6 @@ int znorm_stats_sharded_device(plda_handle *h, const double *dbkg, int64_t Nb, i
 }
 
 // ------------------------------------------------------------------------------------ fit by speaker
-int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K);
 int fit_em_device(plda_handle *h, int64_t K, int D, int iters);
 
 int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K, int iters) {

@@ -63,7 +63,9 @@ struct plda_handle {
   plda::DevBuf f_means, f_counts, f_scatter, f_sum, f_W, f_B;
   plda::DevBuf fit_flag;         // the EM's factorisation flag (read by export_model_kernel at the end of a fit)
   double fit_ms[4] = {0, 0, 0, 0};
-  hipEvent_t fit_ev[2] = {nullptr, nullptr};   // EM start / end on the stream (fit_em_device)
+  hipEvent_t fit_ev[3] = {nullptr, nullptr, nullptr};   // EM start / end, statistics start on the stream (fit.hip)
+  int *fit_dbad = nullptr;       // label-check flags of a statistics pass whose read-back fit_em_device takes over (plda_fit)
+  double fit_t0 = 0.0;           // host clock at the start of that pass
 
   // ---- LDA model (lda.hip; /root/reference/python/liblda/lda.py) ----
   bool lda_fitted = false;
@@ -293,7 +295,7 @@ int lda_fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uin
                    int solver, const double *priors_host);
 int lda_predict_device(plda_handle *h, const double *dX, int64_t N, int mode, double *dout);
 int lda_transform_device(plda_handle *h, const double *dX, int64_t N, int ncomp, double *dout);
-int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K);
+int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K, bool defer_check = false);
 int fit_em_device(plda_handle *h, int64_t K, int D, int iters);
 int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels,
                int64_t K, int iters);

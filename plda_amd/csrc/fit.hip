@@ -550,13 +550,21 @@ static int sort_by_label(plda_handle *h, const uint64_t *dlabels, int64_t N, int
 // Statistics pass (pldamodule.cpp:76-100): leaves means[K,D], counts[K] and the offset scatter of THESE
 // classes in the handle.  The scatter, the weighted class sum and the class weight are all additive over
 // disjoint sets of speakers, which is what lets the pass shard by speaker.
-int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K) {
+// defer_check (plda_fit: the EM follows at once): the label checks are NOT read back here -- fit_em_device reads them with
+// the one host round trip its planning needs anyway, and takes the pass's time from events.
+int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *dlabels, int64_t K, bool defer_check) {
   if (!dX || !dlabels || N <= 0 || D <= 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
   if (K <= 0 || K > N) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
   if (D > 2048) return fail(h, PLDA_E_INVAL, "fit: featdim %d > 2048 unsupported", D);
   const size_t DD = (size_t)D * D;
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t0 = now_ms();
+  h->fit_dbad = nullptr;
+  if (defer_check) {
+    for (hipEvent_t &e : h->fit_ev)
+      if (!e) PLDA_HIP(h, hipEventCreate(&e));
+    PLDA_HIP(h, hipEventRecord(h->fit_ev[2], h->stream));
+  }
 
   // ---------------- statistics (K1a, K1, K2) ----------------
   uint32_t *perm = nullptr;
@@ -589,14 +597,19 @@ int fit_stats_device(plda_handle *h, const double *dX, int64_t N, int D, const u
   }
   // the label checks are read back only now, with the synchronisation the pass ends on anyway: a failed check
   // leaves garbage values (never an invalid index) in what was enqueued after it
+  h->fit_K = K; h->fit_D = D;
+  h->fit_ms[0] = h->fit_ms[1] = h->fit_ms[2] = h->fit_ms[3] = 0.0;
+  if (defer_check) {       // no host round trip: the EM's planning copy brings the flags back (35 us of idle GPU less)
+    h->fit_dbad = dbad;
+    h->fit_t0 = t0;
+    return PLDA_OK;
+  }
   int hbad[2] = {0, 0};
   PLDA_HIP(h, hipMemcpyAsync(hbad, dbad, 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
   if (hbad[0] & 1) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
   if (hbad[0] & 2) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1 (label %d unused)", hbad[1]);
-  h->fit_K = K; h->fit_D = D;
   h->fit_ms[0] = now_ms() - t0;
-  h->fit_ms[1] = h->fit_ms[2] = h->fit_ms[3] = 0.0;
   return PLDA_OK;
 }
 
@@ -624,18 +637,21 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   const size_t DD = (size_t)D * D;
   h->simdiag_has_vr = false;   // a new fit starts cold
   h->jac_total_sweeps = 0;
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  const double t1 = now_ms();
+  int *const stats_bad = h->fit_dbad;      // a statistics pass of this same plda_fit is still on the stream: no synchronisation,
+  h->fit_dbad = nullptr;                   // its label checks come back with the planning copies below
+  if (!stats_bad) PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const double t1 = stats_bad ? h->fit_t0 : now_ms();
   // EM | GetOutput boundary of plda_fit_timings: a pair of events instead of a host synchronisation, so that GetOutput is
   // enqueued while the EM still runs (the synchronisation left the GPU idle for the host's launch latency, 30-50 us)
-  if (!h->fit_ev[0]) { PLDA_HIP(h, hipEventCreate(&h->fit_ev[0])); PLDA_HIP(h, hipEventCreate(&h->fit_ev[1])); }
+  for (hipEvent_t &e : h->fit_ev)
+    if (!e) PLDA_HIP(h, hipEventCreate(&e));
   PLDA_HIP(h, hipEventRecord(h->fit_ev[0], h->stream));
   // pinned landing area of everything this call reads back: the model (mean | transform | psi | offset) and the EM's
   // factorisation flag -- copies into it are queued without blocking the host, one synchronisation ends the fit
   // (+ the EM's planning traffic: class counts, count check and class weight coming back, the classes' order by count and
   //  the groups' counts going out -- pageable, each of those six copies was a blocking 20-40 us)
   const size_t pin_model_bytes = (3 * (size_t)D + DD) * 8 + 64;
-  const size_t pin_need = pin_model_bytes + (size_t)K * (8 + 4 + 8 + 8) + 64;
+  const size_t pin_need = pin_model_bytes + (size_t)K * (8 + 4 + 8 + 8) + 96;
   if (h->pin_model_cap < pin_need) {
     if (h->pin_model) (void)hipHostFree(h->pin_model);
     h->pin_model = nullptr; h->pin_model_cap = 0;
@@ -660,9 +676,20 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   double *mu = h->w[4].as<double>();
   double *scalars = mu + D;
   int *offsets = h->w[1].as<int>();
+  char *const pin_plan = static_cast<char *>(h->pin_model) + pin_model_bytes;
+  int64_t *const hcounts = reinterpret_cast<int64_t *>(pin_plan);                      // [K]
+  double *const pin_gn = reinterpret_cast<double *>(pin_plan + (size_t)K * 8);         // [<= K]
+  double *const pin_gk = pin_gn + K;                                                   // [<= K]
+  double *const pin_cw = pin_gk + K;                                                   // class weight, then the count check,
+  int *const pin_bad = reinterpret_cast<int *>(pin_cw + 1);                            // then the statistics pass's two label words
+  int *const pin_lab = reinterpret_cast<int *>(pin_cw + 2);
+  int *const pin_cls = reinterpret_cast<int *>(pin_cw + 3);                            // [K]
+  pin_lab[0] = pin_lab[1] = 0;
   // one host round trip for everything the group planning needs: the count check, the class weight and the counts
   int *bad = offsets + K + 1;
   int hbad = 0;
+  // (the statistics pass kept its label words in this same buffer: out before the count check's word is cleared)
+  if (stats_bad) PLDA_HIP(h, hipMemcpyAsync(pin_lab, stats_bad, 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipMemsetAsync(bad, 0, 4, h->stream));
   counts_to_offsets_kernel<<<(unsigned)ceil_div(K + 1, 256), 256, 0, h->stream>>>(h->f_counts.as<int64_t>(), K,
                                                                                 offsets, bad);
@@ -676,17 +703,12 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     class_sum_final_kernel<<<(unsigned)ceil_div(D, 256), 256, 0, h->stream>>>(partial, wpart, D, sum, mu, scalars);
   }
   PLDA_LAUNCH_CHECK(h);
-  char *const pin_plan = static_cast<char *>(h->pin_model) + pin_model_bytes;
-  int64_t *const hcounts = reinterpret_cast<int64_t *>(pin_plan);                      // [K]
-  double *const pin_gn = reinterpret_cast<double *>(pin_plan + (size_t)K * 8);         // [<= K]
-  double *const pin_gk = pin_gn + K;                                                   // [<= K]
-  double *const pin_cw = pin_gk + K;                                                   // class weight, then the count check
-  int *const pin_bad = reinterpret_cast<int *>(pin_cw + 1);
-  int *const pin_cls = reinterpret_cast<int *>(pin_cw + 2);                            // [K]
   PLDA_HIP(h, hipMemcpyAsync(pin_bad, bad, 4, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipMemcpyAsync(pin_cw, scalars, 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipMemcpyAsync(hcounts, h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToHost, h->stream));
   PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (pin_lab[0] & 1) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1");
+  if (pin_lab[0] & 2) return fail(h, PLDA_E_LABELS, "fit: labels must be dense 0..K-1 (label %d unused)", pin_lab[1]);
   hbad = *pin_bad;
   const double class_weight = *pin_cw;
   if (hbad) return fail(h, PLDA_E_INVAL, "fit: class counts must be positive");
@@ -875,10 +897,14 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   h->fitted = true;
   ++h->model_epoch;
   h->fit_K = K; h->fit_D = D;
-  float em_span = 0.f;
+  float em_span = 0.f, stats_span = 0.f;
   PLDA_HIP(h, hipEventElapsedTime(&em_span, h->fit_ev[0], h->fit_ev[1]));
+  if (stats_bad) {       // the statistics pass of the same call: its span on the stream (t1 = the host clock at ITS start)
+    PLDA_HIP(h, hipEventElapsedTime(&stats_span, h->fit_ev[2], h->fit_ev[0]));
+    h->fit_ms[0] = (double)stats_span;
+  }
   // em_ms: the EM's span on the stream; output_ms: the rest of the wall clock of this call (GetOutput, model copies)
-  h->fit_ms[1] = (double)em_span; h->fit_ms[2] = (t3 - t1) - (double)em_span; h->fit_ms[3] = (double)iters;
+  h->fit_ms[1] = (double)em_span; h->fit_ms[2] = (t3 - t1) - (double)em_span - (double)stats_span; h->fit_ms[3] = (double)iters;
   return PLDA_OK;
 }
 
@@ -888,7 +914,7 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
   if (K == 1)
     return fail(h, PLDA_E_ONE_SPEAKER,
                 "Number of speakers is 1. Aborting PLDA esimation, at least two speakers are required!");
-  PLDA_TRY(fit_stats_device(h, dX, N, D, dlabels, K));
+  PLDA_TRY(fit_stats_device(h, dX, N, D, dlabels, K, true));
   return fit_em_device(h, K, D, iters);
 }
 
