@@ -325,6 +325,15 @@ __global__ void set_identity2_kernel(double *W, double *B, int D) {
   if (idx < D * D) { const double v = (idx / D == idx % D) ? 1.0 : 0.0; W[idx] = v; B[idx] = v; }
 }
 
+// (W + n_g B)^-1 of the EM's FIRST iteration: W = B = I there (Kaldi's PldaEstimator starts from unit covariances,
+// set_identity2_kernel above), so the inverse is I / (1 + n_g) -- a 70 us factorisation of a multiple of the identity
+// otherwise.  grid (ceil(D^2 / 256), groups)
+__global__ void em_first_inverse_kernel(const double *__restrict__ gn, int D, int64_t stride, double *__restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * D) return;
+  out[(int64_t)blockIdx.y * stride + idx] = (idx / D == idx % D) ? 1.0 / (1.0 + gn[blockIdx.y]) : 0.0;
+}
+
 // offset = -T mean (Plda::ComputeDerivedVars), one wave per output row
 __global__ void offset_kernel(const double *__restrict__ T, const double *__restrict__ mean, int Dout, int Din,
                               double *__restrict__ offset) {
@@ -781,7 +790,11 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     for (int it = 0; it < iters; ++it) {
       // inv = A^-1 ; Q = B A^-1 ; b1 = Mx = W Q^T ; QC = Q C_g (over inv) ; b3 = QCQ = QC Q^T
       double *inv = b2, *Q = b0;
-      if (D <= 256) {
+      if (it == 0 && h->em_variant != 2) {
+        if (D > 256) { inv = b0; Q = b2; }
+        em_first_inverse_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(dgn, D, sDD, inv);
+        PLDA_LAUNCH_CHECK(h);
+      } else if (D <= 256) {
         // registers, one CU per group (PLDA_EM_VARIANT=2: the full sweep instead of whitening + T^T T)
         if (h->em_variant == 2) PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, inv, dflag, G));
         else PLDA_TRY(spd_inverse_via_whitening_f64(h, W, B, dgn, D, Q, inv, dflag, G));   // (Q is free until the next line)
