@@ -155,8 +155,16 @@ int plda_score_one(plda_handle *h, const double *u, int32_t n_enrol, const doubl
 /* Dense trials matrix out[i*ld_out + j] = LLR(U[i], n[i], V[j]) for the M x Nt
  * block (the nested Python loop of scoring/scorePLDA.py:302-318 and
  * tests/pldatest.py:29-33 as one launch): fp64 bias terms + fp32 MFMA GEMM,
- * fp32 scores.  n_enrol NULL => every row uses n_uniform (GEMM depth Dout);
- * otherwise depth 2*Dout.  zmean/zstd as above (nullable). */
+ * fp32 scores.  n_enrol NULL => every row uses n_uniform (GEMM depth Dout).
+ * Otherwise the rows are bucketed by their G DISTINCT counts and the depth is
+ * Dout + G - 1 (one column-bias vector per distinct count, carried as extra
+ * contraction columns; C4's n in 1..5 at D = 256: 264 instead of 512); counts
+ * above 4095, more than 64 distinct ones or G - 1 > Dout / 2 take the depth-2*Dout
+ * form [A1 | A2] x [V | V*V].  plda_score_matrix finds the distinct counts on the
+ * host; the _dev entry points find them with one small device pass and ONE wait
+ * for the handle's stream per call (the host must know G to size the operands);
+ * uniform calls and calls that reuse a prepared test side of the depth-2*Dout
+ * form enqueue only.  zmean/zstd as above (nullable). */
 int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol,
                       int32_t n_uniform, int64_t M, const double *V, int64_t Nt,
                       const double *zmean, const double *zstd, float *out,
@@ -171,13 +179,18 @@ int plda_score_matrix_dev(plda_handle *h, const double *dU, const int32_t *dn_en
  * plda_score_matrix_dev / _sharded_dev calls with the SAME dV, Nt, model and kind of enrol counts skip that work (C3:
  * 2.1 of 72 ms per call).  The cache is keyed on (dV, Nt, model epoch, kind of counts) AND guarded by a content
  * fingerprint of 64 rows spread over the set (first and last included), taken at prepare time: a reusing call recomputes
- * it (one small kernel + a stream synchronisation, ~30 us) and returns PLDA_E_INVAL ("fingerprint") when the rows behind
- * the pointer have changed -- an in-place update, or an allocator that handed the address to another tensor -- instead of
- * scoring against the stale packing; that call also drops the cache.  Rows outside the sample are still the caller's
- * promise.  A different test side, a model change (fit, set_model, truncate, smooth) or plda_score_unprepare end the
- * reuse silently.  Test sides whose packed form would reach 4 GiB are refused (such calls are scored in column blocks,
- * each packed per call). */
+ * it (one small kernel + a stream synchronisation, ~30 us; once per call, not per block of a sharded call) and, when the
+ * rows behind the pointer have changed -- an in-place update, or an allocator that handed the address to another tensor
+ * -- treats the cache as MISSED: the rows are packed again and the call succeeds (round 5; rounds 3-4 returned
+ * PLDA_E_INVAL here, which failed legitimate calls whose new tensor sat at a recycled address).  Rows outside the sample
+ * are still the caller's promise.  A different test side, a model change (fit, set_model, truncate, smooth) or
+ * plda_score_unprepare end the reuse silently.  Test sides whose packed form would reach 4 GiB are refused (such calls
+ * are scored in column blocks, each packed per call).
+ * mixed_counts != 0 prepares the depth-2*Dout form, which later mixed-count calls then USE (no count pass, no wait);
+ * plda_score_prepare_counts_dev prepares the faster bucketed form for the distinct enrol counts the later calls will
+ * bring (host array `counts`, any order, duplicates allowed): calls whose counts are a subset reuse it, others repack. */
 int plda_score_prepare_dev(plda_handle *h, const double *dV, int64_t Nt, int32_t mixed_counts, int32_t n_uniform);
+int plda_score_prepare_counts_dev(plda_handle *h, const double *dV, int64_t Nt, const int32_t *counts, int32_t num_counts);
 int plda_score_unprepare(plda_handle *h);
 /* Kernel timing for roofline accounting: when enabled, every trials-GEMM launch is
  * bracketed by HIP events recorded on the stream it is launched on; plda_profile_read

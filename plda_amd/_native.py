@@ -64,6 +64,7 @@ SIGNATURES = {
     "plda_score_matrix": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
     "plda_score_matrix_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i64]),
     "plda_score_prepare_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32]),
+    "plda_score_prepare_counts_dev": (C.c_int, [_vp, _vp, _i64, _vp, _i32]),
     "plda_score_unprepare": (C.c_int, [_vp]),
     "plda_profile_enable": (C.c_int, [_vp, _i32]),
     "plda_profile_read": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64), _i32]),

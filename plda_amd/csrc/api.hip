@@ -49,10 +49,6 @@ int model_to_device(plda_handle *h) {
 }
 
 // implemented in score.hip / fit.hip
-int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
-                        const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
-                        float *dout, int64_t ld, bool reuse_packed_B = false);
-int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, bool mixed, int n_uniform);
 int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,
                        const int64_t *de, const int64_t *dt, int64_t P, const double *dzmean,
                        const double *dzstd, double *dout);
@@ -199,6 +195,7 @@ int plda_create(int device, plda_handle **out) {
     h->stream = h->own_stream;
     if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_PREP_VARIANT")) h->prep_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_MIXED_VARIANT")) h->mixed_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
@@ -233,8 +230,11 @@ int plda_destroy(plda_handle *h) {
     DevBuf *bufs[] = {&h->d_mean, &h->d_transform, &h->d_psi, &h->d_offset, &h->f_means, &h->f_counts,
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->fit_flag, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
-                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1]};
+                      &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1],
+                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work};
     for (DevBuf *b : bufs) b->release();
+    for (auto &t : h->bt4_tabs) t.tab.release();
+    if (h->cs_pin) (void)hipHostFree(h->cs_pin);
     for (auto &b : h->w) b.release();
     if (h->one_host) (void)hipHostFree(h->one_host);
     if (h->pin_model) (void)hipHostFree(h->pin_model);
@@ -606,7 +606,20 @@ int plda_score_prepare_dev(plda_handle *h, const double *dV, int64_t Nt, int32_t
     if (!h) return PLDA_E_INVAL;
     PLDA_LOCK(h);
     PLDA_TRY(set_device(h));
-    return score_prepare_device(h, dV, Nt, mixed_counts != 0, n_uniform);
+    return score_prepare_device(h, dV, Nt, mixed_counts != 0 ? 1 : 0, n_uniform, nullptr);
+  });
+}
+
+int plda_score_prepare_counts_dev(plda_handle *h, const double *dV, int64_t Nt, const int32_t *counts, int32_t num_counts) {
+  return guarded(h, "plda_score_prepare_counts_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    if (!counts || num_counts <= 0) return fail(h, PLDA_E_INVAL, "score_prepare_counts: empty count list");
+    CountSet cs;
+    score_count_set_host(counts, num_counts, &cs);     // (sorted, duplicates dropped; G = 0: outside what the bucketed form takes)
+    if (cs.G == 0) return score_prepare_device(h, dV, Nt, 1, 0, nullptr);
+    return score_prepare_device(h, dV, Nt, 2, 0, &cs);
   });
 }
 
@@ -627,6 +640,8 @@ static int score_matrix_host_serial(plda_handle *h, const double *U, const int32
                                     int64_t ld_out) {
   const int D = h->Dout;
   Tmp dV, dU, dN, dZm, dZs, dO;
+  CountSet cs;                                           // the distinct counts of ALL rows: every slab sees the same set
+  if (n_enrol) score_count_set_host(n_enrol, M, &cs);
   PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
   // row slabs so that the device score block stays <= 1 GiB
   int64_t slab = std::max<int64_t>(128, ((1ll << 30) / 4 / Nt) / 128 * 128);
@@ -646,7 +661,7 @@ static int score_matrix_host_serial(plda_handle *h, const double *U, const int32
     PLDA_TRY(score_matrix_device(h, dU.as<double>(), n_enrol ? dN.as<int32_t>() : nullptr, n_uniform, m,
                                  dV.as<double>(), Nt, (zmean && zstd) ? dZm.as<double>() : nullptr,
                                  (zmean && zstd) ? dZs.as<double>() : nullptr, dO.as<float>(), Nt,
-                                 /*reuse_packed_B=*/r0 > 0));   // the test side is packed once, not per slab
+                                 /*reuse_packed_B=*/r0 > 0, n_enrol ? &cs : nullptr));   // the test side is packed once, not per slab
     if (ld_out == Nt)
       PLDA_HIP(h, hipMemcpyAsync(out + r0 * ld_out, dO.p, (size_t)m * Nt * 4, hipMemcpyDeviceToHost, h->stream));
     else
@@ -686,6 +701,8 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
     PLDA_TRY(host_pipe(h, &hp));
     const int64_t slab = fit_rows >= 256 ? fit_rows / 128 * 128 : fit_rows;
     Tmp dV, dU, dN, dZm, dZs;
+    CountSet cs;                                         // the distinct counts of ALL rows, from the host array: no device pass
+    if (n_enrol) score_count_set_host(n_enrol, M, &cs);
     PLDA_TRY(upload(h, dV, V, (size_t)Nt * D * 8));
     PLDA_TRY(upload(h, dU, U, (size_t)M * D * 8));
     if (n_enrol) PLDA_TRY(upload(h, dN, n_enrol, (size_t)M * 4));
@@ -701,7 +718,7 @@ int plda_score_matrix(plda_handle *h, const double *U, const int32_t *n_enrol, i
       if (e != hipSuccess) { rc = hip_fail(h, e, "begin_slab", __FILE__, __LINE__); break; }
       rc = score_matrix_device(h, dU.as<double>() + r0 * D, n_enrol ? dN.as<int32_t>() + r0 : nullptr, n_uniform, m,
                                dV.as<double>(), Nt, zn ? dZm.as<double>() + r0 : nullptr, zn ? dZs.as<double>() + r0 : nullptr,
-                               dO, Nt, /*reuse_packed_B=*/r0 > 0);
+                               dO, Nt, /*reuse_packed_B=*/r0 > 0, n_enrol ? &cs : nullptr);
       if (rc != PLDA_OK) break;
       e = hp->ship_slab(h->stream, i, dO, (size_t)m * Nt * 4, reinterpret_cast<char *>(out + r0 * ld_out), (size_t)ld_out * 4,
                         (size_t)Nt * 4, (size_t)m);

@@ -37,9 +37,6 @@
 
 namespace plda {
 
-int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
-                        const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
-                        float *dout, int64_t ld, bool reuse_packed_B);
 int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
                        const double *dmodels, int64_t M, double *dmean, double *dstd);
 int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
@@ -670,6 +667,10 @@ int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t 
     return fail(h, PLDA_E_INVAL, "score_matrix_sharded: gathering a compact slab needs ld_local == ld_full");
   bool packedB = false;
   int64_t lo = 0;                                               // rows of the compact slab written so far
+  // mixed counts: the distinct counts of ALL M rows (replicated on every rank: every rank finds the same set), found once
+  // per call -- one small device pass and one wait for the stream -- not per super-block
+  CountSet cs;
+  if (dn) PLDA_TRY(score_count_set_device(h, dn, M, &cs));
   for (int64_t s = 0; s < p.nsuper; ++s) {
     int64_t r0, cnt;
     p.rows(s, me, M, r0, cnt);
@@ -677,7 +678,7 @@ int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t 
     const int64_t ldm = dlocal ? ld_local : ld_full;
     if (cnt > 0) {
       PLDA_TRY(score_matrix_device(h, dU + r0 * D, dn ? dn + r0 : nullptr, n_uniform, cnt, dV, Nt, zn ? dzmean + r0 : nullptr,
-                                   zn ? dzstd + r0 : nullptr, mine, ldm, packedB));
+                                   zn ? dzstd + r0 : nullptr, mine, ldm, packedB, dn ? &cs : nullptr));
       packedB = true;                                          // the test side is packed once
       lo += cnt;
     }

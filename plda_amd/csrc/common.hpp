@@ -42,6 +42,16 @@ struct Tmp {
 
 namespace plda { struct HostPipe; }
 
+namespace plda {
+// The distinct enrol counts of a mixed-count trials call (score.hip, "bucketed" path): bucket g <-> vals[g], ascending.
+// Passed BY VALUE to the kernels that need it (260 bytes of kernel arguments; no device-side table to keep coherent).
+constexpr int CS_MAX = 64;        // more distinct counts than this: the depth-2D form
+constexpr int CS_NMAX = 4095;     // a count above this: the depth-2D form
+struct CountSet { int G = 0; int32_t vals[CS_MAX] = {}; };
+// One (btM, btN) tile grid of trials_gemm_bt4_kernel: per-XCD queues over a table of tiles (score.hip: bt4_schedule)
+struct Bt4Table { int btM = -1, btN = -1; DevBuf tab; int qbase[8] = {}, qlen[8] = {}; unsigned init[8] = {}; uint64_t used = 0; };
+}  // namespace plda
+
 struct plda_handle {
   std::recursive_mutex mu;   // taken by every C-ABI entry point (api.hip)
   int device = 0;
@@ -94,8 +104,12 @@ struct plda_handle {
   int64_t last_M = 0, last_Nt = 0;
   const char *last_kernel = nullptr;   // the trials-GEMM kernel of the last score_matrix launch (static string)
   int last_k = 0;
-  // a test side packed ahead of time (plda_score_prepare_dev): reused while pointer, size, model and count kind match
-  bool prep_valid = false, prep_mixed = false;
+  // a test side packed ahead of time (plda_score_prepare_dev / _counts_dev): reused while pointer, size, model and count
+  // kind match.  prep_kind: 0 uniform count (prep_nuniform), 1 mixed counts in the depth-2D form, 2 mixed counts in the
+  // bucketed form for the count set prep_counts
+  bool prep_valid = false;
+  int prep_kind = 0;
+  plda::CountSet prep_counts;
   const double *prep_dV = nullptr;
   int64_t prep_Nt = 0;
   uint64_t prep_epoch = 0;
@@ -116,6 +130,7 @@ struct plda_handle {
   int sort_variant = 0;        // PLDA_SORT_VARIANT=1: fit groups the rows by the radix sort always (0: by counting where the tables fit)
   int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass; 2: no tail launch (A/B arms)
   int gemm_variant = 0;
+  int mixed_variant = 0;   // PLDA_MIXED_VARIANT=1: mixed enrol counts always in the depth-2D form [A1 | A2] x [V | V*V] (A/B arm of the bucketed form)
   int prep_variant = 0;    // PLDA_PREP_VARIANT=1: scoring prep as separate bias / pack / pair kernels (A/B arm of prep_side_kernel)
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
@@ -127,9 +142,12 @@ struct plda_handle {
   bool bt4_attr_set = false;
   // tile schedule of the one-wave-per-SIMD trials GEMM (score.hip: bt4_schedule): per XCD a queue of tiles, consumed
   // through one device-scope counter per queue; the table is rebuilt when the tile grid changes
-  plda::DevBuf bt4_tab, bt4_cnt, bt4_fringe;   // (bt4_fringe: 256 x 256 scratch slots of the tiles that cross the matrix edge)
-  int bt4_tab_m = -1, bt4_tab_n = -1;
-  int bt4_qbase[8] = {}, bt4_qlen[8] = {};
+  plda::DevBuf bt4_cnt, bt4_fringe;   // (bt4_fringe: 256 x 256 scratch slots of the tiles that cross the matrix edge)
+  plda::Bt4Table bt4_tabs[6];         // the last few tile grids (sharded scoring alternates full blocks and a ragged tail)
+  uint64_t bt4_clock = 0;
+  // distinct enrol counts of a mixed-count call: presence bytes + result on the device, pinned landing area
+  plda::DevBuf cs_work;
+  void *cs_pin = nullptr;
   bool timeline_valid = false;   // `timeline` holds the stamps of a PLDA_GEMM_VARIANT=31 launch
   plda::DevBuf timeline;
 
@@ -301,6 +319,13 @@ int fit_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_
                int64_t K, int iters);
 
 // ---- score.hip ----
+// cs: the distinct enrol counts of the caller's whole call (mixed counts; nullptr: found from dn on the device)
+int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
+                        const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
+                        float *dout, int64_t ld, bool reuse_packed_B = false, const CountSet *cs = nullptr);
+void score_count_set_host(const int32_t *n, int64_t M, CountSet *cs);
+int score_count_set_device(plda_handle *h, const int32_t *dn, int64_t M, CountSet *cs);
+int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, int kind, int n_uniform, const CountSet *cs);
 int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din,
                           const int32_t *dn, int n_uniform, double *dout);
 

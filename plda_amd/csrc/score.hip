@@ -76,14 +76,14 @@ __global__ void enrol_bias_kernel(const double *__restrict__ U, const int32_t *_
 // Uniform enrol count: the per-dimension coefficients do not depend on the row, so they are
 // computed once per call (one workgroup): w_d = c^2/var, g_d = 1/var - 1/(1+psi) and
 // L = sum_d [log var - log(1+psi)]; the bias kernels then are plain weighted sums of squares.
-__global__ __launch_bounds__(256) void uniform_coef_kernel(const double *__restrict__ psi, int D, int n_uniform,
-                                                           double *__restrict__ coef /*[2*D + 1]: w, g, L*/) {
+// Mixed counts in the bucketed form: one workgroup per DISTINCT count, tables back to back.
+__device__ __forceinline__ void count_coef(const double *__restrict__ psi, int D, int n, double *__restrict__ coef /*[2*D + 1]: w, g, L*/) {
   __shared__ double red[256];
   double acc = 0.0;
   for (int d = threadIdx.x; d < D; d += 256) {
     double c, var;
     const double p = psi[d];
-    llr_coef((double)n_uniform, p, c, var);
+    llr_coef((double)n, p, c, var);
     coef[d] = c * c / var;
     coef[D + d] = 1.0 / var - 1.0 / (1.0 + p);
     acc += log(var) - log(1.0 + p);
@@ -95,6 +95,12 @@ __global__ __launch_bounds__(256) void uniform_coef_kernel(const double *__restr
     __syncthreads();
   }
   if (threadIdx.x == 0) coef[2 * D] = red[0];
+}
+__global__ __launch_bounds__(256) void uniform_coef_kernel(const double *__restrict__ psi, int D, int n_uniform, double *__restrict__ coef) {
+  count_coef(psi, D, n_uniform, coef);
+}
+__global__ __launch_bounds__(256) void bucket_coef_kernel(const double *__restrict__ psi, int D, const CountSet cs, double *__restrict__ coef /*[G][2*D + 1]*/) {
+  count_coef(psi, D, cs.vals[blockIdx.x], coef + (size_t)blockIdx.x * (2 * D + 1));
 }
 
 // out[row] = scale_row * (-1/2) * (L + sum_d w_d x_d^2) (+ z-norm folding), one wave per row
@@ -304,6 +310,206 @@ __global__ __launch_bounds__(256) void prep_side_kernel(const double *__restrict
       if (SIDE == 0) { rscale[row] = (float)sc; pair[row] = make_float2((float)r, (float)sc); }
       else pair[row] = make_float2(1.f, (float)r);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Mixed enrol counts at GEMM depth D + G - 1 (round 5; SURVEY.md Appendix A.5 collapses the second operand half only
+// when ALL counts are equal, and rounds 1-4 followed that: any count array -> depth 2 D).  A2_i = -1/2 (1/var - 1/(1+psi))
+// depends on the row only through n_i, so with the G distinct counts n_(0) < n_(1) < ... ("buckets")
+//     S_ij = A1_i . v_j + r_i + q_(b_i)[j],      q_g[j] = -1/2 sum_d (1/var_d(n_(g)) - 1/(1+psi_d)) v_jd^2
+// -- one column-bias vector per DISTINCT count.  Bucket 0's rides where the uniform path keeps its q_j (the rank-2 bias
+// MFMA: r'_i x 1 + s_i x q_0[j]); the others enter as DIFFERENCES dq_g = q_g - q_0 behind the D columns of the
+// contraction: the enrol side carries s_i x onehot(b_i - 1), the test side dq_1 .. dq_(G-1), padded to whole 8-k steps.
+// No row permutation, no new epilogue, the GEMM kernels are untouched; G = 1 IS the uniform path.  BASELINE C4
+// (n in 1..5, D = 256): depth 264 instead of 512.  Counts above CS_NMAX, more than CS_MAX distinct ones, or G - 1 > D / 2
+// fall back to the depth-2D form (pack_kernel<1> / <3>), which stays as the A/B arm (PLDA_MIXED_VARIANT=1).
+// Reference: Plda::LogLikelihoodRatio through MPlda_score, /root/reference/src/pldamodule.cpp:258-277.
+// ------------------------------------------------------------------------------------
+struct CountSetDev { int G; int overflow; int32_t vals[CS_MAX]; };
+
+__global__ void count_presence_kernel(const int32_t *__restrict__ n, int64_t M, unsigned char *__restrict__ present /*[CS_NMAX + 1]*/,
+                                      int *__restrict__ flags) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = n[i];
+    if (v >= 1 && v <= CS_NMAX) present[v] = 1;     // (racing stores of the same byte value)
+    else flags[0] = 1;
+  }
+}
+
+// presence bytes -> ascending list of the distinct counts (one workgroup; lane l of wave 0 owns counts [64 l, 64 l + 64))
+__global__ __launch_bounds__(256) void count_compact_kernel(const unsigned char *__restrict__ present, const int *__restrict__ flags,
+                                                            CountSetDev *__restrict__ out) {
+  __shared__ unsigned char pr[CS_NMAX + 1];
+  for (int i = threadIdx.x; i <= CS_NMAX; i += 256) pr[i] = present[i];
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  int cnt = 0;
+  for (int k = 0; k < 64; ++k) cnt += pr[lane * 64 + k] ? 1 : 0;
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int total = __shfl(incl, 63);
+  int pos = incl - cnt;
+  for (int k = 0; k < 64; ++k)
+    if (pr[lane * 64 + k]) { if (pos < CS_MAX) out->vals[pos] = lane * 64 + k; ++pos; }
+  if (lane == 0) { out->G = total; out->overflow = (flags[0] != 0 || total > CS_MAX) ? 1 : 0; }
+}
+
+// enrol side of the bucketed form, one pass over the fp64 rows (the structure of prep_side_kernel<0>; the coefficients
+// are the row's own): A1 = c u / var (* s_i), r'_i, s_i, rpair, and the KQx extra k-quad planes s_i x onehot(b_i - 1)
+__global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *__restrict__ X, const int32_t *__restrict__ n_arr, const CountSet cs,
+                                                                 const double *__restrict__ coefG /*[G][2 D + 1]*/, const double *__restrict__ psi, int D,
+                                                                 int64_t R, int64_t Rpad, int KQm, int KQx, const double *__restrict__ zmean,
+                                                                 const double *__restrict__ zstd, float *__restrict__ P, float *__restrict__ bias,
+                                                                 float *__restrict__ rscale, float2 *__restrict__ pair) {
+  __shared__ float tile[2][64][65];
+  __shared__ int sb[64];
+  __shared__ float ss[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int64_t wrow0 = row0 + wave * 16;
+  const int nchunk = (KQm * 4 + 63) >> 6;
+  const bool zn = zmean && zstd;
+  const int S = 2 * D + 1;
+  float rsf[16];
+  double nn[16], Lr[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t row = wrow0 + j;
+    rsf[j] = 1.f;
+    if (zn && row < R) { const double sd = zstd[row]; rsf[j] = (float)(sd != 0.0 ? 1.0 / sd : 1.0); }
+    const int n = row < R ? n_arr[row] : cs.vals[0];
+    int b = 0;
+    for (int g = 1; g < cs.G; ++g) b = cs.vals[g] == n ? g : b;
+    nn[j] = (double)n;
+    Lr[j] = coefG[(size_t)b * S + 2 * D];
+    if (lane == 0) { sb[wave * 16 + j] = row < R ? b : 0; ss[wave * 16 + j] = rsf[j]; }
+  }
+  double acc[16], xc[16], xn[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { acc[j] = 0.0; xn[j] = 0.0; }
+  auto fetch = [&](int c, double (&x)[16]) {
+    const int d = c * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t row = wrow0 + j;
+      x[j] = (d < D && row < R) ? X[row * (int64_t)D + d] : 0.0;
+    }
+  };
+  fetch(0, xn);
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xc[j] = xn[j];
+    if (c + 1 < nchunk) fetch(c + 1, xn);
+    const int d = c * 64 + lane;
+    const bool dv = d < D;
+    const double p = dv ? psi[d] : 0.0;
+    float(*const tl)[65] = tile[c & 1];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double x = xc[j];
+      float val = 0.f;
+      if (dv && wrow0 + j < R) {
+        double cc, var;
+        llr_coef(nn[j], p, cc, var);
+        acc[j] += (cc * cc / var) * x * x;
+        double v = cc * x / var;
+        if (zn) v *= (double)rsf[j];
+        val = (float)v;
+      }
+      tl[lane][wave * 16 + j] = val;
+    }
+    __syncthreads();
+    {
+      const int r = threadIdx.x & 63;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int q = (threadIdx.x >> 6) + pass * 4;   // k-quad of the chunk, 0..15
+        const int kq = c * 16 + q;
+        if (kq < KQm) {
+          f32x4 v;
+          v.x = tl[4 * q + 0][r];
+          v.y = tl[4 * q + 1][r];
+          v.z = tl[4 * q + 2][r];
+          v.w = tl[4 * q + 3][r];
+          reinterpret_cast<f32x4 *>(P)[(int64_t)kq * Rpad + row0 + r] = v;
+        }
+      }
+    }
+  }
+  // (sb / ss were written before the loop's first barrier; nchunk >= 1)
+  {
+    const int r = threadIdx.x & 63;
+    const int pcol = sb[r] - 1;
+    for (int e = threadIdx.x >> 6; e < KQx; e += 4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pcol >= 0 && (pcol >> 2) == e) v[pcol & 3] = ss[r];
+      reinterpret_cast<f32x4 *>(P)[(int64_t)(KQm + e) * Rpad + row0 + r] = v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double a = acc[j];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    const int64_t row = wrow0 + j;
+    if (lane == 0 && row < R) {
+      double r = -0.5 * (a + Lr[j]), sc = 1.0;
+      if (zn) {
+        const double sd = zstd[row];
+        if (sd != 0.0) { sc = 1.0 / sd; r = (r - zmean[row]) * sc; }
+      }
+      bias[row] = (float)r;
+      rscale[row] = (float)sc;
+      pair[row] = make_float2((float)r, (float)sc);
+    }
+  }
+}
+
+// test side of the bucketed form, the extra planes: dq_g[j] = -1/2 sum_d (g_gd - g_0d) v_jd^2 for g = 1 .. G - 1 (fp64, rounded
+// once), zero beyond.  The D main planes, q_0 and cpair come from prep_side_kernel<1> with bucket 0's coefficients.  A
+// second read of the rows (L2 mostly): Nt D 8 B against the GEMM's Nt M (D + G) flop.
+__global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__restrict__ V, const double *__restrict__ coefG, int G, int D,
+                                                                int64_t R, int64_t Rpad, int KQm, int KQx, float *__restrict__ P) {
+  __shared__ float q[CS_MAX][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < CS_MAX * 65; i += 256) (&q[0][0])[i] = 0.f;
+  __syncthreads();
+  const int S = 2 * D + 1;
+  for (int j = 0; j < 16; ++j) {
+    const int64_t row = row0 + wave * 16 + j;
+    if (row >= R) break;
+    const double *v = V + row * (int64_t)D;
+    for (int g0 = 1; g0 < G; g0 += 4) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const double *c0 = coefG + (size_t)g0 * S + D;
+      const bool h1 = g0 + 1 < G, h2 = g0 + 2 < G, h3 = g0 + 3 < G;
+      for (int d = lane; d < D; d += 64) {
+        const double x = v[d], x2 = x * x, gb = coefG[D + d];
+        a0 += (c0[d] - gb) * x2;
+        if (h1) a1 += (c0[S + d] - gb) * x2;
+        if (h2) a2 += (c0[2 * S + d] - gb) * x2;
+        if (h3) a3 += (c0[3 * S + d] - gb) * x2;
+      }
+      a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2); a3 = wave_sum_f64(a3);
+      if (lane == 0) {
+        q[g0 - 1][wave * 16 + j] = (float)(-0.5 * a0);
+        if (h1) q[g0][wave * 16 + j] = (float)(-0.5 * a1);
+        if (h2) q[g0 + 1][wave * 16 + j] = (float)(-0.5 * a2);
+        if (h3) q[g0 + 2][wave * 16 + j] = (float)(-0.5 * a3);
+      }
+    }
+  }
+  __syncthreads();
+  const int r = threadIdx.x & 63;
+  for (int e = threadIdx.x >> 6; e < KQx; e += 4) {
+    f32x4 v;
+    v.x = q[4 * e + 0][r];
+    v.y = q[4 * e + 1][r];
+    v.z = q[4 * e + 2][r];
+    v.w = q[4 * e + 3][r];
+    reinterpret_cast<f32x4 *>(P)[(int64_t)(KQm + e) * Rpad + row0 + r] = v;
   }
 }
 
@@ -937,33 +1143,58 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 // this load (measured per XCD with s_memtime / s_memrealtime stamps, scripts/gemm_clock.py: 2.30 against 2.35 GHz, odd
 // against even XCDs), and awkward grids leave up to 5 % more tiles with some XCDs than with others; with equal static
 // shares the kernel ends 1.4 - 2.4 ms after its average workgroup (of 28 ms at C2).
-static int bt4_schedule(plda_handle *h, int btM, int btN) {
+// Round 5: the table is built ON THE DEVICE (one wave per queue, in the order above) from per-queue offsets the host gets
+// by walking the patches -- no host copy and no stream synchronisation, so a change of the tile grid does not stall the
+// host (the sharded form alternates full blocks and a ragged tail; a server scores varying M) -- and the last few grids
+// keep their tables (h->bt4_tabs, least recently used replaced).  The queue counters are (re)set by a one-wave kernel
+// in front of every launch.
+struct Bt4Init { unsigned v[8]; };
+__global__ __launch_bounds__(64) void bt4_table_kernel(int2 *__restrict__ tab, int btM, int btN, int pN, int64_t npatch, const Bt4Queues qs) {
+  const int x = blockIdx.x, lane = threadIdx.x;
+  int off = qs.qbase[x];
+  for (int64_t p = x; p < npatch; p += 8) {
+    const int pm = (int)(p / pN), pn = (int)(p % pN);
+    const int tm = pm * BPR + lane / BPC, tn = pn * BPC + lane % BPC;
+    const bool ok = lane < BPR * BPC && tm < btM && tn < btN;
+    const unsigned long long mask = __ballot(ok);
+    if (ok) tab[off + __popcll(mask & ((1ull << lane) - 1ull))] = make_int2(tm * 256, tn * 256);
+    off += __popcll(mask);
+  }
+}
+__global__ void bt4_reset_kernel(unsigned *__restrict__ cnt, const Bt4Init init) {
+  if (threadIdx.x < 8) cnt[threadIdx.x] = init.v[threadIdx.x];
+}
+
+static int bt4_schedule(plda_handle *h, int btM, int btN, Bt4Table **out) {
   PLDA_HIP(h, h->bt4_cnt.reserve(32 * sizeof(unsigned)));
-  if (h->bt4_tab_m == btM && h->bt4_tab_n == btN) return PLDA_OK;
+  Bt4Table *lru = &h->bt4_tabs[0];
+  for (auto &t : h->bt4_tabs) {
+    if (t.btM == btM && t.btN == btN) { t.used = ++h->bt4_clock; *out = &t; return PLDA_OK; }
+    if (t.used < lru->used) lru = &t;
+  }
+  Bt4Table &t = *lru;
   const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
-  std::vector<int> tab;
-  tab.reserve((size_t)btM * btN * 2);
-  unsigned init[32] = {};
+  const int64_t npatch = (int64_t)pM * pN;
+  int64_t total = 0;
+  Bt4Queues qs;
   for (int x = 0; x < 8; ++x) {
-    h->bt4_qbase[x] = (int)(tab.size() / 2);
-    for (int64_t p = x; p < (int64_t)pM * pN; p += 8) {
+    t.qbase[x] = (int)total;
+    for (int64_t p = x; p < npatch; p += 8) {
       const int pm = (int)(p / pN), pn = (int)(p % pN);
-      for (int lb = 0; lb < BPR * BPC; ++lb) {
-        const int tm = pm * BPR + lb / BPC, tn = pn * BPC + lb % BPC;
-        if (tm < btM && tn < btN) { tab.push_back(tm * 256); tab.push_back(tn * 256); }
-      }
+      total += (int64_t)std::min(BPR, btM - pm * BPR) * std::min(BPC, btN - pn * BPC);
     }
-    h->bt4_qlen[x] = (int)(tab.size() / 2) - h->bt4_qbase[x];
+    t.qlen[x] = (int)total - t.qbase[x];
     // a workgroup's FIRST tile is its own position in its XCD's queue (no round trip before the first DMA): the
     // counters start behind those
-    init[16 + x] = (unsigned)std::min(32, h->bt4_qlen[x]);
+    t.init[x] = (unsigned)std::min(32, t.qlen[x]);
+    qs.qbase[x] = t.qbase[x]; qs.qlen[x] = t.qlen[x];
   }
-  PLDA_HIP(h, h->bt4_tab.reserve(std::max<size_t>(tab.size(), 2) * sizeof(int)));
-  // (synchronous copies from stack / vector memory: once per tile grid)
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
-  PLDA_HIP(h, hipMemcpy(h->bt4_tab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-  PLDA_HIP(h, hipMemcpy(h->bt4_cnt.p, init, sizeof(init), hipMemcpyHostToDevice));
-  h->bt4_tab_m = btM; h->bt4_tab_n = btN;
+  t.btM = t.btN = -1;
+  PLDA_HIP(h, t.tab.reserve(std::max<size_t>((size_t)total, 1) * sizeof(int2)));
+  bt4_table_kernel<<<8, 64, 0, h->stream>>>(t.tab.as<int2>(), btM, btN, pN, npatch, qs);
+  PLDA_LAUNCH_CHECK(h);
+  t.btM = btM; t.btN = btN; t.used = ++h->bt4_clock;
+  *out = &t;
   return PLDA_OK;
 }
 
@@ -1025,22 +1256,39 @@ __global__ void score_pairs_kernel(const double *__restrict__ U, const int32_t *
 struct TrialOperands {
   int64_t Mpad, Npad;
   int KQ, Kg;   // padded GEMM depth (multiple of 8) and its k-quad count
-  int Kg_alg;   // algorithmic depth: Dout (uniform n) or 2 Dout (mixed n)
-  bool mixed;
+  int Kg_alg;   // algorithmic depth: Dout (uniform n), Dout + G - 1 (mixed n, bucketed) or 2 Dout (mixed n, depth-2D form)
+  int kind;     // 0 uniform count, 1 mixed counts in the depth-2D form, 2 mixed counts bucketed by distinct count
+  bool mixed;   // kind == 1
 };
 
+// does the bucketed form apply (and pay) for this set of distinct counts?  cs.G == 0: the set is unknown / unusable
+static inline bool buckets_usable(const plda_handle *h, const CountSet *cs) {
+  if (!cs || h->mixed_variant == 1) return false;
+  const int Dp = (int)round_up(h->Dout, 8);
+  return cs->G >= 2 && cs->G <= CS_MAX && cs->G - 1 <= std::max(Dp / 2, 8);
+}
+// k-quad planes of a packed operand (without the 8 spare ones)
+static inline int64_t operand_kq(const plda_handle *h, bool has_counts, const CountSet *cs) {
+  const int64_t Dp = round_up(h->Dout, 8);
+  if (has_counts && buckets_usable(h, cs)) return (Dp + round_up(cs->G - 1, 8)) / 4;
+  return std::max<int64_t>((has_counts ? 2 : 1) * Dp, 16) / 4;
+}
+
 // doA / doB: (re)build the enrol side (packed A, row biases, row scales) / the test side (packed B,
-// column biases); a blocked call packs each side once per block of its own dimension
+// column biases); a blocked call packs each side once per block of its own dimension.
+// cs: the distinct enrol counts of the whole call when dn != nullptr (nullptr / unusable: the depth-2D form)
 static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform,
                             int64_t M, const double *dV, int64_t Nt, const double *dzmean,
-                            const double *dzstd, TrialOperands &op, bool doA = true, bool doB = true) {
+                            const double *dzstd, TrialOperands &op, bool doA = true, bool doB = true,
+                            const CountSet *cs = nullptr) {
   TraceScope ts(h, "score.pack_operands");
   const int D = h->Dout;
   const int Dp = (int)round_up(D, 8);
   if (doB) h->prep_valid = false;        // the packed test side is being overwritten (plda_score_prepare_dev re-marks its own)
-  op.mixed = dn != nullptr;
-  op.Kg = std::max(op.mixed ? 2 * Dp : Dp, 16);   // >= two 8-k steps: the 256 x 256 kernel runs them in pairs
-  op.Kg_alg = op.mixed ? 2 * D : D;
+  op.kind = !dn ? 0 : (buckets_usable(h, cs) ? 2 : 1);
+  op.mixed = op.kind == 1;
+  op.Kg = (int)operand_kq(h, dn != nullptr, cs) * 4;   // >= two 8-k steps: the 256 x 256 kernel runs them in pairs
+  op.Kg_alg = op.kind == 2 ? D + cs->G - 1 : (op.mixed ? 2 * D : D);
   op.KQ = op.Kg / 4;
   op.Mpad = round_up(M, 256);   // 256: the big-tile kernel's block tile (the 128 kernel tolerates it)
   op.Npad = round_up(Nt, 256);
@@ -1052,6 +1300,25 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   PLDA_HIP(h, h->s_cbias.reserve((size_t)op.Npad * 4));
   PLDA_HIP(h, h->s_rpair.reserve((size_t)op.Mpad * 8));
   PLDA_HIP(h, h->s_cpair.reserve((size_t)op.Npad * 8));
+  if (op.kind == 2) {
+    // bucketed mixed counts: per-bucket coefficient tables, then one pass over each side (+ the test side's dq planes)
+    const int G = cs->G, KQm = Dp / 4, KQx = op.KQ - KQm;
+    PLDA_HIP(h, h->w[11].reserve((size_t)G * (2 * D + 1) * 8));
+    double *coefG = h->w[11].as<double>();
+    bucket_coef_kernel<<<G, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, *cs, coefG);
+    if (doA)
+      prep_enrol_buckets_kernel<<<(unsigned)(op.Mpad / 64), 256, 0, h->stream>>>(
+          dU, dn, *cs, coefG, h->d_psi.as<double>(), D, M, op.Mpad, KQm, KQx, dzmean, dzstd, h->s_Apk.as<float>(),
+          h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+    if (doB) {
+      prep_side_kernel<1><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
+          dV, coefG + D, coefG + 2 * D, 0, h->d_psi.as<double>(), D, Nt, op.Npad, KQm, nullptr, nullptr, h->s_Bpk.as<float>(),
+          h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+      prep_test_buckets_kernel<<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(dV, coefG, G, D, Nt, op.Npad, KQm, KQx, h->s_Bpk.as<float>());
+    }
+    PLDA_LAUNCH_CHECK(h);
+    return PLDA_OK;
+  }
   const double *psi = h->d_psi.as<double>();
   const bool zn = dzmean && dzstd;
   const int wpb = 4;
@@ -1157,15 +1424,20 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     if (use_bt4) {
       const int sbase = nsteps / nst, fs = sbase + (nsteps - sbase * nst > 0 ? 1 : 0);
       h->last_kernel = "trials_gemm_bt4_kernel";
-      PLDA_TRY(bt4_schedule(h, btM, btN));
+      Bt4Table *tb = nullptr;
+      PLDA_TRY(bt4_schedule(h, btM, btN, &tb));
       // the queues' counters start behind every workgroup's first tile
-      PLDA_HIP(h, hipMemcpyAsync(h->bt4_cnt.p, h->bt4_cnt.as<unsigned>() + 16, 8 * sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
+      {
+        Bt4Init bi;
+        for (int x = 0; x < 8; ++x) bi.v[x] = tb->init[x];
+        bt4_reset_kernel<<<1, 64, 0, h->stream>>>(h->bt4_cnt.as<unsigned>(), bi);
+      }
       // tiles that cross the matrix edge are written whole into scratch slots and copied out behind the launch
       const int rag_m = (M & 255) != 0, rag_n = (Nt & 255) != 0;
       const int fslots = (rag_m || rag_n) ? btM + btN : 0;
       PLDA_HIP(h, h->bt4_fringe.reserve(std::max<size_t>((size_t)fslots * 65536 * 4, 256)));
       Bt4Queues qs;
-      for (int x = 0; x < 8; ++x) { qs.qbase[x] = h->bt4_qbase[x]; qs.qlen[x] = h->bt4_qlen[x]; }
+      for (int x = 0; x < 8; ++x) { qs.qbase[x] = tb->qbase[x]; qs.qlen[x] = tb->qlen[x]; }
       if (!h->bt4_attr_set) {
         const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 0>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 0>),
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 1>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 1>),
@@ -1178,7 +1450,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
 #define BT4L(FS_, MODE_, DBG_)                                                                            \
   trials_gemm_bt4_kernel<FS_, MODE_><<<256, 256, BT4_LDS, h->stream>>>(                                   \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
-      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, (int)M, (int)Nt, h->bt4_fringe.as<float>(), h->bt4_tab.as<int2>(), h->bt4_cnt.as<unsigned>(), qs, DBG_)
+      h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, (int)M, (int)Nt, h->bt4_fringe.as<float>(), tb->tab.as<int2>(), h->bt4_cnt.as<unsigned>(), qs, DBG_)
       if (h->gemm_variant == 41) {
         PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
         PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
@@ -1312,37 +1584,109 @@ static int test_side_fingerprint(plda_handle *h, const double *dV, int64_t Nt, u
   return PLDA_OK;
 }
 
+// ---- the distinct enrol counts of a call ----
+// host array: no device work at all
+void score_count_set_host(const int32_t *n, int64_t M, CountSet *cs) {
+  cs->G = 0;
+  std::vector<unsigned char> present(CS_NMAX + 1, 0);
+  for (int64_t i = 0; i < M; ++i) {
+    const int v = n[i];
+    if (v < 1 || v > CS_NMAX) return;          // unusable: the depth-2D form
+    present[v] = 1;
+  }
+  int G = 0;
+  for (int v = 1; v <= CS_NMAX; ++v)
+    if (present[v]) { if (G == CS_MAX) { cs->G = 0; return; } cs->vals[G++] = v; }
+  cs->G = G;
+}
+// device array: two small kernels, 264 bytes to a pinned landing area and ONE wait for the handle's stream (the host has
+// to know G before it can size the operands; callers that know the counts pass them instead: plda_score_matrix does).
+int score_count_set_device(plda_handle *h, const int32_t *dn, int64_t M, CountSet *cs) {
+  cs->G = 0;
+  if (h->mixed_variant == 1) return PLDA_OK;
+  TraceScope ts(h, "score.count_set");
+  const size_t off_flags = round_up(CS_NMAX + 1, 16), off_out = off_flags + 16;
+  PLDA_HIP(h, h->cs_work.reserve(off_out + sizeof(CountSetDev)));
+  if (!h->cs_pin) PLDA_HIP(h, hipHostMalloc(&h->cs_pin, sizeof(CountSetDev), hipHostMallocDefault));
+  unsigned char *present = h->cs_work.as<unsigned char>();
+  int *flags = reinterpret_cast<int *>(present + off_flags);
+  CountSetDev *dres = reinterpret_cast<CountSetDev *>(present + off_out);
+  PLDA_HIP(h, hipMemsetAsync(present, 0, off_out, h->stream));
+  count_presence_kernel<<<(unsigned)std::min<int64_t>(ceil_div(M, 256), 1024), 256, 0, h->stream>>>(dn, M, present, flags);
+  count_compact_kernel<<<1, 256, 0, h->stream>>>(present, flags, dres);
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_HIP(h, hipMemcpyAsync(h->cs_pin, dres, sizeof(CountSetDev), hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  const CountSetDev *r = static_cast<const CountSetDev *>(h->cs_pin);
+  if (r->overflow || r->G < 1 || r->G > CS_MAX) return PLDA_OK;
+  cs->G = r->G;
+  for (int g = 0; g < r->G; ++g) cs->vals[g] = r->vals[g];
+  return PLDA_OK;
+}
+static bool count_subset(const CountSet &a, const CountSet &b) {   // a's counts all in b (both ascending)
+  int j = 0;
+  for (int i = 0; i < a.G; ++i) {
+    while (j < b.G && b.vals[j] < a.vals[i]) ++j;
+    if (j == b.G || b.vals[j] != a.vals[i]) return false;
+  }
+  return true;
+}
+
 // reuse_packed_B: the test side (dV, Nt, enrol-count kind) is the one the previous call on this handle
 // packed -- the host entry point scores one test set against successive row slabs
+// cs_in: the distinct enrol counts of the CALLER's whole call (host slabs, sharded super-blocks: every slab must see the
+// same set, the test side is packed once); nullptr: found here from dn
 int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
                         const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
-                        float *dout, int64_t ld, bool reuse_packed_B) {
+                        float *dout, int64_t ld, bool reuse_packed_B, const CountSet *cs_in) {
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_matrix: model not fitted");
   if (M <= 0 || Nt <= 0) return PLDA_OK;
   if (!dU || !dV || !dout || ld < Nt) return fail(h, PLDA_E_INVAL, "score_matrix: bad argument");
   if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_matrix: n_uniform must be > 0 when n_enrol is NULL");
+  const int D = h->Dout;
+  const bool zn = dzmean && dzstd;
+  // mixed counts: the set of distinct counts decides the form of the operands
+  CountSet cs_local, cs_use;
+  const CountSet *cs = nullptr;
+  if (dn) {
+    // a prepared depth-2D test side is what the caller asked to reuse: no count set needed
+    const bool prep2d = h->prep_valid && h->prep_kind == 1 && h->prep_dV == dV && h->prep_Nt == Nt && h->prep_epoch == h->model_epoch;
+    if (cs_in) cs = cs_in;
+    else if (!prep2d) { PLDA_TRY(score_count_set_device(h, dn, M, &cs_local)); cs = &cs_local; }
+    if (cs && cs->G == 1) { n_uniform = cs->vals[0]; dn = nullptr; cs = nullptr; }   // one distinct count IS the uniform path
+  }
+  // a test side packed ahead of time by plda_score_prepare[_counts]_dev (same rows, same model, a matching kind of enrol
+  // counts).  (Also consulted by the later slabs of a blocked call -- reuse_packed_B already set -- so that their enrol
+  // side is packed in the form the first slab found on the test side.)
+  bool try_prep = false;
+  if (h->prep_valid && h->prep_dV == dV && h->prep_Nt == Nt && h->prep_epoch == h->model_epoch) {
+    if (!dn) try_prep = h->prep_kind == 0 && h->prep_nuniform == n_uniform;
+    else if (h->prep_kind == 1) { try_prep = true; cs = nullptr; }
+    else if (h->prep_kind == 2 && cs && buckets_usable(h, cs) && count_subset(*cs, h->prep_counts)) { try_prep = true; cs_use = h->prep_counts; cs = &cs_use; }
+  }
+  if (try_prep && !reuse_packed_B) {
+    // the cache is keyed on the POINTER: a caching allocator hands the same address to another tensor, or the caller
+    // updates rows in place -- a content fingerprint mismatch is a cache MISS (the rows are packed again), not an error.
+    // (A prepared side fits one column block: score_prepare_device refuses others.)
+    unsigned long long fp = 0;
+    PLDA_TRY(test_side_fingerprint(h, dV, Nt, &fp));
+    if (fp == h->prep_fp) reuse_packed_B = true;
+    else {
+      h->prep_valid = false;
+      if (dn) {   // back to the call's own count set (a prepared side may have widened it, or made it unnecessary)
+        if (!cs_in && cs_local.G == 0) PLDA_TRY(score_count_set_device(h, dn, M, &cs_local));
+        cs = cs_in ? cs_in : &cs_local;
+        if (cs->G == 1) { n_uniform = cs->vals[0]; dn = nullptr; cs = nullptr; }
+      }
+    }
+  }
   // The 256 x 256 kernel addresses a packed operand with 32-bit byte offsets: a side whose packed form
   // (KQ + 8 planes of 16 B per row) would reach 4 GiB is scored in row / column blocks, each side
   // packed once per block of its own dimension.  (C3's 1 M x 512 test side is 2.2 GB: one block.)
-  const int D = h->Dout;
-  const int64_t kq8 = std::max<int64_t>((dn ? 2 : 1) * round_up(D, 8), 16) / 4 + 8;
+  const int64_t kq8 = operand_kq(h, dn != nullptr, cs) + 8;
   const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;      // rows of one block
   const int64_t nrb = ceil_div(M, cap), ncb = ceil_div(Nt, cap);
-  const bool zn = dzmean && dzstd;
-  h->last_M = M; h->last_Nt = Nt; h->last_k = dn ? 2 * D : D;
-  // a test side packed ahead of time by plda_score_prepare_dev (same rows, same model, same kind of enrol counts)
-  if (ncb == 1 && h->prep_valid && h->prep_dV == dV && h->prep_Nt == Nt && h->prep_epoch == h->model_epoch &&
-      h->prep_mixed == (dn != nullptr) && (dn || h->prep_nuniform == n_uniform)) {
-    unsigned long long fp = 0;
-    PLDA_TRY(test_side_fingerprint(h, dV, Nt, &fp));
-    if (fp != h->prep_fp) {
-      h->prep_valid = false;
-      return fail(h, PLDA_E_INVAL,
-                  "score_matrix: the rows at the prepared test-side address have changed since plda_score_prepare_dev "
-                  "(content fingerprint mismatch); prepare again, or call plda_score_unprepare before reusing the buffer");
-    }
-    reuse_packed_B = true;
-  }
+  h->last_M = M; h->last_Nt = Nt; h->last_k = (int)(dn ? (buckets_usable(h, cs) ? D + cs->G - 1 : 2 * D) : D);
   for (int64_t rb = 0; rb < nrb; ++rb) {
     const int64_t r0 = rb * cap, m = std::min(cap, M - r0);
     for (int64_t cbk = 0; cbk < ncb; ++cbk) {
@@ -1350,7 +1694,7 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
       TrialOperands op;
       PLDA_TRY(prepare_operands(h, dU + r0 * D, dn ? dn + r0 : nullptr, n_uniform, m, dV + c0 * D, nt,
                                 zn ? dzmean + r0 : nullptr, zn ? dzstd + r0 : nullptr, op,
-                                /*doA=*/cbk == 0, /*doB=*/ncb > 1 || (rb == 0 && !reuse_packed_B)));
+                                /*doA=*/cbk == 0, /*doB=*/ncb > 1 || (rb == 0 && !reuse_packed_B), cs));
       float *o = dout + r0 * ld + c0;
       PLDA_TRY(launch_gemm<0>(h, op, m, nt, o, ld, nullptr, nullptr, nullptr));
     }
@@ -1359,22 +1703,30 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
 }
 
 // Pack the test side once for many calls (the reference's callers score one test set against enrol model after enrol
-// model: scoring/scorePLDA.py:302-318): V -> k-quad packed fp32 (+ V*V for mixed counts) and the column biases.
-int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, bool mixed, int n_uniform) {
+// model: scoring/scorePLDA.py:302-318): V -> k-quad packed fp32 and the column biases.  kind 0: uniform count n_uniform;
+// 1: mixed counts in the depth-2D form (+ V*V); 2: mixed counts bucketed, for the distinct counts *cs (later calls whose
+// counts are a subset reuse it).
+int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, int kind, int n_uniform, const CountSet *cs) {
   if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_prepare: model not fitted");
   if (!dV || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_prepare: bad argument");
-  if (!mixed && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_prepare: n_uniform must be > 0 for uniform enrol counts");
-  const int D = h->Dout;
-  const int64_t kq8 = std::max<int64_t>((mixed ? 2 : 1) * round_up(D, 8), 16) / 4 + 8;
+  if (kind == 0 && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_prepare: n_uniform must be > 0 for uniform enrol counts");
+  if (kind == 2) {
+    if (!cs || cs->G < 1) return fail(h, PLDA_E_INVAL, "score_prepare_counts: empty or invalid count list");
+    if (cs->G == 1) { kind = 0; n_uniform = cs->vals[0]; }
+    else if (!buckets_usable(h, cs)) kind = 1;        // too many distinct counts for this dimension: the depth-2D form
+  }
+  const int64_t kq8 = operand_kq(h, kind != 0, kind == 2 ? cs : nullptr) + 8;
   const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;
   if (Nt > cap) return fail(h, PLDA_E_INVAL, "score_prepare: the packed test side would exceed 4 GiB (such calls are scored in column blocks)");
   TrialOperands op;
   static const int32_t dummy_marker = 0;
-  // (only the kind of the enrol counts matters to the test side: a non-null pointer selects the depth-2D form)
-  PLDA_TRY(prepare_operands(h, dV, mixed ? &dummy_marker : nullptr, n_uniform, 0, dV, Nt, nullptr, nullptr, op, /*doA=*/false, /*doB=*/true));
+  // (only the kind of the enrol counts matters to the test side: a non-null pointer selects a mixed-count form)
+  PLDA_TRY(prepare_operands(h, dV, kind != 0 ? &dummy_marker : nullptr, n_uniform, 0, dV, Nt, nullptr, nullptr, op, /*doA=*/false, /*doB=*/true,
+                            kind == 2 ? cs : nullptr));
   PLDA_TRY(test_side_fingerprint(h, dV, Nt, &h->prep_fp));
-  h->prep_valid = true; h->prep_dV = dV; h->prep_Nt = Nt; h->prep_epoch = h->model_epoch; h->prep_mixed = mixed;
+  h->prep_valid = true; h->prep_dV = dV; h->prep_Nt = Nt; h->prep_epoch = h->model_epoch; h->prep_kind = kind;
   h->prep_nuniform = n_uniform;
+  if (kind == 2) h->prep_counts = *cs;
   return PLDA_OK;
 }
 

@@ -510,6 +510,13 @@ class MPlda(object):
         self._ck(self._lib.plda_score_last_kernel(self._h, buf, 128))
         return buf.value.decode()
 
+    def score_last_shape(self):
+        """(M, Nt, algorithmic GEMM depth) of the last score_matrix* call: depth Dout (uniform count), Dout + G - 1
+        (mixed counts, bucketed by the G distinct counts) or 2 Dout (mixed counts, depth-2D form)."""
+        m, nt, k = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self._ck(self._lib.plda_score_last_shape(self._h, C.byref(m), C.byref(nt), C.byref(k)))
+        return int(m.value), int(nt.value), int(k.value)
+
     def score_matrix_dev(self, dU, dn, n_uniform, m, dV, nt, dout, ld, dzmean=None, dzstd=None):
         """Enqueue one trials block on HBM-resident operands (raw device addresses)."""
         self._ck(self._lib.plda_score_matrix_dev(
@@ -521,6 +528,12 @@ class MPlda(object):
         """Pack the test side [nt, Dout] (HBM-resident fp64) once; later score_matrix_dev / sharded calls with the same
         dV, nt, model and kind of enrol counts skip the repacking.  The rows behind dV must not change meanwhile."""
         self._ck(self._lib.plda_score_prepare_dev(self._h, C.c_void_p(int(dV)), int(nt), 1 if mixed_counts else 0, int(n_uniform)))
+
+    def score_prepare_counts_dev(self, dV, nt, counts):
+        """Pack the test side for mixed enrol counts in the bucketed form (GEMM depth Dout + G - 1): `counts` = the enrol
+        counts the later calls will bring (any order, duplicates allowed; a host array)."""
+        c = np.ascontiguousarray(np.asarray(counts).ravel(), dtype=np.int32)
+        self._ck(self._lib.plda_score_prepare_counts_dev(self._h, C.c_void_p(int(dV)), int(nt), _ptr(c), int(c.shape[0])))
 
     def score_unprepare(self):
         self._ck(self._lib.plda_score_unprepare(self._h))

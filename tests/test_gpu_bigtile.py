@@ -7,7 +7,8 @@ test_gpu_scoring.py (<= 517 columns) only ever reach the 128 x 128 kernel.  Here
 
   (i)   forced dispatch (PLDA_GEMM_VARIANT = 30, read at plda_create) of the persistent 256 x 256
         kernel on shapes small enough for the per-trial C oracle `score_block`: uniform n, mixed n
-        (GEMM depth 2D, no column bias) and the z-norm epilogue; ragged edges in both dimensions;
+        (bucketed by distinct count since round 5: depth D + G - 1; tests/test_gpu_mixed_counts.py covers the forms)
+        and the z-norm epilogue; ragged edges in both dimensions;
   (ii)  default dispatch at 8192 x 8192 (exactly the 1024-tile threshold) with the BASELINE shapes'
         depths -- D = 200 uniform n (C2), D = 512 n = 100 (C3), D = 256 mixed n in 1..5 (C4),
         D = 200 z-normalised (C5) -- against the fp64 GEMM-form oracle `llr_matrix`;
@@ -68,7 +69,7 @@ def test_forced_uniform(monkeypatch, oracle, variant, d, m, nt):
 @pytest.mark.parametrize("variant", [30])
 @pytest.mark.parametrize("d,m,nt", [(96, 300, 517), (256, 700, 300), (20, 1024, 1024)])
 def test_forced_mixed_counts(monkeypatch, oracle, variant, d, m, nt):
-    """enrol counts differ -> GEMM depth 2D ([A1 | A2] x [V | V*V]), cbias == nullptr."""
+    """enrol counts differ (n in 1..5: five buckets, GEMM depth D + 4)."""
     eng, psi = _engine(monkeypatch, variant, d)
     rng = np.random.default_rng(200 + d)
     counts = rng.integers(1, 6, m).astype(np.int32)
@@ -211,7 +212,8 @@ def test_default_dispatch_small_dims(monkeypatch):
 
 # ---------------------------------------------------------------- (iii) packed operand >= 4 GiB
 def test_operand_over_4gib(monkeypatch):
-    """D = 512 with mixed counts packs the test side to 256 (+8 spare) k-quads x 16 B per row: 1.02 M
+    """D = 512 with mixed counts in the depth-2D form (PLDA_MIXED_VARIANT=1; the bucketed form of round 5 would need
+    129 + 2 k-quads) packs the test side to 256 (+8 spare) k-quads x 16 B per row: 1.02 M
     rows make it 4.3 GB, beyond the kernel's 32-bit DMA offsets, so score_matrix_device scores two
     column blocks (the enrol side packed once).  Checked on every row x 4096 sampled columns (both
     blocks, the block seam and the tail columns included)."""
@@ -219,6 +221,7 @@ def test_operand_over_4gib(monkeypatch):
     from oracle import plda_oracle_np as onp
     dev = torch.device("cuda", 0)
     d, m, nt = 512, 256, 1_017_000
+    monkeypatch.setenv("PLDA_MIXED_VARIANT", "1")
     eng, psi = _engine(monkeypatch, None, d, 31)
     eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     g = torch.Generator(device=dev); g.manual_seed(5)

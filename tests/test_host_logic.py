@@ -162,3 +162,34 @@ def test_label_compaction_matches_unique():
         uniq, inv = np.unique(y, return_inverse=True)
         assert k == uniq.shape[0]
         assert dense.dtype == np.uint64 and np.array_equal(dense, inv.astype(np.uint64))
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it must become the launcher -- the form the driver uses
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) -- and never run ONE rank that prints
+    n_gpus: 1 (round-4 review).  Without enough GPUs for the RCCL transport it refuses with a non-zero status."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "3"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert os.path.basename(cmd[-5]) == "bench.py"
+    p1 = bench.launch_command(2, [])
+    assert 1024 < int(p1[p1.index("--master-port") + 1]) < 65536         # a free port is picked when none is given
+    # the launcher is what runs, not main()'s single-rank body
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda c, env=None: calls.append((c, env)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.self_launch(2, ["--gpus", "2", "--backend", "gloo", "--transport", "host"], transport="host") == 0
+    assert len(calls) == 1 and calls[0][0][-6:] == ["--gpus", "2", "--backend", "gloo", "--transport", "host"]
+    assert calls[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    import torch
+    if torch.cuda.device_count() < 2:
+        calls.clear()
+        assert bench.self_launch(2, ["--gpus", "2"], transport="rccl") == 2 and not calls     # refused, nothing launched
+        monkeypatch.undo()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "n_gpus" not in r.stdout and "needs 2 GPUs" in r.stderr
