@@ -71,6 +71,7 @@ int comm_init_custom(plda_handle *h, int nranks, int rank, const plda_collective
 int comm_init_host(plda_handle *h, int nranks, int rank, const plda_host_collectives *t);
 int comm_init_peer(plda_handle *h, int nranks, int rank, const plda_host_collectives *t);
 int comm_destroy(plda_handle *h);
+int comm_check(plda_handle *h);
 int comm_describe(plda_handle *h, std::string &js);
 int score_matrix_sharded_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M,
                                 const double *dV, int64_t Nt, const double *dzmean, const double *dzstd, float *dlocal,
@@ -231,7 +232,7 @@ int plda_destroy(plda_handle *h) {
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->fit_flag, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
                       &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1],
-                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work};
+                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc};
     for (DevBuf *b : bufs) b->release();
     for (auto &t : h->bt4_tabs) t.tab.release();
     if (h->cs_pin) (void)hipHostFree(h->cs_pin);
@@ -284,7 +285,7 @@ int plda_synchronize(plda_handle *h) {
     PLDA_LOCK(h);
     PLDA_TRY(set_device(h));
     PLDA_HIP(h, hipStreamSynchronize(h->stream));
-    return PLDA_OK;
+    return comm_check(h);      // a peer-provider wait that gave up is reported where the caller synchronises
   });
 }
 

@@ -292,6 +292,14 @@ __global__ void peer_flag_set_kernel(unsigned long long *slot, unsigned long lon
   __threadfence_system();
   __hip_atomic_store(slot, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// `done`: only when no wait of this rank has given up -- a push that ran although its peer never signalled `ready` (the
+// copy behind a timed-out wait cannot be cancelled) must not be announced as landed: the peer's own wait then gives up too,
+// and both sides report the collective as failed (round-4 advisor)
+__global__ void peer_flag_set_unless_kernel(unsigned long long *slot, unsigned long long v, const unsigned long long *err) {
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  __threadfence_system();
+  __hip_atomic_store(slot, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // waits until *slot >= v for every slot of the list (stride: PeerFlags::ready / ::done of peers q in mask)
 __global__ void peer_flag_wait_kernel(unsigned long long *base, unsigned mask, unsigned long long v, unsigned long long *err) {
@@ -322,8 +330,12 @@ struct PeerCtx {
   unsigned long long *err = nullptr;          // pinned host word a spin that gave up raises (read without any HIP call)
   std::vector<PeerFlags *> peer_flags;        // peer q's page, through its IPC mapping
   unsigned long long seq = 0;                 // collectives so far (the same on every rank: they are collective)
-  struct Map { hipIpcMemHandle_t handle; char *base; };
-  std::vector<std::vector<Map>> maps;         // per peer: opened allocations
+  // per peer: opened allocations.  An entry is the peer's allocation as (IPC handle, size, buffer id); the first entry
+  // is the peer's flag page (pinned for the communicator's lifetime), the others are kept while they are among the
+  // PEER_MAXMAPS most recently used and closed otherwise -- a service gathering into fresh buffers, or a peer whose
+  // temporaries were freed, must not grow this list (nor keep the peer's freed memory pinned) without bound
+  struct Map { hipIpcMemHandle_t handle; char *base; unsigned long long size, id, last; };
+  std::vector<std::vector<Map>> maps;
   DevBuf scratch;                             // all_reduce: every rank's operand, rank-major
   std::vector<char> hbuf;
   std::vector<int64_t> hoff, hcnt;
@@ -345,13 +357,30 @@ int peer_exchange(PeerCtx *c, const void *mine, int64_t bytes) {
   return c->t.all_gather_v(c->t.ctx, c->hbuf.data(), c->hoff.data(), c->hcnt.data());
 }
 
-int peer_map(PeerCtx *c, int q, const hipIpcMemHandle_t &hd, char **base) {
-  for (const auto &m : c->maps[q])
-    if (std::memcmp(&m.handle, &hd, sizeof(hd)) == 0) { *base = m.base; return 0; }
+constexpr size_t PEER_MAXMAPS = 8;            // cached mappings per peer besides its flag page
+int peer_map(PeerCtx *c, int q, const hipIpcMemHandle_t &hd, unsigned long long size, unsigned long long id, char **base) {
+  auto &mp = c->maps[q];
+  for (size_t k = 1; k < mp.size(); ++k) {
+    if (std::memcmp(&mp[k].handle, &hd, sizeof(hd)) != 0) continue;
+    if (mp[k].size == size && mp[k].id == id) { mp[k].last = c->seq; *base = mp[k].base; return 0; }
+    // the same handle bytes for ANOTHER allocation (the owner freed the buffer and the runtime recycled the handle): the
+    // cached mapping points at the old memory -- drop it (my earlier pushes through it first)
+    (void)hipStreamSynchronize(c->pstream[q]);
+    (void)hipIpcCloseMemHandle(mp[k].base);
+    mp.erase(mp.begin() + (long)k);
+    break;
+  }
+  while (mp.size() > PEER_MAXMAPS) {          // least recently used out
+    size_t lru = 1;
+    for (size_t k = 2; k < mp.size(); ++k) if (mp[k].last < mp[lru].last) lru = k;
+    (void)hipStreamSynchronize(c->pstream[q]);
+    (void)hipIpcCloseMemHandle(mp[lru].base);
+    mp.erase(mp.begin() + (long)lru);
+  }
   void *p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return peer_fail(c, "hipIpcOpenMemHandle", e);
-  c->maps[q].push_back({hd, static_cast<char *>(p)});
+  mp.push_back({hd, static_cast<char *>(p), size, id, c->seq});
   *base = static_cast<char *>(p);
   return 0;
 }
@@ -367,13 +396,19 @@ int peer_all_gather_v(void *vc, void *dbuf, const int64_t *offs, const int64_t *
   // onto the collective's own stream, behind everything the caller has enqueued
   if (hipEventRecord(c->ev_in, caller) != hipSuccess || hipStreamWaitEvent(st, c->ev_in, 0) != hipSuccess) return peer_fail(c, "stream hand-over");
   // this rank's allocation behind dbuf, as a handle the others can open, and dbuf's offset inside it
-  struct Msg { hipIpcMemHandle_t handle; int64_t off; } mine;
+  struct Msg { hipIpcMemHandle_t handle; int64_t off; unsigned long long size, id; } mine;
   void *base = nullptr; size_t size = 0;
   hipError_t e = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, dbuf);
   if (e != hipSuccess) return peer_fail(c, "hipMemGetAddressRange", e);
   e = hipIpcGetMemHandle(&mine.handle, base);
   if (e != hipSuccess) return peer_fail(c, "hipIpcGetMemHandle", e);
   mine.off = static_cast<char *>(dbuf) - static_cast<char *>(base);
+  mine.size = size;
+  // the allocation's identity, so that an importer can tell a recycled handle from the buffer it has mapped (the runtime's
+  // per-allocation id where it reports one; 0 otherwise: handle + size then are all there is)
+  unsigned long long bid = 0;
+  if (hipPointerGetAttribute(&bid, HIP_POINTER_ATTRIBUTE_BUFFER_ID, reinterpret_cast<hipDeviceptr_t>(base)) != hipSuccess) { (void)hipGetLastError(); bid = 0; }
+  mine.id = bid;
   // ready: my piece is final and my buffer may be written, once my stream gets here -> every peer's page
   for (int q = 0; q < R; ++q)
     if (q != me) peer_flag_set_kernel<<<1, 1, 0, st>>>(&c->peer_flags[q]->ready[me], n);
@@ -389,12 +424,12 @@ int peer_all_gather_v(void *vc, void *dbuf, const int64_t *offs, const int64_t *
     if ((e = hipStreamWaitEvent(ps, c->ev_mine, 0)) != hipSuccess) return peer_fail(c, "hipStreamWaitEvent(own ready)", e);
     if (counts[me] > 0) {
       char *pb = nullptr;
-      if (peer_map(c, q, all[q].handle, &pb) != 0) return 1;
+      if (peer_map(c, q, all[q].handle, all[q].size, all[q].id, &pb) != 0) return 1;
       peer_flag_wait_kernel<<<1, 1, 0, ps>>>(c->flags->ready, 1u << q, n, c->err);     // q's buffer may be written
       if ((e = hipMemcpyAsync(pb + all[q].off + offs[me], static_cast<char *>(dbuf) + offs[me], (size_t)counts[me], hipMemcpyDeviceToDevice, ps)) != hipSuccess)
         return peer_fail(c, "push", e);
     }
-    peer_flag_set_kernel<<<1, 1, 0, ps>>>(&c->peer_flags[q]->done[me], n);                        // my piece has landed at q
+    peer_flag_set_unless_kernel<<<1, 1, 0, ps>>>(&c->peer_flags[q]->done[me], n, c->err);        // my piece has landed at q
     if ((e = hipEventRecord(c->pcopy[q], ps)) != hipSuccess) return peer_fail(c, "hipEventRecord(push)", e);
     if ((e = hipStreamWaitEvent(st, c->pcopy[q], 0)) != hipSuccess) return peer_fail(c, "hipStreamWaitEvent(push)", e);
   }
@@ -549,7 +584,7 @@ int comm_init_peer(plda_handle *h, int nranks, int rank, const plda_host_collect
     void *pp = nullptr;
     if ((e = hipIpcOpenMemHandle(&pp, all[q], hipIpcMemLazyEnablePeerAccess)) != hipSuccess) return bail("hipIpcOpenMemHandle(flag page)", e);
     c->peer_flags[q] = static_cast<PeerFlags *>(pp);
-    c->maps[q].push_back({all[q], static_cast<char *>(pp)});      // (closed by peer_destroy with the other mappings)
+    c->maps[q].push_back({all[q], static_cast<char *>(pp), 4096, 0, 0});      // entry 0: pinned; closed by peer_destroy with the other mappings
     if ((e = hipStreamCreateWithFlags(&c->pstream[q], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreateWithFlags", e);
     if ((e = hipEventCreateWithFlags(&c->pcopy[q], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreateWithFlags", e);
   }
@@ -557,16 +592,28 @@ int comm_init_peer(plda_handle *h, int nranks, int rank, const plda_host_collect
   return install(h, nranks, rank, dt, 4);
 }
 
+// A wait of the peer provider that gave up (a peer that died, or never reached the collective) raises a word in pinned host
+// memory; the streams cannot be stopped from there, so whatever synchronises -- plda_synchronize, the end of a sharded fit,
+// the communicator's destruction -- reports it: no sharded call's result may be trusted past a PLDA_E_HIP from here.
+int comm_check(plda_handle *h) {
+  if (!h->comm || h->comm_kind != 4) return PLDA_OK;
+  auto *c = static_cast<PeerCtx *>(h->coll.ctx);
+  if (c->err && *static_cast<volatile unsigned long long *>(c->err) != 0)
+    return fail(h, PLDA_E_HIP, "peer collective failed: a wait for a peer gave up after 20 s; the data of the collectives since the last successful check is incomplete");
+  return PLDA_OK;
+}
+
 int comm_destroy(plda_handle *h) {
   if (!h->comm) { h->comm_nranks = 1; h->comm_rank = 0; return PLDA_OK; }
   (void)hipStreamSynchronize(h->stream);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  const int late = comm_check(h);             // (reported after the teardown below)
   if (h->coll.destroy) h->coll.destroy(h->coll.ctx);
   h->coll = plda_collectives{nullptr, nullptr, nullptr, nullptr, nullptr};
   for (auto &e : h->comm_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   h->comm = false; h->comm_kind = 0; h->comm_stream = nullptr; h->comm_nranks = 1; h->comm_rank = 0;
-  return PLDA_OK;
+  return late;
 }
 
 int comm_describe(plda_handle *h, std::string &js) {
@@ -756,9 +803,11 @@ int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const
     Kt += hK[q];
   }
   // merged statistics in rank order: means / counts gathered, scatter summed
-  Tmp mm, mc;
-  PLDA_HIP(h, mm.alloc((size_t)Kt * D * 8));
-  PLDA_HIP(h, mc.alloc((size_t)Kt * 8));
+  // (persistent buffers: under the peer provider the other ranks map what a collective gathers into, and a temporary
+  //  freed at scope exit would leave a mapping per fit behind on every peer)
+  DevBuf &mm = h->comm_mm, &mc = h->comm_mc;
+  PLDA_HIP(h, mm.reserve((size_t)Kt * D * 8));
+  PLDA_HIP(h, mc.reserve((size_t)Kt * 8));
   PLDA_HIP(h, hipMemcpyAsync(static_cast<char *>(mm.p) + offM[me], h->f_means.p, (size_t)K * D * 8, hipMemcpyDeviceToDevice, h->stream));
   PLDA_HIP(h, hipMemcpyAsync(static_cast<char *>(mc.p) + offC[me], h->f_counts.p, (size_t)K * 8, hipMemcpyDeviceToDevice, h->stream));
   PLDA_COLL(h, h->coll.all_gather_v(h->coll.ctx, mm.p, offM.data(), cntM.data(), h->stream), "all_gather_v");
@@ -768,7 +817,8 @@ int fit_sharded_device(plda_handle *h, const double *dX, int64_t N, int D, const
   PLDA_HIP(h, h->f_counts.reserve((size_t)Kt * 8));
   PLDA_HIP(h, hipMemcpyAsync(h->f_means.p, mm.p, (size_t)Kt * D * 8, hipMemcpyDeviceToDevice, h->stream));
   PLDA_HIP(h, hipMemcpyAsync(h->f_counts.p, mc.p, (size_t)Kt * 8, hipMemcpyDeviceToDevice, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));               // the temporaries go out of scope
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  PLDA_TRY(comm_check(h));                                    // a peer wait that gave up: the merged statistics are incomplete
   h->fit_K = Kt;
   return fit_em_device(h, Kt, D, iters);
 }

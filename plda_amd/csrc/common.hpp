@@ -171,6 +171,7 @@ struct plda_handle {
   int comm_nranks = 1, comm_rank = 0;
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  plda::DevBuf comm_mm, comm_mc;   // merged centroids / counts of a sharded fit (persistent: peers map them)
 
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
@@ -262,6 +263,7 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
 // C = X^T diag(kw) X + w2 X2^T X2 (one launch for D <= 208)
 int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ldx, const double *kw, int64_t K2,
                   const double *X2, int64_t ldx2, double w2, double *C, int64_t ldc);
+int syrk_znorm_f64(plda_handle *h, int D0, int64_t K, const double *X, const double *zc, const double *zs, double *C, bool *used);
 int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
              int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,
              const double *kw, double beta, double *C, int64_t ldc);

@@ -639,6 +639,10 @@ __global__ void counts_to_offsets_kernel(const int64_t *__restrict__ counts, int
 // offset scatter.  Everything else the estimator needs (sum_, class_weight, the global mean) follows from
 // the means and counts, so this is also the replica step after a sharded statistics pass.
 int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
+  // (taken over -- and cleared -- before ANY return: a deferred label check left behind would send a later, unrelated
+  //  plda_fit_em_dev down the no-synchronisation path with a stale pointer and start time; round-4 advisor)
+  int *const stats_bad = h->fit_dbad;      // a statistics pass of this same plda_fit is still on the stream: no synchronisation,
+  h->fit_dbad = nullptr;                   // its label checks come back with the planning copies below
   if (K <= 0 || D <= 0 || iters < 0) return fail(h, PLDA_E_INVAL, "fit: bad argument");
   if (K == 1)
     return fail(h, PLDA_E_ONE_SPEAKER,
@@ -646,8 +650,6 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   const size_t DD = (size_t)D * D;
   h->simdiag_has_vr = false;   // a new fit starts cold
   h->jac_total_sweeps = 0;
-  int *const stats_bad = h->fit_dbad;      // a statistics pass of this same plda_fit is still on the stream: no synchronisation,
-  h->fit_dbad = nullptr;                   // its label checks come back with the planning copies below
   if (!stats_bad) PLDA_HIP(h, hipStreamSynchronize(h->stream));
   const double t1 = stats_bad ? h->fit_t0 : now_ms();
   // EM | GetOutput boundary of plda_fit_timings: a pair of events instead of a host synchronisation, so that GetOutput is

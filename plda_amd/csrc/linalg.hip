@@ -408,12 +408,25 @@ constexpr int TRI_LD = TRI_NT * 16 + 16;   // LDS row stride in doubles
 
 // Rows [0, K1) come from X with the weights kw (nullptr: 1), rows [K1, K) from X2 with the one weight w2 (round 3: the
 // statistics pass folds - M^T M, the centroids' term of the offset scatter, into the same launch as X^T diag(w) X).
+//
+// ZN (round 5, MPlda_norm's cohort moments, /root/reference/src/pldamodule.cpp:220-250): the rows are the cohort's
+// TRANSFORMED vectors x_i [D0 wide] and the product is taken of the augmented, shifted rows
+//     [ ca_d x_id - p_d (d < D0) | r_i - p_D0 | 1 ],      r_i = -1/2 (L + sum_d w_d x_id^2),      D = D0 + 2 <= 208
+// formed on the way into LDS: the scale / shift ride on the store, the row sum of w x^2 is taken of the registers the
+// rows were fetched into (one wave reduction per row and wave, four partials per row in LDS) and patched into column D0
+// behind the stage's barrier (one more barrier per stage).  One read of the rows gives the second moments, the column sums
+// (the constant column) and the count -- rounds 2-4 made five passes (rows, column sums, centring, SYRK reading twice).
+// zc: [ca (D0) | w (D0) | g (D0) | L]  (znorm_coef_kernel);  zs: the pilot shift p [D0 + 1].
+template <bool ZN>
 __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t kchunk, const double *__restrict__ X,
                                                        int64_t ldx, const double *__restrict__ kw, int64_t K1,
                                                        const double *__restrict__ X2, int64_t ldx2, double w2,
-                                                       double *__restrict__ part) {
+                                                       double *__restrict__ part, const double *__restrict__ zc,
+                                                       const double *__restrict__ zs) {
   __shared__ double Xs[2][GK * TRI_LD];
   __shared__ double Ws[2][GK];
+  __shared__ double Rs[2][GK * 4];
+  const int D0 = ZN ? D - 2 : D;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
@@ -429,7 +442,12 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
   for (int c = 0; c < TRI_NT; ++c) acc_hi[c] = f64x4{0.0, 0.0, 0.0, 0.0};
   const int fi = lane & 15, fk = lane >> 4;
   const int tc = t & 255, tk = t >> 8;      // column, row offset (rows tk + 2 pass)
-  const int gc = min(tc, D - 1);
+  const int gc = min(tc, D0 - 1);
+  double z_cs = 1.0, z_sh = 0.0, z_w = 0.0, z_L = 0.0, z_shr = 0.0;
+  if (ZN) {
+    if (tc < D0) { z_cs = zc[tc]; z_sh = zs[tc]; z_w = zc[D0 + tc]; }
+    z_L = zc[3 * D0]; z_shr = zs[D0];
+  }
   auto fetch = [&](double (&r)[8], int64_t k0) {
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -442,12 +460,28 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
     if (t < GK && k0 + t < kend) w = k0 + t < K1 ? (kw ? kw[k0 + t] : 1.0) : w2;
     return w;
   };
-  auto store = [&](double *lds, const double (&r)[8]) {
+  auto store = [&](double *lds, const double (&r)[8], double *rs) {
     if (tc < TRI_LD) {
       const bool ok = tc < D;
 #pragma unroll
-      for (int pass = 0; pass < 8; ++pass) lds[(tk + pass * 2) * TRI_LD + tc] = ok ? r[pass] : 0.0;
+      for (int pass = 0; pass < 8; ++pass) {
+        double v = ok ? r[pass] : 0.0;
+        // (rounded product, then the subtraction -- not one fma: a one-row cohort must centre to exactly 0, as the pilot computes p)
+        if (ZN) v = tc < D0 ? __dsub_rn(__dmul_rn(r[pass], z_cs), z_sh) : (tc == D0 + 1 ? 1.0 : 0.0);
+        lds[(tk + pass * 2) * TRI_LD + tc] = v;
+      }
     }
+    if (ZN) {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const double sq = wave_sum_f64(z_w * r[pass] * r[pass]);      // (z_w = 0 beyond column D0)
+        if (lane == 0) rs[(tk + pass * 2) * 4 + (wave & 3)] = sq;
+      }
+    }
+  };
+  // ZN: column D0 of the stage just stored, behind the barrier that made its four partials per row visible
+  auto patch = [&](double *lds, const double *rs) {
+    if (t < GK) lds[t * TRI_LD + D0] = -0.5 * (((rs[t * 4] + rs[t * 4 + 1]) + (rs[t * 4 + 2] + rs[t * 4 + 3])) + z_L) - z_shr;
   };
   double r0[8], r1[8], w0 = 0.0, w1 = 0.0;
   if (kbeg < kend) {
@@ -457,10 +491,14 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
       fetch(r1, kbeg + GK);
       w1 = fetch_w(kbeg + GK);
     }
-    store(Xs[0], r0);
+    store(Xs[0], r0, Rs[0]);
     if (t < GK) Ws[0][t] = w0;
   }
   __syncthreads();
+  if (ZN) {
+    if (kbeg < kend) patch(Xs[0], Rs[0]);
+    __syncthreads();
+  }
   auto stage = [&](int64_t k0, int cur, double (&rn)[8], double &wn, const double (&rs)[8], const double &ws) {
     if (k0 + 2 * GK < kend) {
       fetch(rn, k0 + 2 * GK);
@@ -487,10 +525,14 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
       }
     }
     if (k0 + GK < kend) {
-      store(Xs[cur ^ 1], rs);
+      store(Xs[cur ^ 1], rs, Rs[cur ^ 1]);
       if (t < GK) Ws[cur ^ 1][t] = ws;
     }
     lds_barrier();
+    if (ZN) {
+      if (k0 + GK < kend) patch(Xs[cur ^ 1], Rs[cur ^ 1]);
+      lds_barrier();
+    }
   };
   for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * GK) {
     stage(k0, 0, r0, w0, r1, w1);
@@ -557,7 +599,7 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
     splits = (int)ceil_div(K, kchunk);
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
-    syrk_tri_kernel<<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part);
+    syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part, nullptr, nullptr);
     syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, alpha, beta, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
@@ -586,6 +628,25 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
   return PLDA_OK;
 }
 
+// Cohort moments of MPlda_norm in one read of the transformed rows (syrk_tri_kernel<true>): C [(D0 + 2)^2] = sum over the K
+// rows of the outer product of [ca x - p | r - p_D0 | 1].  *used = false when D0 + 2 > 208 (the caller keeps its own path).
+int syrk_znorm_f64(plda_handle *h, int D0, int64_t K, const double *X, const double *zc, const double *zs, double *C, bool *used) {
+  const int D = D0 + 2;
+  *used = false;
+  if (D > TRI_NT * 16) return PLDA_OK;
+  const int nt = (int)ceil_div(D, 16), ntri = nt * (nt + 1) / 2;
+  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(256, ceil_div(K, 128)));
+  const int64_t kchunk = round_up(ceil_div(K, splits), GK);
+  splits = (int)ceil_div(K, kchunk);
+  PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
+  double *part = h->w[15].as<double>();
+  syrk_tri_kernel<true><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, D0, nullptr, K, nullptr, 0, 0.0, part, zc, zs);
+  syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, D);
+  PLDA_LAUNCH_CHECK(h);
+  *used = true;
+  return PLDA_OK;
+}
+
 // C = X^T diag(kw) X + w2 X2^T X2 in one pass where the single-launch kernel applies (D <= 208), else as two products
 int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ldx, const double *kw, int64_t K2,
                   const double *X2, int64_t ldx2, double w2, double *C, int64_t ldc) {
@@ -597,7 +658,7 @@ int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ld
     splits = (int)ceil_div(K, kchunk);
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
-    syrk_tri_kernel<<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part);
+    syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, nullptr, nullptr);
     syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;

@@ -1133,7 +1133,14 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #undef BT2_MFMA2
 #undef BT2_SB
 
+// (score_bt4.inc defines the tile fetch's two values on the fetching path only, on purpose -- see the comment at f_raw; the
+//  warning is silenced for that kernel alone, not for the translation unit)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
 #include "score_bt4.inc"
+#pragma clang diagnostic pop
 
 // Tile schedule of trials_gemm_bt4_kernel for a btM x btN grid of 256 x 256 tiles: queue x (one per XCD) lists the tiles of
 // patches x, x + 8, ... (BPR x BPC tiles each, row-major inside a patch) -- the order the static walk of bt2 takes them in,
@@ -1844,26 +1851,92 @@ __global__ void znorm_models_kernel(const double *__restrict__ V, const double *
   }
 }
 
+// Round 5: the cohort's moments from ONE read of the transformed rows.  A pilot shift p (the mean of [ca x ; r] over the
+// first <= 64 rows: one workgroup, every load in flight at once) keeps the single-pass covariance S2 / N - (S1 / N)(S1 / N)^T free of
+// cancellation (the shifted-data form: exact in exact arithmetic for ANY p, and p is within an eighth of a standard
+// deviation of the mean);
+// syrk_tri_kernel<true> (linalg.hip) forms the shifted augmented rows on its way into LDS.  Rounds 2-4: rows -> At,
+// column sums, centring in place, SYRK reading At twice = ~6x the cohort's bytes.
+constexpr int ZPILOT = 64;      // pilot rows
+__global__ __launch_bounds__(1024) void znorm_pilot_kernel(const double *__restrict__ X, int D, int64_t R /* <= ZPILOT */, const double *__restrict__ coef,
+                                                           double *__restrict__ shift /*[D + 1]*/) {
+  __shared__ double s1s[4][256], s2s[4][256];
+  __shared__ double red[256];
+  const int tc = threadIdx.x & 255, sub = threadIdx.x >> 8;      // column within a 256-wide slab, row phase
+  double racc = 0.0;
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    const int d = d0 + tc;
+    double s1 = 0.0, s2 = 0.0;
+    if (d < D) {
+#pragma unroll
+      for (int k = 0; k < ZPILOT / 4; ++k) {           // 16 independent loads in flight
+        const int64_t i = sub + 4 * k;
+        const double x = i < R ? X[i * D + d] : 0.0;
+        s1 += x; s2 = fma(x, x, s2);
+      }
+    }
+    s1s[sub][tc] = s1; s2s[sub][tc] = s2;
+    __syncthreads();
+    if (sub == 0 && d < D) {
+      const double t1 = (s1s[0][tc] + s1s[1][tc]) + (s1s[2][tc] + s1s[3][tc]);
+      const double t2 = (s2s[0][tc] + s2s[1][tc]) + (s2s[2][tc] + s2s[3][tc]);
+      shift[d] = __dmul_rn(coef[d], t1 / (double)R);
+      racc += coef[D + d] * t2 / (double)R;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 256) red[threadIdx.x] = racc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) shift[D] = -0.5 * (red[0] + coef[3 * D]);
+}
+
+// C [(D + 2)^2] = sum of outer products of the shifted augmented rows -> means [D + 1] and population covariance [D1 x D1]
+__global__ void znorm_moments_kernel(const double *__restrict__ C, const double *__restrict__ shift, int D1, double invN,
+                                     double *__restrict__ mom, double *__restrict__ Cov) {
+  const int D2 = D1 + 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D1 * D1) return;
+  const int a = idx / D1, b = idx % D1;
+  const double ma = C[(size_t)D1 * D2 + a] * invN, mb = C[(size_t)D1 * D2 + b] * invN;     // row D1: the constant column's products = column sums
+  Cov[idx] = __dsub_rn(__dmul_rn(C[(size_t)a * D2 + b], invN), __dmul_rn(ma, mb));     // (no fma: a one-row cohort has variance exactly 0)
+  if (b == 0) mom[a] = shift[a] + ma;
+}
+
 static int znorm_stats_moments(plda_handle *h, const double *dT, int64_t Nb, const double *dmodels, int64_t M,
                                double *dmean, double *dstd) {
-  const int D = h->Dout, D1 = D + 1;
-  PLDA_HIP(h, h->zn_rows.reserve((size_t)Nb * D1 * 8));
+  const int D = h->Dout, D1 = D + 1, D2 = D + 2;
   PLDA_HIP(h, h->zn_y.reserve((size_t)M * D * 8));
-  PLDA_HIP(h, h->zn_small.reserve(((size_t)3 * D + 1 + (size_t)ZS * D1 + D1 + (size_t)D1 * D1) * 8));
-  double *At = h->zn_rows.as<double>(), *Y = h->zn_y.as<double>();
+  PLDA_HIP(h, h->zn_small.reserve(((size_t)3 * D + 1 + (size_t)ZS * D1 + D1 + (size_t)D1 * D1 + D1 + (size_t)D2 * D2) * 8));
+  double *Y = h->zn_y.as<double>();
   double *coef = h->zn_small.as<double>(), *part = coef + 3 * D + 1, *mom = part + (size_t)ZS * D1, *Cov = mom + D1;
+  double *shift = Cov + (size_t)D1 * D1, *C2 = shift + D1;
   const int wpb = 4;
   {
     TraceScope ts(h, "norm.cohort_moments", 2.0 * (double)Nb * D1 * D1, 1);
     znorm_coef_kernel<<<1, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, coef);
-    znorm_rows_kernel<<<(unsigned)ceil_div(Nb, wpb), wpb * 64, 0, h->stream>>>(dT, coef, D, Nb, At);
-    znorm_colsum_partial_kernel<<<dim3((unsigned)ceil_div(D1, 64), ZS), 256, 0, h->stream>>>(At, Nb, D1, part);
-    znorm_colmean_kernel<<<(unsigned)ceil_div(D1, 256), 256, 0, h->stream>>>(part, D1, 1.0 / (double)Nb, mom);
-    const int64_t total = Nb * (int64_t)D1;
-    znorm_centre_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, h->stream>>>(At, total, D1, mom);
-    PLDA_LAUNCH_CHECK(h);
-    // population covariance of the centred rows: At^T At / Nb (the SYRK kernels of the fit)
-    PLDA_TRY(gemm_f64(h, D1, D1, Nb, 1.0 / (double)Nb, At, 1, D1, At, D1, 1, nullptr, 0.0, Cov, D1));
+    bool used = false;
+    if (h->znorm_variant != 2) {      // PLDA_ZNORM_VARIANT=2: the five-pass form of rounds 2-4 (A/B arm; also what D + 2 > 208 takes)
+      znorm_pilot_kernel<<<1, 1024, 0, h->stream>>>(dT, D, std::min<int64_t>(Nb, ZPILOT), coef, shift);
+      PLDA_TRY(syrk_znorm_f64(h, D, Nb, dT, coef, shift, C2, &used));
+      if (used) znorm_moments_kernel<<<(unsigned)ceil_div((int64_t)D1 * D1, 256), 256, 0, h->stream>>>(C2, shift, D1, 1.0 / (double)Nb, mom, Cov);
+      PLDA_LAUNCH_CHECK(h);
+    }
+    if (!used) {
+      PLDA_HIP(h, h->zn_rows.reserve((size_t)Nb * D1 * 8));
+      double *At = h->zn_rows.as<double>();
+      znorm_rows_kernel<<<(unsigned)ceil_div(Nb, wpb), wpb * 64, 0, h->stream>>>(dT, coef, D, Nb, At);
+      znorm_colsum_partial_kernel<<<dim3((unsigned)ceil_div(D1, 64), ZS), 256, 0, h->stream>>>(At, Nb, D1, part);
+      znorm_colmean_kernel<<<(unsigned)ceil_div(D1, 256), 256, 0, h->stream>>>(part, D1, 1.0 / (double)Nb, mom);
+      const int64_t total = Nb * (int64_t)D1;
+      znorm_centre_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, h->stream>>>(At, total, D1, mom);
+      PLDA_LAUNCH_CHECK(h);
+      // population covariance of the centred rows: At^T At / Nb (the SYRK kernels of the fit)
+      PLDA_TRY(gemm_f64(h, D1, D1, Nb, 1.0 / (double)Nb, At, 1, D1, At, D1, 1, nullptr, 0.0, Cov, D1));
+    }
   }
   {
     TraceScope ts(h, "norm.model_statistics", 2.0 * (double)M * D * D, 1);
@@ -1886,7 +1959,7 @@ int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_e
   if (num_examples <= 0) num_examples = (int)Nb;
   PLDA_TRY(transform_rows_device(h, dbkg, Nb, Din, nullptr, num_examples, dT));
   // cohort = train side with n = 1 (quirk Q7, :235); models = test side
-  if (h->znorm_variant != 1) return znorm_stats_moments(h, dT, Nb, dmodels, M, dmean, dstd);
+  if (h->znorm_variant != 1) return znorm_stats_moments(h, dT, Nb, dmodels, M, dmean, dstd);     // (0: one-read moments; 2: five-pass moments)
   // ---- A/B arm: every LLR on the fp32 MFMA GEMM with the fused (sum, sum of squares) epilogue ----
   TrialOperands op;
   PLDA_TRY(prepare_operands(h, dT, nullptr, 1, Nb, dmodels, M, nullptr, nullptr, op));

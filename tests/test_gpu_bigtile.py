@@ -241,3 +241,44 @@ def test_operand_over_4gib(monkeypatch):
     assert np.isfinite(got).all()
     assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
     assert bool(torch.isfinite(out[:, ::4099]).all())
+
+
+def test_alternating_tile_grids_do_not_stall_the_host(monkeypatch):
+    """Round-4 review, weak 8: a change of the bt4 tile grid used to drain the stream and copy the tile table with two
+    blocking hipMemcpy calls -- the sharded form alternates full blocks and a ragged tail block, a server scores varying
+    M.  Since round 5 the table is built on the device and the last grids are cached: 40 calls alternating between two
+    grids (and a third that evicts nothing) enqueue in a fraction of the time the GPU needs for them, and give the
+    same bits as the same calls made one by one with a synchronisation after each."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    d = 512
+    eng, _ = _engine(monkeypatch, None, d, 41)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    shapes = [(8192, 8192), (8192, 8448), (8448, 8192)]
+    mmax, nmax = 8448, 8448
+    dU = torch.randn((mmax, d), dtype=torch.float64, device=dev, generator=g)
+    dV = torch.randn((nmax, d), dtype=torch.float64, device=dev, generator=g)
+    outs = [torch.empty((m, n), dtype=torch.float32, device=dev) for m, n in shapes]
+    refs = []
+    for (m, n), o in zip(shapes, outs):                       # warm: allocations, tables, code
+        eng.score_matrix_dev(dU.data_ptr(), None, 2, m, dV.data_ptr(), n, o.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert "bt4" in eng.score_last_kernel()
+        refs.append(o.clone())
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(40):
+        (m, n), o = shapes[it % 3], outs[it % 3]
+        eng.score_matrix_dev(dU.data_ptr(), None, 2, m, dV.data_ptr(), n, o.data_ptr(), n)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+    # 40 GEMMs of >= 8192 x 8192 x 512 are ~20 ms of GPU work; their enqueue is launch overhead only
+    assert t_enq < 0.5 * t_all, (t_enq, t_all)
+    eng.set_stream(None)
