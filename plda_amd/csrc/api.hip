@@ -205,6 +205,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_TRANSFORM_VARIANT")) h->transform_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_SORT_VARIANT")) h->sort_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_ZNORM_VARIANT")) h->znorm_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_EER_VARIANT")) h->eer_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
     if (const char *v = std::getenv("PLDA_HOST_VARIANT")) h->host_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_SWEEP_VARIANT")) h->sweep_variant = std::atoi(v);
@@ -232,7 +233,7 @@ int plda_destroy(plda_handle *h) {
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->fit_flag, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
                       &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1],
-                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc};
+                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc, &h->eer_list[0], &h->eer_list[1]};
     for (DevBuf *b : bufs) b->release();
     for (auto &t : h->bt4_tabs) t.tab.release();
     if (h->cs_pin) (void)hipHostFree(h->cs_pin);

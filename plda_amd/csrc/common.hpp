@@ -177,7 +177,10 @@ struct plda_handle {
   plda::DevBuf w[16];
   plda::DevBuf eigdc;            // eig_dc.hip workspace
   plda::DevBuf zn_rows, zn_y, zn_small;   // z-norm statistics by moments (score.hip)
-  int znorm_variant = 0;         // PLDA_ZNORM_VARIANT=1: every LLR on the fused fp32 GEMM (A/B arm)
+  int znorm_variant = 0;         // PLDA_ZNORM_VARIANT=1: every LLR on the fused fp32 GEMM (A/B arm); 2: moments in five passes
+  plda::DevBuf eer_list[2];      // eer.hip, single-pass form: the impostor / target scores inside the pilot's key window
+  int eer_variant = 0;           // PLDA_EER_VARIANT=1: always the three passes; 2: the single-pass form at every size (tests)
+  int eer_last_passes = 0;       // full passes over the matrix the last plda_eer_matrix_dev made (1 or 3)
   const int *eigdc_flag = nullptr;   // device flag of the last direct decomposition (sym_eig_dc_status)
   int eig_variant = 0;           // PLDA_EIG_VARIANT: 0 = direct method where supported, 1 = block Jacobi always
   int eig_debug = 0;             // PLDA_EIG_DEBUG (timing experiments only: results are wrong when set)

@@ -12,6 +12,15 @@
 // three HBM-bound passes over the fp32 scores that histogram an order-preserving uint32 key
 // 11 + 11 + 10 bits at a time (per-block LDS histograms, float4 loads, column strips), with the crossing
 // located in integer arithmetic on the host between passes.  Algorithmic bytes: 3 x 4 B per trial read, nothing written.
+//
+// Round 5, large matrices (one process): ONE pass over the matrix instead of three.  A pilot -- the same exact
+// refinement on every 32nd row (3 % of the bytes) -- brackets the crossing: the key range [klo, khi) in which the
+// SAMPLE's FRR - FAR passes from -delta to +delta, delta = five standard errors of the sample's rates.  The one full pass
+// then counts, per class, the trials below klo and appends the scores inside the window to two compact lists (a few per
+// mille of the trials; wave-aggregated appends), and the exact refinement finishes on the lists with the counts below
+// as its starting offsets.  The answer is the three-pass one bit for bit whenever the window holds the crossing key and
+// both of its neighbours -- checked with the exact counts (g(klo) < 0 <= g(khi), neighbours found inside); otherwise, and
+// for small or sharded inputs, the three passes run.  PLDA_EER_VARIANT=1 forces them (A/B arm, and what the test compares with).
 #include "common.hpp"
 
 #include <algorithm>
@@ -88,7 +97,8 @@ __global__ __launch_bounds__(256) void eer_hist_strip_kernel(const float *__rest
                                                              const int64_t *__restrict__ tspk, int64_t rows_per_wg,
                                                              int shift, int nbits, unsigned prefix, int has_prefix,
                                                              unsigned long long *__restrict__ hist,
-                                                             unsigned *__restrict__ below, unsigned *__restrict__ above) {
+                                                             unsigned *__restrict__ below, unsigned *__restrict__ above, int64_t row_step) {
+  // (row_step > 1: the pilot's sample -- "row" r stands for matrix row r * row_step; M counts sample rows)
   __shared__ unsigned lh[2][EER_BINS];
   for (int i = threadIdx.x; i < 2 * EER_BINS; i += 256) (&lh[0][0])[i] = 0;
   __syncthreads();
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256) void eer_hist_strip_kernel(const float *__rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (row + u >= r1) break;
-      const float *src = scores + (row + u) * ld + col;
+      const float *src = scores + (row + u) * row_step * ld + col;
       if (vec) {
         const f32x4e x = __builtin_nontemporal_load(reinterpret_cast<const f32x4e *>(src));
         v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(256) void eer_hist_strip_kernel(const float *__rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (row + u >= r1) break;
-      const int64_t spk = espk[row + u];
+      const int64_t spk = espk[(row + u) * row_step];
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (ok[e]) account(v[u][e], ts[e] == spk ? 1 : 0);
     }
@@ -150,6 +160,106 @@ __global__ __launch_bounds__(256) void eer_hist_strip_kernel(const float *__rest
   }
 }
 
+// The one full pass of the windowed form (same strip layout).  Per trial: three float compares against the window's
+// ends (the key order is the float order, and -0 == +0 in both), the class, four predicated counters -- below the window
+// per class, targets, at-or-above the window -- and, for the few per mille inside it, a slot in the wave's LDS stage
+// (an LDS atomic taken by those lanes only), which leaves for the class's list 512+ scores at a time behind ONE global
+// atomic (one global atomic per wave and element serialises on the cursor's line: 0.8 s for a window of a tenth of 1e10
+// trials, measured).  NaN scores satisfy no compare: the caller sees below + inside + above != M Nt and runs the three
+// passes, whose key order places them.  A list that fills up keeps counting (the cursor says by how much it overflowed).
+struct EerWindowOut {
+  unsigned long long below[2], targets, above, cursor[2];
+};
+constexpr int EER_WBUF = 1536;       // staged scores per wave and class (48 KB per workgroup); flushed when a batch (<= 1024 more) might not fit
+__global__ __launch_bounds__(256) void eer_window_strip_kernel(const float *__restrict__ scores, int64_t ld, int64_t M, int64_t Nt,
+                                                               const int64_t *__restrict__ espk, const int64_t *__restrict__ tspk,
+                                                               int64_t rows_per_wg, float flo, float fhi, EerWindowOut *__restrict__ wo,
+                                                               float *__restrict__ list0, float *__restrict__ list1, unsigned long long cap) {
+  __shared__ unsigned long long red[4][4];
+  __shared__ float stage[4][2][EER_WBUF];
+  __shared__ int fillc[4][2];
+  const int64_t strips = (Nt + EER_STRIP - 1) / EER_STRIP;
+  const int64_t strip = blockIdx.x % strips, slice = blockIdx.x / strips;
+  const int64_t col = strip * EER_STRIP + (int64_t)threadIdx.x * 4;
+  const int64_t r0 = slice * rows_per_wg, r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t ts[4];
+  bool ok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ok[e] = col + e < Nt;
+    ts[e] = ok[e] ? tspk[col + e] : 0;
+  }
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0) && ok[3];
+  const float qnan = __uint_as_float(0x7fc00000u);
+  unsigned b0 = 0, b1 = 0, t1 = 0, ab = 0;      // (a thread sees <= 4 * rows_per_wg trials: 32 bits)
+  int *const fc = fillc[wave];
+  if (lane < 2) fc[lane] = 0;
+  auto flush = [&](int c) {
+    const int n = __builtin_amdgcn_readfirstlane(fc[c]);
+    if (n == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&wo->cursor[c], (unsigned long long)n);
+    base = __shfl(base, 0);
+    float *dst = c ? list1 : list0;
+    const float *src = stage[wave][c];
+    for (int i = lane; i < n; i += 64)
+      if (base + i < cap) dst[base + i] = src[i];
+    if (lane == 0) fc[c] = 0;
+  };
+  for (int64_t row = r0; row < r1; row += 4) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (row + u >= r1) break;
+      const float *src = scores + (row + u) * ld + col;
+      if (vec) {
+        const f32x4e x = __builtin_nontemporal_load(reinterpret_cast<const f32x4e *>(src));
+        v[u][0] = x.x; v[u][1] = x.y; v[u][2] = x.z; v[u][3] = x.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = ok[e] ? src[e] : qnan;     // (columns beyond the matrix: counted nowhere)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (row + u >= r1) break;
+      const int64_t spk = espk[row + u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[u][e];
+        const bool tgt = ok[e] && ts[e] == spk;
+        const bool lt_lo = x < flo, lt_hi = x < fhi;
+        t1 += tgt ? 1u : 0u;
+        b1 += (lt_lo && tgt) ? 1u : 0u;
+        b0 += (lt_lo && !tgt) ? 1u : 0u;
+        ab += (x >= fhi) ? 1u : 0u;
+        if (lt_hi && !lt_lo) {
+          const int c = tgt ? 1 : 0;
+          const int slot = atomicAdd(&fc[c], 1);
+          stage[wave][c][slot] = x;
+        }
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane(fc[0]) > EER_WBUF - 1024) flush(0);
+    if (__builtin_amdgcn_readfirstlane(fc[1]) > EER_WBUF - 1024) flush(1);
+  }
+  flush(0);
+  flush(1);
+  unsigned long long c[4] = {b0, b1, t1, ab};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int o = 32; o > 0; o >>= 1) c[q] += __shfl_xor(c[q], o);
+    if (lane == 0) red[wave][q] = c[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    unsigned long long *dst = threadIdx.x == 0 ? &wo->below[0] : threadIdx.x == 1 ? &wo->below[1] : threadIdx.x == 2 ? &wo->targets : &wo->above;
+    if (sum) atomicAdd(dst, sum);
+  }
+}
+
 struct EerSource {
   const float *scores; int64_t ld, M, Nt; const int64_t *espk, *tspk;   // matrix + labels, or
   const float *pos; int64_t np; const float *neg; int64_t nn;            // two flat lists
@@ -157,6 +267,11 @@ struct EerSource {
   // (hist: sum over ranks; below: max; above: min).  nullptr = single process.
   int (*reduce)(void *ctx, unsigned long long *hist, unsigned *below, unsigned *above) = nullptr;
   void *ctx = nullptr;
+  int64_t row_step = 1;                        // matrix form: every row_step-th row only (the pilot's sample)
+  // windowed lists (the single-pass form): the lists hold the scores of a key window only; the counts below it and
+  // the class totals come from the full pass
+  bool windowed = false;
+  unsigned long long base_p = 0, base_n = 0, tot_p = 0, tot_n = 0;
 };
 
 // One histogram pass over the local data -> hh (host).  No reduction here: see eer_device.
@@ -164,21 +279,22 @@ static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, 
                     unsigned long long *dhist, unsigned *dbelow, unsigned *dabove, std::vector<unsigned long long> &hh) {
   PLDA_HIP(h, hipMemsetAsync(dhist, 0, 2 * EER_BINS * 8, h->stream));
   if (src.scores) {
-    const unsigned grid = (unsigned)std::min<int64_t>(src.M, 256 * 16);
+    const int64_t Ms = ceil_div(src.M, src.row_step);          // rows this pass walks
+    const unsigned grid = (unsigned)std::min<int64_t>(Ms, 256 * 16);
     if (grid) {
       const int64_t strips = ceil_div(src.Nt, (int64_t)EER_STRIP);
-      const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(src.M, (256 * 16) / strips));
-      const int64_t rows_per_wg = ceil_div(src.M, slices);
-      eer_hist_strip_kernel<<<(unsigned)(strips * ceil_div(src.M, rows_per_wg)), 256, 0, h->stream>>>(
-          src.scores, src.ld, src.M, src.Nt, src.espk, src.tspk, rows_per_wg, shift, nbits, prefix, has_prefix, dhist,
-          dbelow, dabove);
+      const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(Ms, (256 * 16) / strips));
+      const int64_t rows_per_wg = ceil_div(Ms, slices);
+      eer_hist_strip_kernel<<<(unsigned)(strips * ceil_div(Ms, rows_per_wg)), 256, 0, h->stream>>>(
+          src.scores, src.ld, Ms, src.Nt, src.espk, src.tspk, rows_per_wg, shift, nbits, prefix, has_prefix, dhist,
+          dbelow, dabove, src.row_step);
     }
   } else {
     for (int c = 0; c < 2; ++c) {
       const float *p = c ? src.pos : src.neg;
       const int64_t n = c ? src.np : src.nn;
       const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 256), 256 * 16);
-      eer_hist_kernel<<<grid, 256, 0, h->stream>>>(p, n, c, shift, nbits, prefix, has_prefix, dhist, dbelow, dabove);
+      if (grid) eer_hist_kernel<<<grid, 256, 0, h->stream>>>(p, n, c, shift, nbits, prefix, has_prefix, dhist, dbelow, dabove);
     }
   }
   PLDA_LAUNCH_CHECK(h);
@@ -194,8 +310,11 @@ static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, 
 // A rank that fails (HIP error, inconsistent counts) keeps taking part with a poisoned histogram --
 // 2^48 added to counter 0, far above any real count -- so that all ranks see the failure after the
 // next sum and return an error together instead of leaving their peers blocked in a collective.
-int eer_device(plda_handle *h, const EerSource &src, double *out) {
+// window_missed (windowed lists only): set when the crossing key or one of its neighbours is not inside the lists --
+// the caller then runs the three passes over the matrix; nothing is written to `out`.
+int eer_device(plda_handle *h, const EerSource &src, double *out, bool *window_missed = nullptr) {
   typedef unsigned __int128 u128;
+  if (window_missed) *window_missed = false;
   constexpr unsigned long long POISON = 1ull << 48;
   PLDA_HIP(h, h->w[10].reserve(2 * EER_BINS * 8 + 64));
   unsigned long long *dhist = h->w[10].as<unsigned long long>();
@@ -225,6 +344,7 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
     const int nb = 1 << bits[pass];
     if (pass == 0) {
       for (int b = 0; b < nb; ++b) { Nn += H[b]; Np += H[EER_BINS + b]; }
+      if (src.windowed) { Np = src.tot_p; Nn = src.tot_n; Pb = src.base_p; Nb = src.base_n; }   // the lists are a window of the data
       if (Np == 0 || Nn == 0) { rc = fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor trial"); continue; }
     }
     int sel = -1;
@@ -234,6 +354,7 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
       if ((H[b] | H[EER_BINS + b]) && (u128)p2 * Nn >= (u128)(Nn - n2) * Np) { sel = b; cP = H[EER_BINS + b]; cN = H[b]; break; }
       P = p2; N = n2;
     }
+    if (sel < 0 && src.windowed && window_missed) { *window_missed = true; return PLDA_OK; }   // the crossing lies above the window
     if (sel < 0) { rc = fail(h, PLDA_E_NUMERIC, "eer: crossing not found (inconsistent counts)"); continue; }
     Pb = P; Nb = N;
     prefix = (prefix << bits[pass]) | (unsigned)sel;
@@ -256,6 +377,12 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
   if (k0 < 0 && (Pb + Nb) > 0) k0 = hb[0];
   for (int b = b2 + 1; b < 1024; ++b) if (last[b] | last[EER_BINS + b]) { k2 = (long long)((k1 & ~1023u) | (unsigned)b); break; }
   if (k2 < 0 && (Pb + cP + Nb + cN) < (Np + Nn)) k2 = hb[1];
+  if (src.windowed) {
+    // the neighbours must have been SEEN in the lists: a predecessor / successor that exists in the data (counts say so)
+    // but lies outside the window leaves hb at its initial value
+    const bool need0 = (Pb + Nb) > 0, need2 = (Pb + cP + Nb + cN) < (Np + Nn);
+    if ((need0 && k0 == 0) || (need2 && k2 == 0xffffffffll)) { if (window_missed) *window_missed = true; return PLDA_OK; }
+  }
   // g(k1) = (Pb + cP)/Np - (Nn - Nb - cN)/Nn >= 0 ; g(prev) = Pb/Np - (Nn - Nb)/Nn < 0 (prev = k0, or the start).
   // The choice between the two candidates is made on |FAR - FRR| formed in float64 from the float64 rates,
   // exactly as the definition evaluates it (an exact tie such as 393/400 vs 394/400 around 787/800 must
@@ -276,12 +403,134 @@ int eer_device(plda_handle *h, const EerSource &src, double *out) {
   return PLDA_OK;
 }
 
+// ---- the single-pass form (see the header) ----
+constexpr int64_t EER_PILOT_STEP = 32;
+// Returns PLDA_OK with *done = true when `out` holds the result; *done = false: run the three passes.
+static int eer_matrix_windowed(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
+                               const int64_t *dtspk, double *out, bool *done) {
+  typedef unsigned __int128 u128;
+  *done = false;
+  TraceScope ts(h, "eer.pilot");
+  PLDA_HIP(h, h->w[10].reserve(2 * EER_BINS * 8 + 64 + sizeof(EerWindowOut)));
+  unsigned long long *dhist = h->w[10].as<unsigned long long>();
+  unsigned *dbelow = reinterpret_cast<unsigned *>(dhist + 2 * EER_BINS), *dabove = dbelow + 1;
+  EerWindowOut *dwo = reinterpret_cast<EerWindowOut *>(dhist + 2 * EER_BINS + 8);
+  EerSource smp{dscores, ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
+  smp.row_step = EER_PILOT_STEP;
+  // pilot, pass 0 on the sample: per coarse bin (top 11 key bits) the sample's g = FRR - FAR; the band |g| < delta of five
+  // standard errors around the sample's crossing starts in coarse bin ca and ends in cb (often the same); one pass over
+  // the sample per end then places the window's ends on sub-bins (22 key bits)
+  std::vector<unsigned long long> H0, H1;
+  PLDA_TRY(eer_pass(h, smp, 21, 11, 0, 0, dhist, dbelow, dabove, H0));
+  unsigned long long Np = 0, Nn = 0;
+  for (int b = 0; b < EER_BINS; ++b) { Nn += H0[b]; Np += H0[EER_BINS + b]; }
+  if (Np < 2000 || Nn < 2000) return PLDA_OK;                       // too few targets in the sample to bracket anything
+  auto g_after = [&](unsigned long long p, unsigned long long n) { return (double)p / (double)Np - (double)(Nn - n) / (double)Nn; };
+  double delta = 0.0;
+  {
+    unsigned long long P = 0, N = 0;
+    int c0 = -1;
+    for (int b = 0; b < EER_BINS; ++b) {
+      const unsigned long long p2 = P + H0[EER_BINS + b], n2 = N + H0[b];
+      if ((H0[b] | H0[EER_BINS + b]) && (u128)p2 * Nn >= (u128)(Nn - n2) * Np) { c0 = b; break; }
+      P = p2; N = n2;
+    }
+    if (c0 < 0) return PLDA_OK;
+    const double pe = std::min(0.5, std::max((double)P / (double)Np, 10.0 / (double)Np));     // ~ the sample's FRR at the crossing
+    delta = 5.0 * (std::sqrt(pe * (1.0 - pe) / (double)Np) + std::sqrt(pe * (1.0 - pe) / (double)Nn)) + 2.0 / (double)Np;
+  }
+  int ca = -1, cb = -1;
+  unsigned long long Pa = 0, Na = 0, Pc = 0, Nc = 0;                 // sample counts below coarse bins ca, cb
+  {
+    unsigned long long P = 0, N = 0;
+    for (int b = 0; b < EER_BINS; ++b) {
+      const unsigned long long p2 = P + H0[EER_BINS + b], n2 = N + H0[b];
+      const double g = g_after(p2, n2);
+      if (ca < 0 && g > -delta) { ca = b; Pa = P; Na = N; }
+      if (g >= delta) { cb = b; Pc = P; Nc = N; break; }
+      P = p2; N = n2;
+    }
+  }
+  if (ca < 0 || cb < 0) return PLDA_OK;
+  int blo = 0, bhi = EER_BINS - 1;
+  unsigned long long win_lo = Pa + Na, win_hi = 0;                   // sample trials below the window's ends
+  PLDA_TRY(eer_pass(h, smp, 10, 11, (unsigned)ca, 1, dhist, dbelow, dabove, H1));
+  {
+    unsigned long long p = Pa, n = Na;
+    for (int b = 0; b < EER_BINS; ++b) {
+      const unsigned long long p2 = p + H1[EER_BINS + b], n2 = n + H1[b];
+      if (g_after(p2, n2) > -delta) { blo = b; break; }
+      p = p2; n = n2;
+    }
+    blo = std::max(blo - 1, 0);                                      // one sub-bin of margin
+    for (int b = 0; b < blo; ++b) win_lo += H1[b] + H1[EER_BINS + b];
+  }
+  if (cb != ca) PLDA_TRY(eer_pass(h, smp, 10, 11, (unsigned)cb, 1, dhist, dbelow, dabove, H1));
+  {
+    unsigned long long p = Pc, n = Nc;
+    for (int b = 0; b < EER_BINS; ++b) {
+      p += H1[EER_BINS + b]; n += H1[b];
+      if (g_after(p, n) >= delta) { bhi = b; break; }
+    }
+    bhi = std::min(bhi + 1, EER_BINS - 1);
+    win_hi = Pc + Nc;
+    for (int b = 0; b <= bhi; ++b) win_hi += H1[b] + H1[EER_BINS + b];
+  }
+  const unsigned klo = ((unsigned)ca << 21) | ((unsigned)blo << 10);
+  const unsigned long long khi64 = ((unsigned long long)cb << 21) | ((unsigned long long)(bhi + 1) << 10);
+  if (khi64 > 0xffffffffull || khi64 <= klo) return PLDA_OK;
+  const unsigned khi = (unsigned)khi64;
+  const unsigned long long win = win_hi > win_lo ? win_hi - win_lo : 0;
+  // the lists: the sample's in-window count scaled up, with room to spare; too wide a window is not worth a list
+  const unsigned long long cap = (unsigned long long)((double)win * (double)EER_PILOT_STEP * 2.0) + (1ull << 20);
+  if (cap > (unsigned long long)M * (unsigned long long)Nt / 8) return PLDA_OK;
+  PLDA_HIP(h, h->eer_list[0].reserve((size_t)cap * 4));
+  PLDA_HIP(h, h->eer_list[1].reserve((size_t)cap * 4));
+  ts.next("eer.window_pass", (double)M * (double)Nt * 4.0, 2);
+  PLDA_HIP(h, hipMemsetAsync(dwo, 0, sizeof(EerWindowOut), h->stream));
+  {
+    const int64_t strips = ceil_div(Nt, (int64_t)EER_STRIP);
+    const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(M, (256 * 16) / strips));
+    const int64_t rows_per_wg = ceil_div(M, slices);
+    eer_window_strip_kernel<<<(unsigned)(strips * ceil_div(M, rows_per_wg)), 256, 0, h->stream>>>(
+        dscores, ld, M, Nt, despk, dtspk, rows_per_wg, key_score(klo), key_score(khi), dwo, h->eer_list[0].as<float>(), h->eer_list[1].as<float>(), cap);
+    PLDA_LAUNCH_CHECK(h);
+  }
+  EerWindowOut wo;
+  PLDA_HIP(h, hipMemcpyAsync(&wo, dwo, sizeof(wo), hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  ts.next("eer.finish_on_window");
+  if (wo.cursor[0] > cap || wo.cursor[1] > cap) return PLDA_OK;     // a list overflowed
+  // every trial is below, inside or above the window -- unless its score is a NaN (the three passes place those by key)
+  if (wo.below[0] + wo.below[1] + wo.cursor[0] + wo.cursor[1] + wo.above != (unsigned long long)M * (unsigned long long)Nt) return PLDA_OK;
+  const unsigned long long TP = wo.targets, TN = (unsigned long long)M * (unsigned long long)Nt - wo.targets;
+  if (TP == 0 || TN == 0) return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor trial");
+  // exact g at the window's ends: below it FRR - FAR must still be negative, at its end non-negative
+  if ((u128)wo.below[1] * TN >= (u128)(TN - wo.below[0]) * TP) return PLDA_OK;
+  if ((u128)(wo.below[1] + wo.cursor[1]) * TN < (u128)(TN - wo.below[0] - wo.cursor[0]) * TP) return PLDA_OK;
+  if (wo.cursor[0] + wo.cursor[1] == 0) return PLDA_OK;
+  EerSource lst{nullptr, 0, 0, 0, nullptr, nullptr, h->eer_list[1].as<float>(), (int64_t)wo.cursor[1], h->eer_list[0].as<float>(), (int64_t)wo.cursor[0]};
+  lst.windowed = true;
+  lst.base_p = wo.below[1]; lst.base_n = wo.below[0]; lst.tot_p = TP; lst.tot_n = TN;
+  bool missed = false;
+  PLDA_TRY(eer_device(h, lst, out, &missed));
+  *done = !missed;
+  return PLDA_OK;
+}
+
 int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
                       const int64_t *dtspk, double *out,
                       int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *), void *ctx) {
   // a rank of a sharded call may own no row at all (M == 0): it still takes part in the reductions
   if (!out || Nt <= 0 || ld < Nt || M < 0 || (M == 0 && !reduce) || (M > 0 && (!dscores || !despk || !dtspk)))
     return fail(h, PLDA_E_INVAL, "eer: bad argument");
+  h->eer_last_passes = 3;
+  if (!reduce && h->eer_variant != 1 && (h->eer_variant == 2 || (double)M * (double)Nt >= 2.5e8) && M >= 4 * EER_PILOT_STEP) {
+    bool done = false;
+    PLDA_TRY(eer_matrix_windowed(h, dscores, ld, M, Nt, despk, dtspk, out, &done));
+    if (done) { h->eer_last_passes = 1; return PLDA_OK; }
+  }
+  TraceScope ts(h, "eer.three_passes", 3.0 * (double)M * (double)Nt * 4.0, 2);
   EerSource s{M > 0 ? dscores : reinterpret_cast<const float *>(out), ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
   s.reduce = reduce;
   s.ctx = ctx;

@@ -53,5 +53,22 @@ for _ in range(3):
     out = eer.eer_from_matrix_dev(eng, S.data_ptr(), N, N, N, y.data_ptr(), y.data_ptr())
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
-res["full"] = {"ms": dt * 1e3, "GBps_3pass": 3 * N * N * 4 / dt / 1e9, "out": [float(x) for x in out]}
+eng.trace_enable(True); eng.trace_read(reset=True)
+eer.eer_from_matrix_dev(eng, S.data_ptr(), N, N, N, y.data_ptr(), y.data_ptr())
+spans = [{"name": sp["name"], "ms": round(sp["ms"], 3)} for sp in eng.trace_read(reset=True)]
+eng.trace_enable(False)
+res["full"] = {"ms": dt * 1e3, "GBps_of_one_read": N * N * 4 / dt / 1e9, "out": [float(x) for x in out], "spans": spans}
+# the three-pass arm on the same matrix (PLDA_EER_VARIANT=1): must give the same six numbers
+os.environ["PLDA_EER_VARIANT"] = "1"
+e3 = MPlda(0)
+del os.environ["PLDA_EER_VARIANT"]
+e3.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+out3 = eer.eer_from_matrix_dev(e3, S.data_ptr(), N, N, N, y.data_ptr(), y.data_ptr())
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    out3 = eer.eer_from_matrix_dev(e3, S.data_ptr(), N, N, N, y.data_ptr(), y.data_ptr())
+torch.cuda.synchronize()
+dt3 = (time.perf_counter() - t0) / 3
+res["three_pass_arm"] = {"ms": dt3 * 1e3, "GBps_3pass": 3 * N * N * 4 / dt3 / 1e9, "identical": bool(np.array_equal(out, out3))}
 print(json.dumps(res))

@@ -146,3 +146,69 @@ def test_eer_of_a_row_sharded_matrix(world):
         assert p.exitcode == 0
     assert [r[1] for r in res] == [True] * world, res
     assert all(r[2] == res[0][2] for r in res)
+
+
+def _eer_both(monkeypatch, S, ld, m, nt, des, dts, force=False):
+    """(single-pass result, spans of the call, three-pass result) on the same matrix."""
+    from plda_amd import MPlda, eer
+    monkeypatch.setenv("PLDA_EER_VARIANT", "2" if force else "0")
+    fast = MPlda(0)
+    monkeypatch.setenv("PLDA_EER_VARIANT", "1")
+    slow = MPlda(0)
+    monkeypatch.delenv("PLDA_EER_VARIANT")
+    fast.trace_enable(True)
+    a = eer.eer_from_matrix_dev(fast, S.data_ptr(), ld, m, nt, des.data_ptr(), dts.data_ptr())
+    names = [sp["name"] for sp in fast.trace_read()]
+    b = eer.eer_from_matrix_dev(slow, S.data_ptr(), ld, m, nt, des.data_ptr(), dts.data_ptr())
+    return a, names, b
+
+
+def test_single_pass_eer_is_the_three_pass_eer(monkeypatch):
+    """Round 5: large matrices take ONE full pass (pilot on every 32nd row -> key window -> counts below + the window's
+    scores -> exact refinement on the lists).  20 000 x 20 000 Gaussian scores with 200 speakers (2e6 targets): the
+    single pass must run (trace) and give the three-pass answer bit for bit -- threshold, FAR, FRR, EER, counts."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m = nt = 20000
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    es = torch.randint(0, 200, (m,), device=dev, generator=g)
+    ts = torch.randint(0, 200, (nt,), device=dev, generator=g)
+    S = torch.randn((m, nt), dtype=torch.float32, device=dev, generator=g)
+    S += 2.5 * (es[:, None] == ts[None, :]).float()
+    a, names, b = _eer_both(monkeypatch, S, nt, m, nt, es, ts)
+    assert "eer.window_pass" in names and "eer.three_passes" not in names, names
+    assert np.array_equal(a, b), (a, b)
+    assert 0.05 < a[3] < 0.2 and a[4] + a[5] == m * nt
+
+
+@pytest.mark.parametrize("case", ["gauss", "ties", "coarse_ties", "separable", "few_targets", "ragged"])
+def test_single_pass_eer_forced_on_small_and_awkward_inputs(monkeypatch, case):
+    """PLDA_EER_VARIANT=2 sends every matrix with >= 256 rows through the single-pass form: whatever the pilot makes of
+    it -- a window, or no usable window (heavy ties put the crossing key's neighbours outside any window; separable
+    classes have no crossing inside the data; too few targets in the sample) -- the answer is the three-pass one, and the
+    NumPy restatement's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(sum(map(ord, case)))
+    m, nt, k = (1500, 2100, 30) if case != "ragged" else (1031, 4099, 12)
+    ld = nt if case != "ragged" else nt + 5
+    es, ts = rng.integers(0, k, m), rng.integers(0, k, nt)
+    if case == "few_targets":
+        es[:] = np.arange(m) + 1000; ts[:] = np.arange(nt) + 5000; es[:40] = 7; ts[:25] = 7
+    tgt = es[:, None] == ts[None, :]
+    Sh = rng.standard_normal((m, ld)).astype(np.float32)
+    Sh[:, :nt] += (8.0 if case == "separable" else 1.5) * tgt
+    if case == "separable":
+        Sh[:, :nt] = np.clip(Sh[:, :nt], -3, 3) + 8.0 * tgt
+    if case == "ties":
+        Sh = np.round(Sh, 2)
+    if case == "coarse_ties":
+        Sh = np.round(Sh * 2) / 2
+    S = torch.from_numpy(Sh).to(dev)
+    des, dts = torch.from_numpy(es).to(dev), torch.from_numpy(ts).to(dev)
+    a, names, b = _eer_both(monkeypatch, S, ld, m, nt, des, dts, force=True)
+    assert "eer.pilot" in names, names
+    assert np.array_equal(a, b), (case, a, b)
+    sub = Sh[:, :nt]
+    ref = onp.eer(sub[~tgt], sub[tgt])
+    assert tuple(a[1:4]) == ref[1:] and a[0] == pytest.approx(ref[0], rel=1e-12)
