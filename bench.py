@@ -767,8 +767,9 @@ def main():
             # what crossed xGMI, where a reader of the parsed line sees it (round-4 review): the assembled-matrix rate over RCCL
             # and over the direct-write provider, and the bytes every rank took in per second
             if "value" in gather_info:
-                res["gather_rccl_trials_per_s"] = gather_info["value"]
-                res["gather_rccl_ingest_GBps_per_rank"] = gather_info.get("ingest_GBps_per_rank")
+                res["gather_transport"] = (multi or {}).get("transport")
+                res["gather_trials_per_s"] = gather_info["value"]
+                res["gather_ingest_GBps_per_rank"] = gather_info.get("ingest_GBps_per_rank")
             pdw = gather_info.get("peer_direct_write") or {}
             if "value" in pdw:
                 res["gather_peer_trials_per_s"] = pdw["value"]

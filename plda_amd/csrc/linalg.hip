@@ -556,26 +556,41 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
     }
 }
 
-__global__ __launch_bounds__(256) void syrk_tri_reduce_kernel(const double *__restrict__ part, int splits, int D,
-                                                              double alpha, double beta, double *__restrict__ C,
-                                                              int64_t ldc) {
+// Round 5: 1024 threads per tile -- element e = t & 255 of the tile, quarter q = t >> 8 of the splits -- so that a tile's
+// 256 partials are four chains of <= 64 with sixteen loads in flight each instead of one chain of 256 with eight (the
+// reduction was 25-30 us of dependent L2 round trips at C2, a fifth of K2); the four quarter sums meet in LDS and are
+// added in a fixed order: deterministic, and exactly symmetric (both mirror elements get the same sum).
+__global__ __launch_bounds__(1024) void syrk_tri_reduce_kernel(const double *__restrict__ part, int splits, int D,
+                                                               double alpha, double beta, double *__restrict__ C,
+                                                               int64_t ldc) {
+  __shared__ double qs[4][256];
   const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
   int tr = 0, tcol = (int)blockIdx.x;
   while (tcol > tr) { tcol -= tr + 1; ++tr; }
-  const int lane = threadIdx.x & 63, reg = threadIdx.x >> 6;
+  const int e = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int lane = e & 63, reg = e >> 6;
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   const int gr = tr * 16 + (lane >> 4) + 4 * reg, gcol = tcol * 16 + (lane & 15);
-  if (gr >= D || gcol >= D || gcol > gr) return;
-  const double *p = part + (int64_t)blockIdx.x * 256 + reg * 64 + lane;
+  const bool live = gr < D && gcol < D && gcol <= gr;
+  const int per = (splits + 3) >> 2, z0 = q * per, z1 = min(splits, z0 + per);
+  const double *p = part + (int64_t)blockIdx.x * 256 + e;
   const int64_t zs = (int64_t)ntri * 256;
-  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int z = 0;
-  for (; z + 8 <= splits; z += 8) {
+  double s16[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s8[u] += p[(int64_t)(z + u) * zs];
+  for (int u = 0; u < 16; ++u) s16[u] = 0.0;
+  if (live) {
+    int z = z0;
+    for (; z + 16 <= z1; z += 16) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s16[u] += p[(int64_t)(z + u) * zs];
+    }
+    for (int u = 0; z < z1; ++z, ++u) s16[u] += p[(int64_t)z * zs];
   }
-  for (; z < splits; ++z) s8[0] += p[(int64_t)z * zs];
-  const double sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  qs[q][e] = (((s16[0] + s16[1]) + (s16[2] + s16[3])) + ((s16[4] + s16[5]) + (s16[6] + s16[7]))) +
+             (((s16[8] + s16[9]) + (s16[10] + s16[11])) + ((s16[12] + s16[13]) + (s16[14] + s16[15])));
+  __syncthreads();
+  if (q != 0 || !live) return;
+  const double sum = (qs[0][e] + qs[1][e]) + (qs[2][e] + qs[3][e]);
   double *c1 = C + (int64_t)gr * ldc + gcol, *c2 = C + (int64_t)gcol * ldc + gr;
   const double v1 = alpha * sum + (beta != 0.0 ? beta * *c1 : 0.0);
   const double v2 = alpha * sum + (beta != 0.0 ? beta * *c2 : 0.0);
@@ -600,7 +615,7 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
     syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part, nullptr, nullptr);
-    syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, alpha, beta, C, ldc);
+    syrk_tri_reduce_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, splits, D, alpha, beta, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
   }
@@ -641,7 +656,7 @@ int syrk_znorm_f64(plda_handle *h, int D0, int64_t K, const double *X, const dou
   PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
   double *part = h->w[15].as<double>();
   syrk_tri_kernel<true><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, D0, nullptr, K, nullptr, 0, 0.0, part, zc, zs);
-  syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, D);
+  syrk_tri_reduce_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, D);
   PLDA_LAUNCH_CHECK(h);
   *used = true;
   return PLDA_OK;
@@ -659,7 +674,7 @@ int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ld
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
     syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, nullptr, nullptr);
-    syrk_tri_reduce_kernel<<<(unsigned)ntri, 256, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, ldc);
+    syrk_tri_reduce_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
   }

@@ -254,7 +254,10 @@ def test_alternating_tile_grids_do_not_stall_the_host(monkeypatch):
     dev = torch.device("cuda", 0)
     d = 512
     eng, _ = _engine(monkeypatch, None, d, 41)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # (a stream of its own, as bench.py uses: launches on the legacy null stream are ordered against every other stream of
+    #  the process, and what else the test process has in flight then shows up in the enqueue time)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
     g = torch.Generator(device=dev); g.manual_seed(11)
     shapes = [(8192, 8192), (8192, 8448), (8448, 8192)]
     mmax, nmax = 8448, 8448

@@ -180,3 +180,26 @@ def test_sharded_entry_points_between_processes(world, transport):
         bad = [k for k, v in ok.items() if not v]
         assert not bad, (rank, bad)
     assert [p.exitcode for p in procs] == [0] * world
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (round-4 review: it used to run one rank and print
+    n_gpus: 1): the script re-executes itself under torch.distributed.run.  Two ranks share this box's one GPU through the
+    direct-write peer provider (gloo carries the IPC handles), a small C2-shaped problem; the line must say n_gpus: 2,
+    carry the gather-inclusive keys at top level and pass its own oracle check on every rank."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--transport", "peer",
+                        "--rows", "20000", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_nranks"] == 2 and j["multi_gpu"]["transport"] == "peer"
+    assert j["oracle_check"]["within_1e-4_on_every_rank"] is True
+    assert j["gather_inclusive"]["gathered_blocks_bit_identical_to_their_owners"] is True
+    assert j["gather_trials_per_s"] == j["gather_inclusive"]["value"] > 0 and j["gather_transport"] == "peer"
