@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libplda_hip.so")
 SOURCES = ["api.hip", "score.hip", "linalg.hip", "fit.hip", "frontend.hip", "eer.hip", "lda.hip", "comm.hip", "eig_dc.hip", "hostio.hip", "transform.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "hostio.hpp"), os.path.join(CSRC, "sweep_mfma.inc"), os.path.join(CSRC, "score_bt4.inc"), os.path.join(CSRC, "syrk_blk.inc"), os.path.join(HERE, "..", "include", "plda_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "hostio.hpp"), os.path.join(CSRC, "sweep_mfma.inc"), os.path.join(CSRC, "score_bt4.inc"), os.path.join(CSRC, "score_bf16x3.inc"), os.path.join(CSRC, "syrk_blk.inc"), os.path.join(HERE, "..", "include", "plda_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

@@ -197,6 +197,10 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_PREP_VARIANT")) h->prep_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_MIXED_VARIANT")) h->mixed_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_SCORE_DTYPE")) {
+      if (std::strcmp(v, "bf16x3") == 0) h->score_dtype = 1;
+      else if (std::strcmp(v, "f32") != 0 && *v) { delete h; return fail(nullptr, PLDA_E_INVAL, "plda_create: PLDA_SCORE_DTYPE=%s (f32 or bf16x3)", v); }
+    }
     if (const char *v = std::getenv("PLDA_EM_VARIANT")) h->em_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_JACOBI_VARIANT")) h->jacobi_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_GEMM64_VARIANT")) h->gemm64_variant = std::atoi(v);
@@ -233,7 +237,7 @@ int plda_destroy(plda_handle *h) {
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->fit_flag, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
                       &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1],
-                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc, &h->eer_list[0], &h->eer_list[1]};
+                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc, &h->eer_list[0], &h->eer_list[1], &h->s_A16, &h->s_B16};
     for (DevBuf *b : bufs) b->release();
     for (auto &t : h->bt4_tabs) t.tab.release();
     if (h->cs_pin) (void)hipHostFree(h->cs_pin);

@@ -98,6 +98,8 @@ struct plda_handle {
 
   // ---- scoring workspace ----
   plda::DevBuf s_Apk, s_Bpk, s_rbias, s_rscale, s_cbias, s_rpair, s_cpair;
+  plda::DevBuf s_A16, s_B16;   // the packed operands as three bf16 planes per k-oct (score_bf16x3.inc: opt-in arm)
+  int score_dtype = 0;         // PLDA_SCORE_DTYPE=bf16x3 -> 1: the trials GEMM's contraction as three bf16 terms (opt-in; default fp32 MFMA)
   plda::DevBuf tf_pad;   // zero-padded copy of the transform for the one-pass K4 kernel, cached per model
   uint64_t tf_pad_epoch = ~0ull;
   int tf_pad_rows = 0, tf_pad_dinp = 0;

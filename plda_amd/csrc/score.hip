@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #pragma clang diagnostic ignored "-Wconditional-uninitialized"
 #include "score_bt4.inc"
 #pragma clang diagnostic pop
+#include "score_bf16x3.inc"
 
 // Tile schedule of trials_gemm_bt4_kernel for a btM x btN grid of 256 x 256 tiles: queue x (one per XCD) lists the tiles of
 // patches x, x + 8, ... (BPR x BPC tiles each, row-major inside a patch) -- the order the static walk of bt2 takes them in,
@@ -1412,6 +1413,28 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     h->prof_used++;
     h->prof_flop += 2.0 * (double)op.Kg_alg * (double)M * (double)Nt;
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
+  }
+  // opt-in arm: the contraction as three bf16 terms per operand (score_bf16x3.inc; PLDA_SCORE_DTYPE=bf16x3)
+  if (EPI == 0 && h->score_dtype == 1) {
+    const int KO = (int)round_up(op.KQ, 4) / 2, nsteps = KO / 2;          // k-octs (even), 16-k steps
+    PLDA_HIP(h, h->s_A16.reserve((size_t)3 * KO * op.Mpad * 16));
+    PLDA_HIP(h, h->s_B16.reserve((size_t)3 * KO * op.Npad * 16));
+    split_bf16x3_kernel<<<dim3((unsigned)(op.Mpad / 256), (unsigned)KO), 256, 0, h->stream>>>(h->s_Apk.as<f32x4>(), op.Mpad, op.KQ, h->s_A16.as<f32x4>());
+    split_bf16x3_kernel<<<dim3((unsigned)(op.Npad / 256), (unsigned)KO), 256, 0, h->stream>>>(h->s_Bpk.as<f32x4>(), op.Npad, op.KQ, h->s_B16.as<f32x4>());
+    static DeviceOnce once;
+    if (once.needed(h->device)) {
+      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
+      once.done(h->device);
+    }
+    const int b3M = (int)ceil_div(M, 256), b3N = (int)(op.Npad / 256);
+    const int pM = (int)ceil_div(b3M, BPR), pN = (int)ceil_div(b3N, BPC);
+    h->last_kernel = "trials_gemm_bf16x3_kernel";
+    trials_gemm_bf16x3_kernel<<<256, 512, B3_LDS, h->stream>>>(h->s_A16.as<f32x4>(), h->s_B16.as<f32x4>(), op.Mpad, op.Npad, nsteps,
+                                                               h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout, ld, M, Nt,
+                                                               b3M, b3N, pN, pM * pN);
+    PLDA_LAUNCH_CHECK(h);
+    if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
+    return PLDA_OK;
   }
   // persistent 256 x 256 kernel: when there are enough tiles to keep 256 CUs busy (PLDA_GEMM_VARIANT=20
   // forces the 128 x 128 kernel, 30 the 256 x 256 one, 31 its timeline-instrumented instantiation)
