@@ -1415,7 +1415,8 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     PLDA_HIP(h, hipEventRecord(ev0, h->stream));
   }
   // opt-in arm: the contraction as three bf16 terms per operand (score_bf16x3.inc; PLDA_SCORE_DTYPE=bf16x3)
-  if (EPI == 0 && h->score_dtype == 1) {
+  if (EPI == 0 && h->score_dtype == 1 && ld < (1ll << 22) &&
+      (int64_t)3 * ((int)round_up(op.KQ, 4) / 2) * std::max(op.Mpad, op.Npad) * 16 < (1ll << 32)) {
     const int KO = (int)round_up(op.KQ, 4) / 2, nsteps = KO / 2;          // k-octs (even), 16-k steps
     PLDA_HIP(h, h->s_A16.reserve((size_t)3 * KO * op.Mpad * 16));
     PLDA_HIP(h, h->s_B16.reserve((size_t)3 * KO * op.Npad * 16));
@@ -1423,15 +1424,28 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     split_bf16x3_kernel<<<dim3((unsigned)(op.Npad / 256), (unsigned)KO), 256, 0, h->stream>>>(h->s_Bpk.as<f32x4>(), op.Npad, op.KQ, h->s_B16.as<f32x4>());
     static DeviceOnce once;
     if (once.needed(h->device)) {
-      PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
+      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<4>),
+                           reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<8>), reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<12>),
+                           reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<16>)};
+      for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
       once.done(h->device);
     }
-    const int b3M = (int)ceil_div(M, 256), b3N = (int)(op.Npad / 256);
-    const int pM = (int)ceil_div(b3M, BPR), pN = (int)ceil_div(b3N, BPC);
+    const int b3M = (int)ceil_div(M, 256), b3N = (int)ceil_div(Nt, 128);       // 256 x 128 tiles (Npad is a multiple of 256)
+    const int pM = (int)ceil_div(b3M, B3_PR), pN = (int)ceil_div(b3N, B3_PC);
     h->last_kernel = "trials_gemm_bf16x3_kernel";
-    trials_gemm_bf16x3_kernel<<<256, 512, B3_LDS, h->stream>>>(h->s_A16.as<f32x4>(), h->s_B16.as<f32x4>(), op.Mpad, op.Npad, nsteps,
-                                                               h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout, ld, M, Nt,
-                                                               b3M, b3N, pN, pM * pN);
+#define B3L(MODE_)                                                                                                                      \
+  trials_gemm_bf16x3_kernel<MODE_><<<256, 512, B3_LDS, h->stream>>>(h->s_A16.as<f32x4>(), h->s_B16.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad,  \
+                                                                    nsteps, h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout, \
+                                                                    ld, M, Nt, b3M, b3N, pN, pM * pN, h->timeline.as<unsigned long long>())
+    if (h->gemm_variant == 63) {                  // the product kernel + clock stamps of workgroup 0 (plda_profile_timeline)
+      PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
+      B3L(16);
+      h->timeline_valid = true;
+    } else if (h->gemm_variant == 54) B3L(4);            // bounding arms (timing only): no DMA / no stores / neither
+    else if (h->gemm_variant == 58) B3L(8);
+    else if (h->gemm_variant == 62) B3L(12);
+    else B3L(0);
+#undef B3L
     PLDA_LAUNCH_CHECK(h);
     if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
     return PLDA_OK;
@@ -1713,7 +1727,8 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
   // The 256 x 256 kernel addresses a packed operand with 32-bit byte offsets: a side whose packed form
   // (KQ + 8 planes of 16 B per row) would reach 4 GiB is scored in row / column blocks, each side
   // packed once per block of its own dimension.  (C3's 1 M x 512 test side is 2.2 GB: one block.)
-  const int64_t kq8 = operand_kq(h, dn != nullptr, cs) + 8;
+  int64_t kq8 = operand_kq(h, dn != nullptr, cs) + 8;
+  if (h->score_dtype == 1) kq8 = std::max<int64_t>(kq8, 3 * std::max<int64_t>(round_up(kq8 - 8, 4) / 2, 4));   // the bf16 x 3 planes of the opt-in arm: 24 B per 4 k
   const int64_t cap = (((1ll << 32) - 1) / (kq8 * 16)) / 256 * 256;      // rows of one block
   const int64_t nrb = ceil_div(M, cap), ncb = ceil_div(Nt, cap);
   h->last_M = M; h->last_Nt = Nt; h->last_k = (int)(dn ? (buckets_usable(h, cs) ? D + cs->G - 1 : 2 * D) : D);
