@@ -175,6 +175,7 @@ def test_single_pass_eer_is_the_three_pass_eer(monkeypatch):
     ts = torch.randint(0, 200, (nt,), device=dev, generator=g)
     S = torch.randn((m, nt), dtype=torch.float32, device=dev, generator=g)
     S += 2.5 * (es[:, None] == ts[None, :]).float()
+    torch.cuda.synchronize()          # (the engines run on their own non-blocking streams: torch's kernels must have finished writing S)
     a, names, b = _eer_both(monkeypatch, S, nt, m, nt, es, ts)
     assert "eer.window_pass" in names and "eer.three_passes" not in names, names
     assert np.array_equal(a, b), (a, b)
