@@ -697,6 +697,37 @@ def main():
         except Exception as ex:      # a diagnostic: never fails the bench line
             clock_info = {"error": str(ex)[:200]}
 
+    # ---- the consumer of the trials matrix (scoring/scorePLDA.py:302-318 -> scoring/eer.py:68-76), outside the timed region:
+    #      the exact EER of the timed output (one full pass since round 5), and the same EER straight from the operands
+    #      (plda_score_eer_dev: the scores exist one <= 4 GiB row slab at a time).  Synthetic labels: speaker = index mod 5000.
+    eer_info = None
+    if rank == 0 and world == 1 and not emu and not args.no_extra and not args.targetdim:
+        try:
+            from plda_amd import eer as geer
+            nspk = max(2, min(5000, M // 2))
+            de = (torch.arange(M, device=dev, dtype=torch.int64) % nspk).contiguous()
+            dt_ = (torch.arange(Nt, device=dev, dtype=torch.int64) % nspk).contiguous()
+            torch.cuda.synchronize(dev)
+
+            def best(fn, reps=3):
+                b_, r_ = 1e30, None
+                for _ in range(reps):
+                    t0_ = time.perf_counter(); r_ = fn(); b_ = min(b_, time.perf_counter() - t0_)
+                return b_, r_
+            geer.eer_from_matrix_dev(eng, out.data_ptr(), Nt, M, Nt, de.data_ptr(), dt_.data_ptr())
+            t_m, r_m = best(lambda: geer.eer_from_matrix_dev(eng, out.data_ptr(), Nt, M, Nt, de.data_ptr(), dt_.data_ptr()))
+            geer.eer_from_operands_dev(eng, dU.data_ptr(), dnp, n_uniform, M, dT.data_ptr(), Nt, de.data_ptr(), dt_.data_ptr())
+            t_o, r_o = best(lambda: geer.eer_from_operands_dev(eng, dU.data_ptr(), dnp, n_uniform, M, dT.data_ptr(), Nt, de.data_ptr(), dt_.data_ptr()), 2)
+            eer_info = {"of_the_timed_matrix_ms": round(t_m * 1e3, 3), "matrix_read_GBps": round(M * Nt * 4 / t_m / 1e9, 1),
+                        "from_operands_ms": round(t_o * 1e3, 3), "from_operands_trials_per_s": M * Nt / t_o,
+                        "step_plus_matrix_eer_ms": round(elapsed / args.steps * 1e3 + t_m * 1e3, 3),
+                        "identical": bool(np.array_equal(r_m, r_o)), "eer": float(r_m[3]), "targets": int(r_m[4]),
+                        "how": "plda_eer_matrix_dev on the timed output (pilot on every 32nd row, ONE full pass, exact refinement on the window's "
+                               "scores); plda_score_eer_dev: the same from the operands, scores held one row slab at a time -- never %.0f GB" % (M * Nt * 4 / 1e9)}
+            # (the slabs re-packed the test side and the timed buffer is untouched)
+        except Exception as ex:      # noqa: BLE001 -- an extra leg
+            eer_info = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+
     # ---- OPT-IN arm (never `value`, never `roofline`): the same trials with the contraction as three bf16 terms per operand
     #      (PLDA_SCORE_DTYPE=bf16x3, csrc/score_bf16x3.inc) on a second handle, same operands, same output buffer.  north_star
     #      prescribes fp32 MFMA for the trials GEMM, and that kernel sits at its ceiling; this arm trades the matrix pipe's
@@ -801,6 +832,8 @@ def main():
         }
         if multi:
             res["multi_gpu"] = multi
+        if eer_info:
+            res["eer"] = eer_info
         if b3:
             res["bf16x3_arm"] = b3
         if td:

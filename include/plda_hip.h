@@ -302,6 +302,15 @@ int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_
                         const int64_t *denrol_spk, const int64_t *dtest_spk, double *out);
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn,
                    double *out);
+/* The EER of the trials between enrol models and test vectors WITHOUT the matrix (round 5): what the reference's caller
+ * wants from its M x Nt calls of MPlda_score (scoring/scorePLDA.py:302-318 -> scoring/eer.py:68-76) is these six numbers,
+ * not the scores -- BASELINE C4's matrix is 192 GB.  Arguments as plda_score_matrix_dev (transformed vectors, per-model
+ * counts or one count, optional z-norm statistics) plus the speaker ids of plda_eer_matrix_dev; the scores exist one row
+ * slab of <= 4 GiB at a time (scored by the trials GEMM, consumed by the one-pass EER, dropped).  The result is identical
+ * to plda_score_matrix_dev + plda_eer_matrix_dev.  out is a HOST array; the call synchronises the handle's stream. */
+int plda_score_eer_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform, int64_t M,
+                       const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
+                       const int64_t *denrol_spk, const int64_t *dtest_spk, double *out);
 /* Row-sharded trials matrix (one process per GPU, each holding a slab of enrol rows and ALL test
  * labels): the same three histogram passes over the local slab; after each pass the library calls
  * `reduce(ctx, hist, NULL, NULL)` with hist[2 * 2048] host counters to be SUMMED over the ranks in

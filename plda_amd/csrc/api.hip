@@ -65,6 +65,8 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
                       const int64_t *dtspk, double *out,
                       int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *) = nullptr, void *ctx = nullptr);
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out);
+int score_eer_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M, const double *dV, int64_t Nt,
+                     const double *dzmean, const double *dzstd, const int64_t *despk, const int64_t *dtspk, double *out);
 // comm.hip
 int comm_init(plda_handle *h, int nranks, int rank, const void *uid);
 int comm_init_custom(plda_handle *h, int nranks, int rank, const plda_collectives *t);
@@ -210,6 +212,7 @@ int plda_create(int device, plda_handle **out) {
     if (const char *v = std::getenv("PLDA_SORT_VARIANT")) h->sort_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_ZNORM_VARIANT")) h->znorm_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_EER_VARIANT")) h->eer_variant = std::atoi(v);
+    if (const char *v = std::getenv("PLDA_EER_SLAB_ROWS")) h->eer_slab_rows = std::atoll(v);
     if (const char *v = std::getenv("PLDA_HIP_TRACE")) h->trace_on = h->trace_print = std::atoi(v) != 0;
     if (const char *v = std::getenv("PLDA_HOST_VARIANT")) h->host_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_SWEEP_VARIANT")) h->sweep_variant = std::atoi(v);
@@ -237,7 +240,7 @@ int plda_destroy(plda_handle *h) {
                       &h->f_scatter, &h->f_sum, &h->f_W, &h->f_B, &h->fit_flag, &h->s_Apk, &h->s_Bpk, &h->s_rbias,
                       &h->s_rscale, &h->s_cbias, &h->s_rpair, &h->s_cpair, &h->tf_pad, &h->l_means, &h->l_priors, &h->l_xbar, &h->l_scalings,
                       &h->l_coef, &h->l_intercept, &h->l_evr, &h->timeline, &h->eigdc, &h->zn_rows, &h->zn_y, &h->zn_small, &h->hio_O[0], &h->hio_O[1],
-                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc, &h->eer_list[0], &h->eer_list[1], &h->s_A16, &h->s_B16};
+                      &h->bt4_cnt, &h->bt4_fringe, &h->cs_work, &h->comm_mm, &h->comm_mc, &h->eer_list[0], &h->eer_list[1], &h->s_A16, &h->s_B16, &h->eer_slab, &h->eer_smp};
     for (DevBuf *b : bufs) b->release();
     for (auto &t : h->bt4_tabs) t.tab.release();
     if (h->cs_pin) (void)hipHostFree(h->cs_pin);
@@ -1480,6 +1483,17 @@ int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_
     PLDA_LOCK(h);
     PLDA_TRY(set_device(h));
     return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out);
+  });
+}
+
+int plda_score_eer_dev(plda_handle *h, const double *dU, const int32_t *dn_enrol, int32_t n_uniform, int64_t M, const double *dV,
+                       int64_t Nt, const double *dzmean, const double *dzstd, const int64_t *denrol_spk, const int64_t *dtest_spk,
+                       double *out) {
+  return guarded(h, "plda_score_eer_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return score_eer_device(h, dU, dn_enrol, n_uniform, M, dV, Nt, dzmean, dzstd, denrol_spk, dtest_spk, out);
   });
 }
 

@@ -180,8 +180,10 @@ struct plda_handle {
   plda::DevBuf eigdc;            // eig_dc.hip workspace
   plda::DevBuf zn_rows, zn_y, zn_small;   // z-norm statistics by moments (score.hip)
   int znorm_variant = 0;         // PLDA_ZNORM_VARIANT=1: every LLR on the fused fp32 GEMM (A/B arm); 2: moments in five passes
+  plda::DevBuf eer_slab, eer_smp; // plda_score_eer_dev: the row slab of scores in flight; the pilot's gathered enrol rows
   plda::DevBuf eer_list[2];      // eer.hip, single-pass form: the impostor / target scores inside the pilot's key window
   int eer_variant = 0;           // PLDA_EER_VARIANT=1: always the three passes; 2: the single-pass form at every size (tests)
+  int64_t eer_slab_rows = 0;     // PLDA_EER_SLAB_ROWS: rows per slab of plda_score_eer_dev (0: <= 4 GiB of scores)
   int eer_last_passes = 0;       // full passes over the matrix the last plda_eer_matrix_dev made (1 or 3)
   const int *eigdc_flag = nullptr;   // device flag of the last direct decomposition (sym_eig_dc_status)
   int eig_variant = 0;           // PLDA_EIG_VARIANT: 0 = direct method where supported, 1 = block Jacobi always

@@ -272,13 +272,36 @@ struct EerSource {
   // the class totals come from the full pass
   bool windowed = false;
   unsigned long long base_p = 0, base_n = 0, tot_p = 0, tot_n = 0;
+  // a matrix that exists one row slab at a time (plda_score_eer_dev: the scores are produced, consumed and dropped): `scores`
+  // is nullptr, M / Nt / espk / tspk describe the whole matrix
+  const struct EerSlabs *slabs = nullptr;
+};
+// produce: enqueue the scores of rows [r0, r0 + rows) (rows <= slab_rows) on the handle's stream, say where they are;
+// sample: the same for every step-th row of the matrix (<= slab_rows of them) together with THOSE rows' speaker ids
+struct EerSlabs {
+  int64_t slab_rows;
+  int (*produce)(void *ctx, int64_t r0, int64_t rows, const float **scores, int64_t *ld);
+  int (*sample)(void *ctx, int64_t step, const float **scores, int64_t *ld, const int64_t **espk, int64_t *rows);
+  void *ctx;
 };
 
 // One histogram pass over the local data -> hh (host).  No reduction here: see eer_device.
 static int eer_pass(plda_handle *h, const EerSource &src, int shift, int nbits, unsigned prefix, int has_prefix,
                     unsigned long long *dhist, unsigned *dbelow, unsigned *dabove, std::vector<unsigned long long> &hh) {
   PLDA_HIP(h, hipMemsetAsync(dhist, 0, 2 * EER_BINS * 8, h->stream));
-  if (src.scores) {
+  if (src.slabs) {
+    for (int64_t r0 = 0; r0 < src.M; r0 += src.slabs->slab_rows) {
+      const int64_t rows = std::min(src.slabs->slab_rows, src.M - r0);
+      const float *sc = nullptr;
+      int64_t ld = 0;
+      PLDA_TRY(src.slabs->produce(src.slabs->ctx, r0, rows, &sc, &ld));
+      const int64_t strips = ceil_div(src.Nt, (int64_t)EER_STRIP);
+      const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(rows, (256 * 16) / strips));
+      const int64_t rows_per_wg = ceil_div(rows, slices);
+      eer_hist_strip_kernel<<<(unsigned)(strips * ceil_div(rows, rows_per_wg)), 256, 0, h->stream>>>(
+          sc, ld, rows, src.Nt, src.espk + r0, src.tspk, rows_per_wg, shift, nbits, prefix, has_prefix, dhist, dbelow, dabove, 1);
+    }
+  } else if (src.scores) {
     const int64_t Ms = ceil_div(src.M, src.row_step);          // rows this pass walks
     const unsigned grid = (unsigned)std::min<int64_t>(Ms, 256 * 16);
     if (grid) {
@@ -406,10 +429,13 @@ int eer_device(plda_handle *h, const EerSource &src, double *out, bool *window_m
 // ---- the single-pass form (see the header) ----
 constexpr int64_t EER_PILOT_STEP = 32;
 // Returns PLDA_OK with *done = true when `out` holds the result; *done = false: run the three passes.
-static int eer_matrix_windowed(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk,
-                               const int64_t *dtspk, double *out, bool *done) {
+// (full: the whole matrix -- in memory, or as slabs)
+static int eer_matrix_windowed(plda_handle *h, const EerSource &full, double *out, bool *done) {
   typedef unsigned __int128 u128;
   *done = false;
+  const float *dscores = full.scores;
+  const int64_t ld = full.ld, M = full.M, Nt = full.Nt;
+  const int64_t *despk = full.espk, *dtspk = full.tspk;
   TraceScope ts(h, "eer.pilot");
   PLDA_HIP(h, h->w[10].reserve(2 * EER_BINS * 8 + 64 + sizeof(EerWindowOut)));
   unsigned long long *dhist = h->w[10].as<unsigned long long>();
@@ -417,6 +443,14 @@ static int eer_matrix_windowed(plda_handle *h, const float *dscores, int64_t ld,
   EerWindowOut *dwo = reinterpret_cast<EerWindowOut *>(dhist + 2 * EER_BINS + 8);
   EerSource smp{dscores, ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
   smp.row_step = EER_PILOT_STEP;
+  int64_t pilot_step = EER_PILOT_STEP;
+  if (full.slabs) {
+    // the sample is produced (a small GEMM of its own) and must fit the slab buffer
+    pilot_step = std::max<int64_t>(EER_PILOT_STEP, ceil_div(M, full.slabs->slab_rows));
+    const float *sc = nullptr; const int64_t *se = nullptr; int64_t sld = 0, srows = 0;
+    PLDA_TRY(full.slabs->sample(full.slabs->ctx, pilot_step, &sc, &sld, &se, &srows));
+    smp = EerSource{sc, sld, srows, Nt, se, dtspk, nullptr, 0, nullptr, 0};
+  }
   // pilot, pass 0 on the sample: per coarse bin (top 11 key bits) the sample's g = FRR - FAR; the band |g| < delta of five
   // standard errors around the sample's crossing starts in coarse bin ca and ends in cb (often the same); one pass over
   // the sample per end then places the window's ends on sub-bins (22 key bits)
@@ -482,18 +516,23 @@ static int eer_matrix_windowed(plda_handle *h, const float *dscores, int64_t ld,
   const unsigned khi = (unsigned)khi64;
   const unsigned long long win = win_hi > win_lo ? win_hi - win_lo : 0;
   // the lists: the sample's in-window count scaled up, with room to spare; too wide a window is not worth a list
-  const unsigned long long cap = (unsigned long long)((double)win * (double)EER_PILOT_STEP * 2.0) + (1ull << 20);
+  const unsigned long long cap = (unsigned long long)((double)win * (double)pilot_step * 2.0) + (1ull << 20);
   if (cap > (unsigned long long)M * (unsigned long long)Nt / 8) return PLDA_OK;
   PLDA_HIP(h, h->eer_list[0].reserve((size_t)cap * 4));
   PLDA_HIP(h, h->eer_list[1].reserve((size_t)cap * 4));
   ts.next("eer.window_pass", (double)M * (double)Nt * 4.0, 2);
   PLDA_HIP(h, hipMemsetAsync(dwo, 0, sizeof(EerWindowOut), h->stream));
-  {
+  const int64_t slab = full.slabs ? full.slabs->slab_rows : M;
+  for (int64_t r0 = 0; r0 < M; r0 += slab) {
+    const int64_t rows = std::min(slab, M - r0);
+    const float *sc = dscores;
+    int64_t sld = ld;
+    if (full.slabs) PLDA_TRY(full.slabs->produce(full.slabs->ctx, r0, rows, &sc, &sld));
     const int64_t strips = ceil_div(Nt, (int64_t)EER_STRIP);
-    const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(M, (256 * 16) / strips));
-    const int64_t rows_per_wg = ceil_div(M, slices);
-    eer_window_strip_kernel<<<(unsigned)(strips * ceil_div(M, rows_per_wg)), 256, 0, h->stream>>>(
-        dscores, ld, M, Nt, despk, dtspk, rows_per_wg, key_score(klo), key_score(khi), dwo, h->eer_list[0].as<float>(), h->eer_list[1].as<float>(), cap);
+    const int64_t slices = std::max<int64_t>(1, std::min<int64_t>(rows, (256 * 16) / strips));
+    const int64_t rows_per_wg = ceil_div(rows, slices);
+    eer_window_strip_kernel<<<(unsigned)(strips * ceil_div(rows, rows_per_wg)), 256, 0, h->stream>>>(
+        sc, sld, rows, Nt, despk + r0, dtspk, rows_per_wg, key_score(klo), key_score(khi), dwo, h->eer_list[0].as<float>(), h->eer_list[1].as<float>(), cap);
     PLDA_LAUNCH_CHECK(h);
   }
   EerWindowOut wo;
@@ -527,7 +566,8 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
   h->eer_last_passes = 3;
   if (!reduce && h->eer_variant != 1 && (h->eer_variant == 2 || (double)M * (double)Nt >= 2.5e8) && M >= 4 * EER_PILOT_STEP) {
     bool done = false;
-    PLDA_TRY(eer_matrix_windowed(h, dscores, ld, M, Nt, despk, dtspk, out, &done));
+    const EerSource fullsrc{dscores, ld, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
+    PLDA_TRY(eer_matrix_windowed(h, fullsrc, out, &done));
     if (done) { h->eer_last_passes = 1; return PLDA_OK; }
   }
   TraceScope ts(h, "eer.three_passes", 3.0 * (double)M * (double)Nt * 4.0, 2);
@@ -535,6 +575,97 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
   s.reduce = reduce;
   s.ctx = ctx;
   return eer_device(h, s, out);
+}
+
+// ------------------------------------------------------------------------------------
+// EER of a trials matrix that is never held (round 5: plda_score_eer_dev).  The reference's caller scores every trial and
+// hands the scores to eer.py (scoring/scorePLDA.py:302-318 -> scoring/eer.py:68-76): what it wants is four numbers, not M x Nt
+// floats -- C4's matrix is 192 GB.  Here the scores exist one row slab at a time (<= 4 GiB): the pilot's sample is a GEMM of
+// every step-th enrol row, then every slab is scored (the test side packed once, the distinct enrol counts found once) and
+// consumed by the window pass; the three-pass form, should the window miss, re-scores the slabs per pass.  Identical to
+// plda_eer_matrix_dev on the materialised matrix (the kernels give a trial the same bits wherever its tile lies).
+// Not yet inside the GEMM's epilogue: the slab is written and read back once, through HBM.
+// ------------------------------------------------------------------------------------
+__global__ void eer_gather_rows_kernel(const double *__restrict__ X, int D, int64_t step, int64_t rows, double *__restrict__ out) {
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) out[r * D + d] = X[r * step * D + d];
+}
+__global__ void eer_gather_meta_kernel(const int32_t *__restrict__ n, const double *__restrict__ zm, const double *__restrict__ zs,
+                                       const int64_t *__restrict__ spk, int64_t step, int64_t rows, int32_t *__restrict__ on,
+                                       double *__restrict__ ozm, double *__restrict__ ozs, int64_t *__restrict__ ospk) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  if (n) on[r] = n[r * step];
+  if (zm) { ozm[r] = zm[r * step]; ozs[r] = zs[r * step]; }
+  ospk[r] = spk[r * step];
+}
+
+struct ScoreEerCtx {
+  plda_handle *h;
+  const double *dU; const int32_t *dn; int n_uniform; int64_t M; const double *dV; int64_t Nt;
+  const double *dzm, *dzs; const int64_t *despk;
+  CountSet cs; bool has_cs; bool packedB;
+  float *slab; int64_t slab_rows;
+};
+static int score_eer_produce(void *vc, int64_t r0, int64_t rows, const float **scores, int64_t *ld) {
+  auto *c = static_cast<ScoreEerCtx *>(vc);
+  const int D = c->h->Dout;
+  PLDA_TRY(score_matrix_device(c->h, c->dU + r0 * D, c->dn ? c->dn + r0 : nullptr, c->n_uniform, rows, c->dV, c->Nt,
+                               c->dzm ? c->dzm + r0 : nullptr, c->dzs ? c->dzs + r0 : nullptr, c->slab, c->Nt, c->packedB,
+                               c->has_cs ? &c->cs : nullptr));
+  c->packedB = true;
+  *scores = c->slab; *ld = c->Nt;
+  return PLDA_OK;
+}
+static int score_eer_sample(void *vc, int64_t step, const float **scores, int64_t *ld, const int64_t **espk, int64_t *rows) {
+  auto *c = static_cast<ScoreEerCtx *>(vc);
+  plda_handle *h = c->h;
+  const int D = h->Dout;
+  const int64_t Ms = ceil_div(c->M, step);
+  const size_t oU = 0, oZ = round_up((size_t)Ms * D * 8, 256), oS = oZ + round_up((size_t)Ms * 16, 256), oN = oS + round_up((size_t)Ms * 8, 256);
+  PLDA_HIP(h, h->eer_smp.reserve(oN + (size_t)Ms * 4 + 256));
+  char *b = h->eer_smp.as<char>();
+  double *sU = reinterpret_cast<double *>(b + oU), *szm = reinterpret_cast<double *>(b + oZ), *szs = szm + Ms;
+  int64_t *sspk = reinterpret_cast<int64_t *>(b + oS);
+  int32_t *sn = reinterpret_cast<int32_t *>(b + oN);
+  eer_gather_rows_kernel<<<(unsigned)Ms, 256, 0, h->stream>>>(c->dU, D, step, Ms, sU);
+  eer_gather_meta_kernel<<<(unsigned)ceil_div(Ms, 256), 256, 0, h->stream>>>(c->dn, c->dzm, c->dzs, c->despk, step, Ms, sn, szm, szs, sspk);
+  PLDA_LAUNCH_CHECK(h);
+  PLDA_TRY(score_matrix_device(h, sU, c->dn ? sn : nullptr, c->n_uniform, Ms, c->dV, c->Nt, c->dzm ? szm : nullptr, c->dzm ? szs : nullptr,
+                               c->slab, c->Nt, c->packedB, c->has_cs ? &c->cs : nullptr));
+  c->packedB = true;
+  *scores = c->slab; *ld = c->Nt; *espk = sspk; *rows = Ms;
+  return PLDA_OK;
+}
+
+int score_eer_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M, const double *dV, int64_t Nt,
+                     const double *dzmean, const double *dzstd, const int64_t *despk, const int64_t *dtspk, double *out) {
+  if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score_eer: model not fitted");
+  if (!dU || !dV || !despk || !dtspk || !out || M <= 0 || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_eer: bad argument");
+  if (!dn && n_uniform <= 0) return fail(h, PLDA_E_INVAL, "score_eer: n_uniform must be > 0 when n_enrol is NULL");
+  ScoreEerCtx c{h, dU, dn, n_uniform, M, dV, Nt, (dzmean && dzstd) ? dzmean : nullptr, (dzmean && dzstd) ? dzstd : nullptr, despk};
+  c.has_cs = false; c.packedB = false;
+  if (dn) { PLDA_TRY(score_count_set_device(h, dn, M, &c.cs)); c.has_cs = true; }
+  // slabs of <= 4 GiB of scores, whole 256-row tiles, at least one tile row
+  int64_t rows = std::max<int64_t>(256, (((int64_t)4 << 30) / 4 / Nt) / 256 * 256);
+  if (h->eer_slab_rows > 0) rows = round_up(h->eer_slab_rows, 256);      // PLDA_EER_SLAB_ROWS: small slabs for the tests
+  rows = std::min(rows, round_up(M, 256));
+  c.slab_rows = rows;
+  PLDA_HIP(h, h->eer_slab.reserve((size_t)rows * Nt * 4));
+  c.slab = h->eer_slab.as<float>();
+  const EerSlabs sl{rows, score_eer_produce, score_eer_sample, &c};
+  EerSource src{nullptr, Nt, M, Nt, despk, dtspk, nullptr, 0, nullptr, 0};
+  src.slabs = &sl;
+  h->prep_valid = false;           // (the slabs pack the test side themselves)
+  h->eer_last_passes = 3;
+  if (h->eer_variant != 1 && (h->eer_variant == 2 || (double)M * (double)Nt >= 2.5e8) && M >= 4 * EER_PILOT_STEP) {
+    bool done = false;
+    PLDA_TRY(eer_matrix_windowed(h, src, out, &done));
+    if (done) { h->eer_last_passes = 1; return PLDA_OK; }
+  }
+  TraceScope ts(h, "eer.three_passes (slabs re-scored per pass)", 3.0 * (double)M * (double)Nt * 4.0, 2);
+  return eer_device(h, src, out);
 }
 
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out) {

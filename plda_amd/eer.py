@@ -28,6 +28,18 @@ def eer_from_matrix_dev(engine, dscores, ld, m, nt, denrol_spk, dtest_spk):
     return out
 
 
+def eer_from_operands_dev(engine, dU, dn, n_uniform, m, dV, nt, denrol_spk, dtest_spk, dzmean=None, dzstd=None):
+    """The EER of the m x nt trials between HBM-resident transformed enrol / test vectors without the score matrix
+    (`plda_score_eer_dev`): arguments as `MPlda.score_matrix_dev` plus the int64 speaker ids of both sides.  Returns the
+    6-vector of `eer_from_matrix_dev`, identical to scoring the matrix first."""
+    out = np.zeros(6)
+    p = lambda x: C.c_void_p(int(x)) if x else None      # noqa: E731
+    N.check(engine._h, engine._lib.plda_score_eer_dev(engine._h, p(dU), p(dn), int(n_uniform), int(m), p(dV), int(nt),
+                                                      p(dzmean), p(dzstd), p(denrol_spk), p(dtest_spk),
+                                                      C.c_void_p(out.ctypes.data)))
+    return out
+
+
 def format_line(far, frr, threshold):
     """The line eer.py:72-73 writes."""
     return "EER = %.2f%%, FAR = %.2f, FRR=%.2f, Threshold = %e\n" % ((far + frr) / 2 * 100, far, frr, threshold)

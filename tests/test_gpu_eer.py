@@ -213,3 +213,53 @@ def test_single_pass_eer_forced_on_small_and_awkward_inputs(monkeypatch, case):
     sub = Sh[:, :nt]
     ref = onp.eer(sub[~tgt], sub[tgt])
     assert tuple(a[1:4]) == ref[1:] and a[0] == pytest.approx(ref[0], rel=1e-12)
+
+
+@pytest.mark.parametrize("case", ["uniform_windowed", "mixed_znorm_windowed", "three_pass_slabs", "big_uniform"])
+def test_eer_without_the_matrix(monkeypatch, case):
+    """plda_score_eer_dev (round 5): the EER of the trials between transformed enrol / test vectors with the scores held one
+    row slab at a time -- what scoring/scorePLDA.py:302-318 -> scoring/eer.py:68-76 computes from M x Nt calls of MPlda_score.
+    Identical (all six numbers) to scoring the matrix and taking plda_eer_matrix_dev of it: several slabs per pass
+    (PLDA_EER_SLAB_ROWS), the single-pass form (forced at small sizes, natural at 20 000 x 20 000) and the three-pass form
+    that re-scores the slabs per pass, uniform and mixed enrol counts, z-normalised rows."""
+    import torch
+    from plda_amd import MPlda, eer
+    dev = torch.device("cuda", 0)
+    d, m, nt, k = (48, 3000, 2500, 40) if case != "big_uniform" else (32, 20000, 20000, 200)
+    rng = np.random.default_rng(sum(map(ord, case)))
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    model = (rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy())
+    es, ts = rng.integers(0, k, m), rng.integers(0, k, nt)
+    spk = rng.standard_normal((k, d)) * 1.2                       # speaker structure, so that the EER is not 50 %
+    U = torch.from_numpy(spk[es] + rng.standard_normal((m, d))).to(dev)
+    V = torch.from_numpy(spk[ts] + rng.standard_normal((nt, d))).to(dev)
+    des, dts = torch.from_numpy(es).to(dev), torch.from_numpy(ts).to(dev)
+    mixed = case == "mixed_znorm_windowed"
+    dn = torch.from_numpy(rng.integers(1, 6, m).astype(np.int32)).to(dev) if mixed else None
+    zm = torch.from_numpy(rng.standard_normal(m) * 3.0).to(dev) if mixed else None
+    zs = torch.from_numpy(rng.random(m) * 2.0 + 0.5).to(dev) if mixed else None
+    monkeypatch.setenv("PLDA_EER_VARIANT", "1" if case == "three_pass_slabs" else ("0" if case == "big_uniform" else "2"))
+    if case != "big_uniform":
+        monkeypatch.setenv("PLDA_EER_SLAB_ROWS", "512")           # 6 slabs
+    eng = MPlda(0)
+    eng.set_model(*model)
+    monkeypatch.setenv("PLDA_EER_VARIANT", "1")
+    ref_eng = MPlda(0)
+    ref_eng.set_model(*model)
+    S = torch.empty((m, nt), dtype=torch.float32, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    ref_eng.score_matrix_dev(U.data_ptr(), ptr(dn), 0 if mixed else 2, m, V.data_ptr(), nt, S.data_ptr(), nt, ptr(zm), ptr(zs))
+    ref_eng.synchronize()
+    ref = eer.eer_from_matrix_dev(ref_eng, S.data_ptr(), nt, m, nt, des.data_ptr(), dts.data_ptr())
+    eng.trace_enable(True)
+    got = eer.eer_from_operands_dev(eng, U.data_ptr(), ptr(dn), 0 if mixed else 2, m, V.data_ptr(), nt, des.data_ptr(), dts.data_ptr(),
+                                    ptr(zm), ptr(zs))
+    names = [sp["name"] for sp in eng.trace_read()]
+    assert np.array_equal(got, ref), (case, got, ref)
+    assert 0.0 < got[3] < 0.45 and got[4] + got[5] == m * nt
+    if case == "three_pass_slabs":
+        assert any(n.startswith("eer.three_passes") for n in names), names
+    else:
+        assert "eer.pilot" in names, names
+    if case == "big_uniform":
+        assert "eer.window_pass" in names and not any(n.startswith("eer.three_passes") for n in names), names
