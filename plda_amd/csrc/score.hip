@@ -469,6 +469,9 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
 // test side of the bucketed form, the extra planes: dq_g[j] = -1/2 sum_d (g_gd - g_0d) v_jd^2 for g = 1 .. G - 1 (fp64, rounded
 // once), zero beyond.  The D main planes, q_0 and cpair come from prep_side_kernel<1> with bucket 0's coefficients.  A
 // second read of the rows (L2 mostly): Nt D 8 B against the GEMM's Nt M (D + G) flop.
+// (round 5, second version: the coefficient differences of a group of four buckets live in REGISTERS for the 16 rows a wave
+//  handles -- per lane eight chunks of 64 dimensions, D <= 512 -- so that the inner loop is one 8-byte load and four FMAs per
+//  element; the first version re-read five coefficients from L1 per element and took 1.26 ms for C4's 2.4 GB of test rows.)
 __global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__restrict__ V, const double *__restrict__ coefG, int G, int D,
                                                                 int64_t R, int64_t Rpad, int KQm, int KQx, float *__restrict__ P) {
   __shared__ float q[CS_MAX][65];
@@ -477,20 +480,44 @@ __global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__
   for (int i = threadIdx.x; i < CS_MAX * 65; i += 256) (&q[0][0])[i] = 0.f;
   __syncthreads();
   const int S = 2 * D + 1;
-  for (int j = 0; j < 16; ++j) {
-    const int64_t row = row0 + wave * 16 + j;
-    if (row >= R) break;
-    const double *v = V + row * (int64_t)D;
-    for (int g0 = 1; g0 < G; g0 += 4) {
+  const int64_t wrow0 = row0 + wave * 16;
+  const bool cached = D <= 512;
+  for (int g0 = 1; g0 < G && wrow0 < R; g0 += 4) {
+    const bool h1 = g0 + 1 < G, h2 = g0 + 2 < G, h3 = g0 + 3 < G;
+    const double *c0 = coefG + (size_t)g0 * S + D;
+    double dc[4][8];
+    if (cached) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int d = lane + 64 * c;
+        const bool ok = d < D;
+        const double gb = ok ? coefG[D + d] : 0.0;
+        dc[0][c] = ok ? c0[d] - gb : 0.0;
+        dc[1][c] = ok && h1 ? c0[S + d] - gb : 0.0;
+        dc[2][c] = ok && h2 ? c0[2 * S + d] - gb : 0.0;
+        dc[3][c] = ok && h3 ? c0[3 * S + d] - gb : 0.0;
+      }
+    }
+    for (int j = 0; j < 16; ++j) {
+      const int64_t row = wrow0 + j;
+      if (row >= R) break;
+      const double *v = V + row * (int64_t)D;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      const double *c0 = coefG + (size_t)g0 * S + D;
-      const bool h1 = g0 + 1 < G, h2 = g0 + 2 < G, h3 = g0 + 3 < G;
-      for (int d = lane; d < D; d += 64) {
-        const double x = v[d], x2 = x * x, gb = coefG[D + d];
-        a0 += (c0[d] - gb) * x2;
-        if (h1) a1 += (c0[S + d] - gb) * x2;
-        if (h2) a2 += (c0[2 * S + d] - gb) * x2;
-        if (h3) a3 += (c0[3 * S + d] - gb) * x2;
+      if (cached) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int d = lane + 64 * c;
+          const double x = d < D ? v[d] : 0.0, x2 = x * x;
+          a0 = fma(dc[0][c], x2, a0); a1 = fma(dc[1][c], x2, a1); a2 = fma(dc[2][c], x2, a2); a3 = fma(dc[3][c], x2, a3);
+        }
+      } else {
+        for (int d = lane; d < D; d += 64) {
+          const double x = v[d], x2 = x * x, gb = coefG[D + d];
+          a0 += (c0[d] - gb) * x2;
+          if (h1) a1 += (c0[S + d] - gb) * x2;
+          if (h2) a2 += (c0[2 * S + d] - gb) * x2;
+          if (h3) a3 += (c0[3 * S + d] - gb) * x2;
+        }
       }
       a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2); a3 = wave_sum_f64(a3);
       if (lane == 0) {
