@@ -1866,6 +1866,26 @@ __global__ void znorm_rows_kernel(const double *__restrict__ X, const double *__
   if (lane == 0) o[D] = -0.5 * (acc + coef[3 * D]);
 }
 
+// the same with the pilot shift applied and the constant column appended: At[i] = [ca x_i - p ; r_i - p_D ; 1]  (D + 2 wide).
+// For D + 2 > 208, where the SYRK cannot form its rows on the way into LDS (syrk_tri_kernel<true>): rows written once,
+// read once by the block SYRK -- three transfers of the cohort instead of the six of the five-pass form.
+__global__ void znorm_rows_shift_kernel(const double *__restrict__ X, const double *__restrict__ coef, const double *__restrict__ shift,
+                                        int D, int64_t R, double *__restrict__ At) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const double *x = X + row * (int64_t)D;
+  double *o = At + row * (int64_t)(D + 2);
+  double acc = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    const double xv = x[d];
+    o[d] = __dsub_rn(__dmul_rn(coef[d], xv), shift[d]);
+    acc = fma(coef[D + d] * xv, xv, acc);
+  }
+  acc = wave_sum_f64(acc);
+  if (lane == 0) { o[D] = -0.5 * (acc + coef[3 * D]) - shift[D]; o[D + 1] = 1.0; }
+}
+
 // column sums of a [R, C] matrix, deterministic two stages: grid (ceil(C / 64), ZS) then one block
 constexpr int ZS = 128;
 __global__ __launch_bounds__(256) void znorm_colsum_partial_kernel(const double *__restrict__ A, int64_t R, int C,
@@ -1989,6 +2009,17 @@ static int znorm_stats_moments(plda_handle *h, const double *dT, int64_t Nb, con
       PLDA_TRY(syrk_znorm_f64(h, D, Nb, dT, coef, shift, C2, &used));
       if (used) znorm_moments_kernel<<<(unsigned)ceil_div((int64_t)D1 * D1, 256), 256, 0, h->stream>>>(C2, shift, D1, 1.0 / (double)Nb, mom, Cov);
       PLDA_LAUNCH_CHECK(h);
+    }
+    if (!used && h->znorm_variant != 2 && D2 <= 514) {
+      // wider than the one-read kernel takes: shifted augmented rows written once, the block SYRK reads them once
+      PLDA_HIP(h, h->zn_rows.reserve((size_t)Nb * D2 * 8));
+      double *At = h->zn_rows.as<double>();
+      znorm_rows_shift_kernel<<<(unsigned)ceil_div(Nb, wpb), wpb * 64, 0, h->stream>>>(dT, coef, shift, D, Nb, At);
+      PLDA_LAUNCH_CHECK(h);
+      PLDA_TRY(gemm_f64(h, D2, D2, Nb, 1.0, At, 1, D2, At, D2, 1, nullptr, 0.0, C2, D2));
+      znorm_moments_kernel<<<(unsigned)ceil_div((int64_t)D1 * D1, 256), 256, 0, h->stream>>>(C2, shift, D1, 1.0 / (double)Nb, mom, Cov);
+      PLDA_LAUNCH_CHECK(h);
+      used = true;
     }
     if (!used) {
       PLDA_HIP(h, h->zn_rows.reserve((size_t)Nb * D1 * 8));

@@ -197,7 +197,7 @@ def test_sharded_scorer_on_device_tensors(engine, oracle):
 
 
 @pytest.mark.parametrize("d,nb,nmodels", [(48, 391, 40), (200, 1000, 64), (206, 650, 4), (207, 600, 5), (208, 700, 3), (230, 520, 7), (10, 2, 4),
-                                          (33, 1, 6), (64, 70, 9)])
+                                          (33, 1, 6), (64, 70, 9), (256, 2300, 6)])
 @pytest.mark.parametrize("variant", ["0", "1", "2"])
 def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant):
     """MPlda_norm (pldamodule.cpp:196-256).  Arm 0 (default): statistics from the cohort's fp64 moments -- the LLR is
@@ -205,8 +205,8 @@ def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant
     pilot shift + the (D + 2)-wide SYRK that forms its rows on the way into LDS), arm 2: the same moments in the five
     passes of rounds 2-4 (also what D + 2 > 208 takes); both held to 1e-10 against the oracle's explicit per-pair
     loop; arm 1: every LLR on the fp32 GEMM with the fused sum / sum-of-squares epilogue, held to the 1e-4 of
-    north_star.  Shapes straddle the one-read kernel's limit (D + 2 = 208 | 209), the older (D + 1)-wide SYRK's kernel
-    choice, a cohort of 70 rows (the pilot takes 64) and the degenerate cohorts of one and two rows (std = 0 exactly
+    north_star.  Shapes straddle the one-read kernel's limit (D + 2 = 208 | 209: beyond it arm 0 writes the shifted rows
+    once and the block SYRK reads them once; 256 x 2300 reaches that SYRK), the older (D + 1)-wide SYRK's kernel choice, a cohort of 70 rows (the pilot takes 64) and the degenerate cohorts of one and two rows (std = 0 exactly
     for one row, as the reference's population std)."""
     monkeypatch.setenv("PLDA_ZNORM_VARIANT", variant)
     from plda_amd import MPlda
