@@ -230,6 +230,34 @@ def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant
         assert (np.abs(gs - rs) <= tol * np.maximum(rs, 1e-3 * scale)).all(), (np.abs(gs - rs) / rs).max()
 
 
+@pytest.mark.parametrize("d", [1, 24, 200])
+def test_llr_with_mixed_counts_against_the_closed_form_gaussian_ratio(d):
+    """The same known answer (scipy.stats, neither the oracle nor the engine's kernels) for enrol models with DIFFERENT
+    utterance counts -- the bucketed form of the trials GEMM (one column-bias vector per distinct count) and the fp64
+    trial-list kernel: per dimension the joint covariance of (enrol mean of n_i vectors, test vector) is
+    [[psi + 1/n_i, psi], [psi, psi + 1]]."""
+    from scipy.stats import norm
+    from plda_amd import MPlda
+    rng = np.random.default_rng(300 + d)
+    psi = np.sort(rng.random(d) * 5.0 + 1e-3)[::-1].copy()
+    eng = MPlda(0)
+    eng.set_model(np.zeros(d), np.eye(d), psi)
+    m, nt = 37, 41
+    n = rng.choice([1, 2, 5, 11], m).astype(np.int32)
+    n[:4] = [1, 2, 5, 11]
+    U, V = rng.standard_normal((m, d)) * 1.5, rng.standard_normal((nt, d)) * 1.5
+    inv = 1.0 / n[:, None].astype(np.float64)
+    cmean = (psi[None, :] / (psi[None, :] + inv))[:, None, :] * U[:, None, :]
+    cvar = (psi[None, :] + 1.0 - psi[None, :] ** 2 / (psi[None, :] + inv))[:, None, :]
+    ref = (norm.logpdf(V[None, :, :], cmean, np.sqrt(cvar)) - norm.logpdf(V[None, :, :], 0.0, np.sqrt(psi + 1.0))).sum(-1)
+    got = eng.score_matrix((n, U), (1, V))
+    assert eng.score_last_shape()[2] == d + 3                      # four distinct counts: three extra contraction columns
+    assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
+    e, t = np.repeat(np.arange(m), nt), np.tile(np.arange(nt), m)
+    lst = eng.score_trials((n, U), (1, V), e, t).reshape(m, nt)
+    assert np.abs(lst - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("d,n_enrol", [(1, 1), (1, 4), (7, 3), (200, 1)])
 def test_llr_against_the_closed_form_gaussian_ratio(d, n_enrol):
     """A known answer that is not the oracle: in the PLDA space (diagonal psi, unit within-class variance) the mean u
