@@ -302,6 +302,15 @@ int plda_eer_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_
                         const int64_t *denrol_spk, const int64_t *dtest_spk, double *out);
 int plda_eer_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn,
                    double *out);
+/* The points of the DET curve scoring/eer.py:34-62 plots (bob.measure.plot.det(negatives, positives, 100); definition
+ * restated, bob absent): n_points (2 .. 2047) thresholds spread evenly from the smallest to the largest score, accumulated in
+ * float64; far[i] = #{impostor >= t_i} / Nn, frr[i] = #{target < t_i} / Np (HOST arrays; thresholds nullable).  The plot's axes
+ * are the normal deviates of the two rates (plda_amd.eer.ppndf); drawing it stays with the caller. */
+int plda_det_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt,
+                        const int64_t *denrol_spk, const int64_t *dtest_spk, int32_t n_points, double *far, double *frr,
+                        double *thresholds);
+int plda_det_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn, int32_t n_points,
+                   double *far, double *frr, double *thresholds);
 /* The EER of the trials between enrol models and test vectors WITHOUT the matrix (round 5): what the reference's caller
  * wants from its M x Nt calls of MPlda_score (scoring/scorePLDA.py:302-318 -> scoring/eer.py:68-76) is these six numbers,
  * not the scores -- BASELINE C4's matrix is 192 GB.  Arguments as plda_score_matrix_dev (transformed vectors, per-model

@@ -237,3 +237,31 @@ def eer(negatives, positives):
     pred = np.abs(far - frr)
     best = len(pred) - 1 - int(np.argmin(pred[::-1]))                  # later candidate on ties
     return float(mids[best]), float(far[best]), float(frr[best]), float(0.5 * (far[best] + frr[best]))
+
+
+def det(negatives, positives, n_points):
+    """The points of the DET curve scoring/eer.py:34-62 plots through bob.measure.plot.det(negatives, positives, 100)
+    (absent, un-pinned: published definition restated; PARITY UNPINNED): n_points thresholds from the smallest to the
+    largest score of the union, accumulated as t_0 = min, t_{i+1} = t_i + (max - min) / (n_points - 1) in float64;
+    FAR_i = #{neg >= t_i} / Nn, FRR_i = #{pos < t_i} / Np (bob.measure.farfrr).  Returns (thresholds, far, frr); the plot's
+    axes are ppndf (the normal deviate) of the two rates: `ppndf` below."""
+    neg = np.sort(np.asarray(negatives, np.float32).astype(np.float64))
+    pos = np.sort(np.asarray(positives, np.float32).astype(np.float64))
+    lo = min(neg[0], pos[0]); hi = max(neg[-1], pos[-1])
+    step = (hi - lo) / (n_points - 1.0)
+    thr = np.empty(n_points)
+    t = lo
+    for i in range(n_points):
+        thr[i] = t
+        t += step
+    far = (len(neg) - np.searchsorted(neg, thr, side="left")) / len(neg)
+    frr = np.searchsorted(pos, thr, side="left") / len(pos)
+    return thr, far, frr
+
+
+def ppndf(p):
+    """The normal deviate of a rate as bob.measure.ppndf defines it: the probit of p clipped to [eps, 1 - eps],
+    eps = 2.2204e-16 (restated)."""
+    from scipy.special import ndtri
+    eps = 2.2204e-16
+    return ndtri(np.clip(np.asarray(p, np.float64), eps, 1.0 - eps))

@@ -80,6 +80,8 @@ SIGNATURES = {
     "plda_dvector_pool_dev": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _i64, _i32, _i32, _vp]),
     "plda_eer_matrix_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "plda_eer_lists": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "plda_det_matrix_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "plda_det_lists": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "plda_score_eer_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "plda_eer_matrix_sharded_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "plda_comm_unique_id": (C.c_int, [_vp, _i64]),

@@ -65,6 +65,10 @@ int eer_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t 
                       const int64_t *dtspk, double *out,
                       int (*reduce)(void *, unsigned long long *, unsigned *, unsigned *) = nullptr, void *ctx = nullptr);
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out);
+int det_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk, const int64_t *dtspk,
+                      int npoints, double *far, double *frr, double *thresholds);
+int det_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, int npoints, double *far, double *frr,
+                     double *thresholds);
 int score_eer_device(plda_handle *h, const double *dU, const int32_t *dn, int n_uniform, int64_t M, const double *dV, int64_t Nt,
                      const double *dzmean, const double *dzstd, const int64_t *despk, const int64_t *dtspk, double *out);
 // comm.hip
@@ -1506,6 +1510,33 @@ int plda_eer_matrix_sharded_dev(plda_handle *h, const float *dscores, int64_t ld
     if (!reduce) return fail(h, PLDA_E_INVAL, "eer_matrix_sharded: a reduction callback is required");
     PLDA_TRY(set_device(h));
     return eer_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, out, reduce, ctx);
+  });
+}
+
+int plda_det_matrix_dev(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *denrol_spk,
+                        const int64_t *dtest_spk, int32_t n_points, double *far, double *frr, double *thresholds) {
+  return guarded(h, "plda_det_matrix_dev", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    PLDA_TRY(set_device(h));
+    return det_matrix_device(h, dscores, ld, M, Nt, denrol_spk, dtest_spk, n_points, far, frr, thresholds);
+  });
+}
+
+int plda_det_lists(plda_handle *h, const float *pos, int64_t np, const float *neg, int64_t nn, int32_t n_points, double *far,
+                   double *frr, double *thresholds) {
+  return guarded(h, "plda_det_lists", [&]() -> int {
+    if (!h) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    if (!pos || !neg || !far || !frr || np <= 0 || nn <= 0)
+      return fail(h, PLDA_E_INVAL, "det: need at least one target and one impostor score");
+    PLDA_TRY(set_device(h));
+    Tmp dP, dN;
+    PLDA_TRY(upload(h, dP, pos, (size_t)np * 4));
+    PLDA_TRY(upload(h, dN, neg, (size_t)nn * 4));
+    const int rc = det_lists_device(h, dP.as<float>(), np, dN.as<float>(), nn, n_points, far, frr, thresholds);
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    return rc;
   });
 }
 

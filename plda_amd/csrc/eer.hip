@@ -668,6 +668,124 @@ int score_eer_device(plda_handle *h, const double *dU, const int32_t *dn, int n_
   return eer_device(h, src, out);
 }
 
+// ------------------------------------------------------------------------------------
+// DET points (round 5): the numbers behind scoring/eer.py:34-62's plot -- bob.measure.plot.det(negatives, positives, 100)
+// evaluates farfrr at n thresholds spread evenly from the smallest to the largest score (bob absent: definition
+// restated in oracle/plda_oracle_np.py:det, PARITY UNPINNED; the plotting itself stays out of scope).  Two passes over
+// the scores: the extreme keys, then per class a histogram of k(s) = #{i : t_i <= s} -- a guess from the division,
+// corrected against the fp64 threshold table the host accumulated exactly as the definition does -- from which
+// FAR_i = #{neg : k >= i + 1} / Nn and FRR_i = #{pos : k <= i} / Np follow as suffix / prefix sums.  n <= 2047.
+// ------------------------------------------------------------------------------------
+constexpr int DET_MAX = 2047;
+__global__ __launch_bounds__(256) void det_minmax_kernel(const float *__restrict__ scores, int64_t ld, int64_t M, int64_t Nt,
+                                                         unsigned *__restrict__ mm /*[0] min key, [1] max key*/) {
+  unsigned lo = 0xffffffffu, hi = 0u;
+  const int64_t total = M * Nt;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const unsigned k = score_key(scores[(idx / Nt) * ld + idx % Nt]);
+    lo = k < lo ? k : lo; hi = k > hi ? k : hi;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+    lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(mm, lo); atomicMax(mm + 1, hi); }
+}
+// cls < 0: the class of trial (i, j) is espk[i] == tspk[j]; else every score is of class cls (the two-list form, M = 1)
+__global__ __launch_bounds__(256) void det_hist_kernel(const float *__restrict__ scores, int64_t ld, int64_t M, int64_t Nt,
+                                                       const int64_t *__restrict__ espk, const int64_t *__restrict__ tspk, int cls,
+                                                       const double *__restrict__ thr, int n, double lo, double inv_step,
+                                                       unsigned long long *__restrict__ hist /*[2][DET_MAX + 1]*/) {
+  __shared__ unsigned lh[2][DET_MAX + 1];
+  __shared__ double ts[DET_MAX + 1];
+  for (int i = threadIdx.x; i < 2 * (DET_MAX + 1); i += 256) (&lh[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < n; i += 256) ts[i] = thr[i];
+  __syncthreads();
+  const int64_t total = M * Nt;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / Nt, c = idx % Nt;
+    const double sc = (double)scores[r * ld + c];
+    int k = (int)((sc - lo) * inv_step) + 1;            // guess of #{i : t_i <= s}
+    k = k < 0 ? 0 : (k > n ? n : k);
+    while (k > 0 && ts[k - 1] > sc) --k;                // t_{k-1} <= s must hold
+    while (k < n && ts[k] <= sc) ++k;                   // and t_k > s
+    const int cl = cls >= 0 ? cls : (espk[r] == tspk[c] ? 1 : 0);
+    atomicAdd(&lh[cl][k], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * (DET_MAX + 1); i += 256) {
+    const unsigned v = (&lh[0][0])[i];
+    if (v) atomicAdd(hist + i, (unsigned long long)v);
+  }
+}
+
+// parts: up to two (scores, ld, M, Nt, cls) pieces -- the labelled matrix (cls = -1), or the impostor and target lists
+struct DetPart { const float *scores; int64_t ld, M, Nt; int cls; };
+static int det_device(plda_handle *h, const DetPart *parts, int nparts, const int64_t *despk, const int64_t *dtspk, int npoints,
+                      double *far, double *frr, double *thresholds) {
+  if (npoints < 2 || npoints > DET_MAX) return fail(h, PLDA_E_INVAL, "det: 2 <= n_points <= %d", DET_MAX);
+  const size_t hb = (size_t)2 * (DET_MAX + 1) * 8;
+  PLDA_HIP(h, h->w[10].reserve(hb + 64 + (size_t)DET_MAX * 8 + 64));
+  unsigned long long *dhist = h->w[10].as<unsigned long long>();
+  unsigned *dmm = reinterpret_cast<unsigned *>(dhist + 2 * (DET_MAX + 1));
+  double *dthr = reinterpret_cast<double *>(dmm + 16);
+  static const unsigned init[2] = {0xffffffffu, 0u};
+  PLDA_HIP(h, hipMemcpyAsync(dmm, init, 8, hipMemcpyHostToDevice, h->stream));
+  for (int p = 0; p < nparts; ++p) {
+    const int64_t total = parts[p].M * parts[p].Nt;
+    if (total > 0) det_minmax_kernel<<<(unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 32), 256, 0, h->stream>>>(parts[p].scores, parts[p].ld, parts[p].M, parts[p].Nt, dmm);
+  }
+  PLDA_LAUNCH_CHECK(h);
+  unsigned mm[2];
+  PLDA_HIP(h, hipMemcpyAsync(mm, dmm, 8, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (mm[0] > mm[1]) return fail(h, PLDA_E_INVAL, "det: no scores");
+  // the thresholds exactly as the definition accumulates them (float64 running sum)
+  const double lo = (double)key_score(mm[0]), hi = (double)key_score(mm[1]);
+  const double step = (hi - lo) / ((double)npoints - 1.0);
+  std::vector<double> thr((size_t)npoints);
+  double t = lo;
+  for (int i = 0; i < npoints; ++i) { thr[(size_t)i] = t; t += step; }
+  PLDA_HIP(h, hipMemcpyAsync(dthr, thr.data(), (size_t)npoints * 8, hipMemcpyHostToDevice, h->stream));
+  PLDA_HIP(h, hipMemsetAsync(dhist, 0, hb, h->stream));
+  for (int p = 0; p < nparts; ++p) {
+    const int64_t total = parts[p].M * parts[p].Nt;
+    if (total > 0)
+      det_hist_kernel<<<(unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 8), 256, 0, h->stream>>>(
+          parts[p].scores, parts[p].ld, parts[p].M, parts[p].Nt, despk, dtspk, parts[p].cls, dthr, npoints, lo, step > 0.0 ? 1.0 / step : 0.0, dhist);
+  }
+  PLDA_LAUNCH_CHECK(h);
+  std::vector<unsigned long long> H((size_t)2 * (DET_MAX + 1));
+  PLDA_HIP(h, hipMemcpyAsync(H.data(), dhist, hb, hipMemcpyDeviceToHost, h->stream));
+  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  unsigned long long Nn = 0, Np = 0;
+  for (int k = 0; k <= npoints; ++k) { Nn += H[(size_t)k]; Np += H[(size_t)(DET_MAX + 1) + k]; }
+  if (Nn == 0 || Np == 0) return fail(h, PLDA_E_INVAL, "det: need at least one target and one impostor score");
+  // k(s) = #{i : t_i <= s}:  s >= t_i  <=>  k >= i + 1;   s < t_i  <=>  k <= i
+  unsigned long long below_p = 0, ge_n = Nn;
+  for (int i = 0; i < npoints; ++i) {
+    ge_n -= H[(size_t)i];                                   // impostors with k == i are below t_i
+    below_p += H[(size_t)(DET_MAX + 1) + i];                // targets with k <= i are below t_i
+    far[i] = (double)ge_n / (double)Nn;
+    frr[i] = (double)below_p / (double)Np;
+    if (thresholds) thresholds[i] = thr[(size_t)i];
+  }
+  return PLDA_OK;
+}
+
+int det_matrix_device(plda_handle *h, const float *dscores, int64_t ld, int64_t M, int64_t Nt, const int64_t *despk, const int64_t *dtspk,
+                      int npoints, double *far, double *frr, double *thresholds) {
+  if (!dscores || !despk || !dtspk || !far || !frr || M <= 0 || Nt <= 0 || ld < Nt) return fail(h, PLDA_E_INVAL, "det: bad argument");
+  const DetPart part{dscores, ld, M, Nt, -1};
+  return det_device(h, &part, 1, despk, dtspk, npoints, far, frr, thresholds);
+}
+int det_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, int npoints, double *far, double *frr,
+                     double *thresholds) {
+  if (!dpos || !dneg || !far || !frr || np <= 0 || nn <= 0) return fail(h, PLDA_E_INVAL, "det: need at least one target and one impostor score");
+  const DetPart parts[2] = {{dneg, nn, 1, nn, 0}, {dpos, np, 1, np, 1}};
+  return det_device(h, parts, 2, nullptr, nullptr, npoints, far, frr, thresholds);
+}
+
 int eer_lists_device(plda_handle *h, const float *dpos, int64_t np, const float *dneg, int64_t nn, double *out) {
   if (!dpos || !dneg || !out || np <= 0 || nn <= 0) return fail(h, PLDA_E_INVAL, "eer: need at least one target and one impostor score");
   EerSource s{nullptr, 0, 0, 0, nullptr, nullptr, dpos, np, dneg, nn};

@@ -40,6 +40,36 @@ def eer_from_operands_dev(engine, dU, dn, n_uniform, m, dV, nt, denrol_spk, dtes
     return out
 
 
+def det_from_lists(engine, truescores, impostscores, n_points=100):
+    """(thresholds, FAR, FRR) at the n_points thresholds of the DET curve eer.py:34-62 plots (`bob.measure.plot.det(neg, pos,
+    100)`): arrays of length n_points.  The plot's coordinates are `ppndf(FRR)`, `ppndf(FAR)`."""
+    pos = np.ascontiguousarray(truescores, np.float32)
+    neg = np.ascontiguousarray(impostscores, np.float32)
+    far, frr, thr = np.zeros(n_points), np.zeros(n_points), np.zeros(n_points)
+    N.check(engine._h, engine._lib.plda_det_lists(engine._h, C.c_void_p(pos.ctypes.data), pos.shape[0], C.c_void_p(neg.ctypes.data),
+                                                  neg.shape[0], int(n_points), C.c_void_p(far.ctypes.data),
+                                                  C.c_void_p(frr.ctypes.data), C.c_void_p(thr.ctypes.data)))
+    return thr, far, frr
+
+
+def det_from_matrix_dev(engine, dscores, ld, m, nt, denrol_spk, dtest_spk, n_points=100):
+    """Same on an HBM-resident fp32 trials matrix with int64 speaker ids on the device."""
+    far, frr, thr = np.zeros(n_points), np.zeros(n_points), np.zeros(n_points)
+    N.check(engine._h, engine._lib.plda_det_matrix_dev(engine._h, C.c_void_p(int(dscores)), int(ld), int(m), int(nt),
+                                                       C.c_void_p(int(denrol_spk)), C.c_void_p(int(dtest_spk)), int(n_points),
+                                                       C.c_void_p(far.ctypes.data), C.c_void_p(frr.ctypes.data),
+                                                       C.c_void_p(thr.ctypes.data)))
+    return thr, far, frr
+
+
+def ppndf(p):
+    """The normal deviate of a rate, the scale of a DET plot's axes (bob.measure.ppndf: probit of p clipped to
+    [2.2204e-16, 1 - 2.2204e-16]; restated)."""
+    from scipy.special import ndtri
+    eps = 2.2204e-16
+    return ndtri(np.clip(np.asarray(p, np.float64), eps, 1.0 - eps))
+
+
 def format_line(far, frr, threshold):
     """The line eer.py:72-73 writes."""
     return "EER = %.2f%%, FAR = %.2f, FRR=%.2f, Threshold = %e\n" % ((far + frr) / 2 * 100, far, frr, threshold)

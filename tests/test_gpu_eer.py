@@ -263,3 +263,36 @@ def test_eer_without_the_matrix(monkeypatch, case):
         assert "eer.pilot" in names, names
     if case == "big_uniform":
         assert "eer.window_pass" in names and not any(n.startswith("eer.three_passes") for n in names), names
+
+
+@pytest.mark.parametrize("n_points", [2, 100, 2047])
+@pytest.mark.parametrize("case", ["gauss", "ties", "one_value"])
+def test_det_points_match_restatement(eng, case, n_points):
+    """The points of the DET curve scoring/eer.py:34-62 plots (bob.measure.plot.det(neg, pos, 100): farfrr at thresholds spread
+    evenly over the score range, accumulated in float64): thresholds and both rates EQUAL to the NumPy restatement
+    (oracle/plda_oracle_np.py:det) -- two-list form and labelled-matrix form (padded leading dimension)."""
+    import torch
+    from plda_amd import eer
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(sum(map(ord, case)) + n_points)
+    m, nt, ld, k = 211, 333, 340, 7
+    es, ts = rng.integers(0, k, m), rng.integers(0, k, nt)
+    tgt = es[:, None] == ts[None, :]
+    Sh = rng.standard_normal((m, ld)).astype(np.float32)
+    Sh[:, :nt] += 2.0 * tgt
+    if case == "ties":
+        Sh = np.round(Sh * 2) / 2
+    if case == "one_value":
+        Sh[:] = 0.25
+    sub = Sh[:, :nt]
+    thr_r, far_r, frr_r = onp.det(sub[~tgt], sub[tgt], n_points)
+    thr, far, frr = eer.det_from_lists(eng, sub[tgt], sub[~tgt], n_points)
+    assert np.array_equal(thr, thr_r) and np.array_equal(far, far_r) and np.array_equal(frr, frr_r)
+    S = torch.from_numpy(Sh).to(dev)
+    des, dts = torch.from_numpy(es).to(dev), torch.from_numpy(ts).to(dev)
+    thr, far, frr = eer.det_from_matrix_dev(eng, S.data_ptr(), ld, m, nt, des.data_ptr(), dts.data_ptr(), n_points)
+    assert np.array_equal(thr, thr_r) and np.array_equal(far, far_r) and np.array_equal(frr, frr_r)
+    assert far[0] == 1.0 and frr[0] == 0.0 and (np.diff(far) <= 0).all() and (np.diff(frr) >= 0).all()
+    dev_far, dev_frr = eer.ppndf(far), eer.ppndf(frr)
+    assert np.isfinite(dev_far).all() and np.isfinite(dev_frr).all()
+    assert np.array_equal(dev_far, onp.ppndf(far_r))

@@ -334,3 +334,21 @@ def test_length_normalisation_weights_are_the_models_variances(oracle, n):
         assert abs(np.sum(u * u / (psi + 1.0 / n)) - D) < 1e-9 * D
     sigma = np.sqrt(2.0 / D / draws)                             # std of a chi2_D / D average over `draws` draws
     assert abs(inv_f2.mean() - 1.0) < 4 * sigma, (inv_f2.mean(), sigma)
+
+
+def test_det_restatement_is_consistent_with_farfrr_and_eer():
+    """oracle det(): the thresholds run from the smallest to the largest score, FAR falls from 1, FRR rises from 0, every
+    point IS farfrr at its threshold, and the curve brackets the EER the eer() restatement finds (scoring/eer.py:34-76)."""
+    from oracle import plda_oracle_np as onp
+    rng = np.random.default_rng(5)
+    pos = rng.normal(1.5, 1.0, 4000).astype(np.float32); neg = rng.normal(-0.5, 1.0, 60000).astype(np.float32)
+    thr, far, frr = onp.det(neg, pos, 100)
+    assert thr[0] == min(pos.min(), neg.min()) and abs(thr[-1] - max(pos.max(), neg.max())) < 1e-9
+    assert far[0] == 1.0 and frr[0] == 0.0 and (np.diff(far) <= 0).all() and (np.diff(frr) >= 0).all()
+    for i in (0, 17, 50, 99):
+        assert far[i] == (neg.astype(np.float64) >= thr[i]).mean() and frr[i] == (pos.astype(np.float64) < thr[i]).mean()
+    t, f1, f2, e = onp.eer(neg, pos)
+    j = int(np.searchsorted(thr, t))
+    assert far[j - 1] >= f1 >= far[min(j, 99)] and frr[j - 1] <= f2 <= frr[min(j, 99)]
+    d = onp.ppndf(np.array([0.0, 0.5, 1.0]))
+    assert np.isfinite(d).all() and d[1] == 0.0 and abs(d[0] + d[2]) < 1e-5 and d[0] < -8.0      # (1 - eps rounds: not exactly symmetric)
