@@ -49,7 +49,7 @@ constexpr int CS_MAX = 64;        // more distinct counts than this: the depth-2
 constexpr int CS_NMAX = 4095;     // a count above this: the depth-2D form
 struct CountSet { int G = 0; int32_t vals[CS_MAX] = {}; };
 // One (btM, btN) tile grid of trials_gemm_bt4_kernel: per-XCD queues over a table of tiles (score.hip: bt4_schedule)
-struct Bt4Table { int btM = -1, btN = -1; DevBuf tab; int qbase[8] = {}, qlen[8] = {}; unsigned init[8] = {}; uint64_t used = 0; };
+struct Bt4Table { int btM = -1, btN = -1, colwalk = 0; DevBuf tab; int qbase[8] = {}, qlen[8] = {}; unsigned init[8] = {}; uint64_t used = 0; };
 }  // namespace plda
 
 struct plda_handle {

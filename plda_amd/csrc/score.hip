@@ -1184,11 +1184,33 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 // keep their tables (h->bt4_tabs, least recently used replaced).  The queue counters are (re)set by a one-wave kernel
 // in front of every launch.
 struct Bt4Init { unsigned v[8]; };
-__global__ __launch_bounds__(64) void bt4_table_kernel(int2 *__restrict__ tab, int btM, int btN, int pN, int64_t npatch, const Bt4Queues qs) {
+// Patch k of queue x.  Row walk (rounds 4-5a): patches x, x + 8, ... of the row-major patch grid -- consecutive patches of an
+// XCD share their A panels, every B panel is fetched once per patch row.  Column walk: queue x owns the patch columns x, x + 8,
+// ... and goes down each -- consecutive patches share their B panels, every A panel is fetched once per patch column.
+// The columns beyond the last full round of eight (pN % 8 of them) are dealt patch by patch in row-major order, so no queue is a
+// whole column longer than another.
+__device__ __host__ inline int64_t bt4_queue_patches(int x, int pM, int pN, int colwalk) {
+  if (colwalk) {
+    const int64_t rest = (int64_t)pM * (pN % 8);
+    return (int64_t)pM * (pN / 8) + (x < rest ? (rest - x + 7) / 8 : 0);
+  }
+  const int64_t np = (int64_t)pM * pN;
+  return x < np ? (np - x + 7) / 8 : 0;
+}
+__device__ __host__ inline void bt4_patch(int x, int64_t k, int pM, int pN, int colwalk, int &pm, int &pn) {
+  if (colwalk) {
+    const int64_t whole = (int64_t)pM * (pN / 8);
+    if (k < whole) { pn = x + 8 * (int)(k / pM); pm = (int)(k % pM); }
+    else { const int r = pN % 8; const int64_t q = x + 8 * (k - whole); pm = (int)(q / r); pn = (pN / 8) * 8 + (int)(q % r); }
+  } else { const int64_t p = x + 8 * k; pm = (int)(p / pN); pn = (int)(p % pN); }
+}
+__global__ __launch_bounds__(64) void bt4_table_kernel(int2 *__restrict__ tab, int btM, int btN, int pM, int pN, int colwalk, const Bt4Queues qs) {
   const int x = blockIdx.x, lane = threadIdx.x;
   int off = qs.qbase[x];
-  for (int64_t p = x; p < npatch; p += 8) {
-    const int pm = (int)(p / pN), pn = (int)(p % pN);
+  const int64_t nq = bt4_queue_patches(x, pM, pN, colwalk);
+  for (int64_t k = 0; k < nq; ++k) {
+    int pm, pn;
+    bt4_patch(x, k, pM, pN, colwalk, pm, pn);
     const int tm = pm * BPR + lane / BPC, tn = pn * BPC + lane % BPC;
     const bool ok = lane < BPR * BPC && tm < btM && tn < btN;
     const unsigned long long mask = __ballot(ok);
@@ -1200,22 +1222,36 @@ __global__ void bt4_reset_kernel(unsigned *__restrict__ cnt, const Bt4Init init)
   if (threadIdx.x < 8) cnt[threadIdx.x] = init.v[threadIdx.x];
 }
 
-static int bt4_schedule(plda_handle *h, int btM, int btN, Bt4Table **out) {
+static int bt4_schedule(plda_handle *h, int btM, int btN, int KQ, Bt4Table **out) {
   PLDA_HIP(h, h->bt4_cnt.reserve(32 * sizeof(unsigned)));
+  // Which operand's panels stay in an XCD's L2 from patch to patch, i.e. which operand is fetched again and again (round 5).
+  // Along a patch row (rounds 2-5a: always) every B panel is fetched once per patch row; down a patch column every A panel once
+  // per patch column.  What decides is where the repeated operand comes from: at C4 the 1.27 GB test side -- five times the
+  // 256 MB Infinity Cache -- came from HBM 40 times; down the columns the 42 MB enrol side repeats and the cache holds it.
+  // Measured (scripts/probe/colwalk_ab.sh, colwalk_mid.sh; ms per step, row walk -> column walk, same box): C4 183.1 -> 174.2,
+  // C3 72.2 -> 71.5 (FETCH_SIZE per launch 56.8 -> 36.0 GB and 35.1 -> 30.5 GB); where both operands fit the cache or neither
+  // does the column walk LOSES a little: C2 28.23 -> 28.38 (11.0 -> 4.4 GB), 150k x 150k x 512 156.1 -> 157.4, 200k x 200k x 200
+  // and 140k x 140k x 256 equal.  So: down the columns exactly when the enrol side fits half the cache and the test side does
+  // not.  (Starting each XCD at a different height of its column, and dealing the columns beyond the last round of eight patch
+  // by patch, changed nothing measurable; the second is kept for the balance of the queues.)
+  // PLDA_GEMM_VARIANT=48: the row walk always; 49: the column walk always (A/B arms).
+  const size_t keep = (size_t)128 << 20, bytesA = (size_t)btM * 256 * KQ * 16, bytesB = (size_t)btN * 256 * KQ * 16;
+  const int colwalk = h->gemm_variant == 48 ? 0 : h->gemm_variant == 49 ? 1 : (bytesA <= keep && bytesB > keep) ? 1 : 0;
   Bt4Table *lru = &h->bt4_tabs[0];
   for (auto &t : h->bt4_tabs) {
-    if (t.btM == btM && t.btN == btN) { t.used = ++h->bt4_clock; *out = &t; return PLDA_OK; }
+    if (t.btM == btM && t.btN == btN && t.colwalk == colwalk) { t.used = ++h->bt4_clock; *out = &t; return PLDA_OK; }
     if (t.used < lru->used) lru = &t;
   }
   Bt4Table &t = *lru;
   const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
-  const int64_t npatch = (int64_t)pM * pN;
   int64_t total = 0;
   Bt4Queues qs;
   for (int x = 0; x < 8; ++x) {
     t.qbase[x] = (int)total;
-    for (int64_t p = x; p < npatch; p += 8) {
-      const int pm = (int)(p / pN), pn = (int)(p % pN);
+    const int64_t nq = bt4_queue_patches(x, pM, pN, colwalk);
+    for (int64_t k = 0; k < nq; ++k) {
+      int pm, pn;
+      bt4_patch(x, k, pM, pN, colwalk, pm, pn);
       total += (int64_t)std::min(BPR, btM - pm * BPR) * std::min(BPC, btN - pn * BPC);
     }
     t.qlen[x] = (int)total - t.qbase[x];
@@ -1226,9 +1262,9 @@ static int bt4_schedule(plda_handle *h, int btM, int btN, Bt4Table **out) {
   }
   t.btM = t.btN = -1;
   PLDA_HIP(h, t.tab.reserve(std::max<size_t>((size_t)total, 1) * sizeof(int2)));
-  bt4_table_kernel<<<8, 64, 0, h->stream>>>(t.tab.as<int2>(), btM, btN, pN, npatch, qs);
+  bt4_table_kernel<<<8, 64, 0, h->stream>>>(t.tab.as<int2>(), btM, btN, pM, pN, colwalk, qs);
   PLDA_LAUNCH_CHECK(h);
-  t.btM = btM; t.btN = btN; t.used = ++h->bt4_clock;
+  t.btM = btM; t.btN = btN; t.colwalk = colwalk; t.used = ++h->bt4_clock;
   *out = &t;
   return PLDA_OK;
 }
@@ -1491,12 +1527,12 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   {
     const int nsteps = op.KQ >> 1, nst = (nsteps + 3) >> 2;
     const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 3 && M < (1ll << 31) && Nt < (1ll << 31) &&
-                         (h->gemm_variant == 40 || h->gemm_variant == 41 || (h->gemm_variant >= 44 && h->gemm_variant <= 47) || (h->gemm_variant == 0 && big));
+                         (h->gemm_variant == 40 || h->gemm_variant == 41 || h->gemm_variant == 48 || h->gemm_variant == 49 || (h->gemm_variant >= 44 && h->gemm_variant <= 47) || (h->gemm_variant == 0 && big));
     if (use_bt4) {
       const int sbase = nsteps / nst, fs = sbase + (nsteps - sbase * nst > 0 ? 1 : 0);
       h->last_kernel = "trials_gemm_bt4_kernel";
       Bt4Table *tb = nullptr;
-      PLDA_TRY(bt4_schedule(h, btM, btN, &tb));
+      PLDA_TRY(bt4_schedule(h, btM, btN, op.KQ, &tb));
       // the queues' counters start behind every workgroup's first tile
       {
         Bt4Init bi;
@@ -1533,7 +1569,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
         if (fs == 3) BT4L(3, 16, h->timeline.as<unsigned long long>());
         else BT4L(4, 16, h->timeline.as<unsigned long long>());
         h->timeline_valid = true;
-      } else if (h->gemm_variant >= 44 && fs == 4) {
+      } else if (h->gemm_variant >= 44 && h->gemm_variant <= 46 && fs == 4) {
         if (h->gemm_variant == 44) BT4L(4, 4, nullptr);
         else if (h->gemm_variant == 45) BT4L(4, 8, nullptr);
         else BT4L(4, 12, nullptr);

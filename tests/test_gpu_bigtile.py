@@ -144,6 +144,27 @@ def test_one_wave_per_simd_kernel_bit_identical(monkeypatch, d, m, nt):
         assert np.array_equal(a, b), (d, m, nt, np.abs(a - b).max())
 
 
+# tile-queue orders of the one-wave-per-SIMD kernel (score.hip: bt4_schedule): 48 walks the patch rows, 49 goes down the patch
+# columns (queue x owns columns x, x + 8, ...; the columns beyond the last round of eight dealt patch by patch).  The order only
+# moves tiles between workgroups: same bits.  Shapes: 21 x 17 tiles (3 patch columns: remainder only), 5 x 75 tiles (10 patch
+# columns: one round of eight + 2), 2 x 130 tiles (17 patch columns, one patch row), ragged edges.
+@pytest.mark.parametrize("d,m,nt", [(72, 5300, 4200), (96, 1100, 19000), (200, 400, 33100)])
+def test_tile_queue_orders_bit_identical(monkeypatch, d, m, nt):
+    rng = np.random.default_rng(d + nt)
+    U, V = _vectors(rng, m, d), _vectors(rng, nt, d)
+    counts = rng.integers(1, 4, m).astype(np.int32)
+    outs = {}
+    for variant in (48, 49):
+        eng, _ = _engine(monkeypatch, variant, d)
+        outs[variant] = (eng.score_matrix((2, U), (1, V)), eng.score_matrix((counts, U), (1, V)))
+        assert eng.score_last_shape()[2] > 0
+    eng, _ = _engine(monkeypatch, 20, d)
+    ref = eng.score_matrix((2, U), (1, V))
+    for a, b in zip(outs[48], outs[49]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.array_equal(outs[49][0], ref)
+
+
 @pytest.mark.parametrize("d,m,nt", [(200, 300, 517), (64, 1024, 1024), (33, 257, 769)])
 def test_one_wave_per_simd_kernel_oracle(monkeypatch, oracle, d, m, nt):
     eng, psi = _engine(monkeypatch, 40, d)
