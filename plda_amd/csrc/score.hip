@@ -1162,6 +1162,28 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 
 // (score_bt4.inc defines the tile fetch's two values on the fetching path only, on purpose -- see the comment at f_raw; the
 //  warning is silenced for that kernel alone, not for the translation unit)
+// Patch k of XCD queue x of a patch grid pM x pN (both 256 x 256 kernels' queues and the bf16x3 arm's static walk).  Row walk (rounds 4-5a): patches x, x + 8, ... of the row-major patch grid -- consecutive patches of an
+// XCD share their A panels, every B panel is fetched once per patch row.  Column walk: queue x owns the patch columns x, x + 8,
+// ... and goes down each -- consecutive patches share their B panels, every A panel is fetched once per patch column.
+// The columns beyond the last full round of eight (pN % 8 of them) are dealt patch by patch in row-major order, so no queue is a
+// whole column longer than another.
+template <typename I = int64_t>
+__device__ __host__ inline I bt4_queue_patches(int x, int pM, int pN, int colwalk) {
+  if (colwalk) {
+    const I rest = (I)pM * (pN % 8);
+    return (I)pM * (pN / 8) + (x < rest ? (rest - x + 7) / 8 : 0);
+  }
+  const I np = (I)pM * pN;
+  return x < np ? (np - x + 7) / 8 : 0;
+}
+template <typename I>
+__device__ __host__ inline void bt4_patch(int x, I k, int pM, int pN, int colwalk, int &pm, int &pn) {
+  if (colwalk) {
+    const I whole = (I)pM * (pN / 8);
+    if (k < whole) { pn = x + 8 * (int)(k / pM); pm = (int)(k % pM); }
+    else { const int r = pN % 8; const I q = x + 8 * (k - whole); pm = (int)(q / r); pn = (pN / 8) * 8 + (int)(q % r); }
+  } else { const I p = x + 8 * k; pm = (int)(p / pN); pn = (int)(p % pN); }
+}
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wuninitialized"
 #pragma clang diagnostic ignored "-Wsometimes-uninitialized"
@@ -1184,26 +1206,6 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 // keep their tables (h->bt4_tabs, least recently used replaced).  The queue counters are (re)set by a one-wave kernel
 // in front of every launch.
 struct Bt4Init { unsigned v[8]; };
-// Patch k of queue x.  Row walk (rounds 4-5a): patches x, x + 8, ... of the row-major patch grid -- consecutive patches of an
-// XCD share their A panels, every B panel is fetched once per patch row.  Column walk: queue x owns the patch columns x, x + 8,
-// ... and goes down each -- consecutive patches share their B panels, every A panel is fetched once per patch column.
-// The columns beyond the last full round of eight (pN % 8 of them) are dealt patch by patch in row-major order, so no queue is a
-// whole column longer than another.
-__device__ __host__ inline int64_t bt4_queue_patches(int x, int pM, int pN, int colwalk) {
-  if (colwalk) {
-    const int64_t rest = (int64_t)pM * (pN % 8);
-    return (int64_t)pM * (pN / 8) + (x < rest ? (rest - x + 7) / 8 : 0);
-  }
-  const int64_t np = (int64_t)pM * pN;
-  return x < np ? (np - x + 7) / 8 : 0;
-}
-__device__ __host__ inline void bt4_patch(int x, int64_t k, int pM, int pN, int colwalk, int &pm, int &pn) {
-  if (colwalk) {
-    const int64_t whole = (int64_t)pM * (pN / 8);
-    if (k < whole) { pn = x + 8 * (int)(k / pM); pm = (int)(k % pM); }
-    else { const int r = pN % 8; const int64_t q = x + 8 * (k - whole); pm = (int)(q / r); pn = (pN / 8) * 8 + (int)(q % r); }
-  } else { const int64_t p = x + 8 * k; pm = (int)(p / pN); pn = (int)(p % pN); }
-}
 __global__ __launch_bounds__(64) void bt4_table_kernel(int2 *__restrict__ tab, int btM, int btN, int pM, int pN, int colwalk, const Bt4Queues qs) {
   const int x = blockIdx.x, lane = threadIdx.x;
   int off = qs.qbase[x];
@@ -1495,11 +1497,14 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     }
     const int b3M = (int)ceil_div(M, 256), b3N = (int)ceil_div(Nt, 128);       // 256 x 128 tiles (Npad is a multiple of 256)
     const int pM = (int)ceil_div(b3M, B3_PR), pN = (int)ceil_div(b3N, B3_PC);
+    // the walk of the patches: as bt4_schedule chooses it (which operand repeats, and whether the Infinity Cache holds it)
+    const size_t keep3 = (size_t)128 << 20, bytesA3 = (size_t)3 * KO * op.Mpad * 16, bytesB3 = (size_t)3 * KO * op.Npad * 16;
+    const int colwalk3 = h->gemm_variant == 48 ? 0 : h->gemm_variant == 49 ? 1 : (bytesA3 <= keep3 && bytesB3 > keep3) ? 1 : 0;
     h->last_kernel = "trials_gemm_bf16x3_kernel";
 #define B3L(MODE_)                                                                                                                      \
   trials_gemm_bf16x3_kernel<MODE_><<<256, 512, B3_LDS, h->stream>>>(h->s_A16.as<f32x4>(), h->s_B16.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad,  \
                                                                     nsteps, h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout, \
-                                                                    ld, M, Nt, b3M, b3N, pN, pM * pN, h->timeline.as<unsigned long long>())
+                                                                    ld, M, Nt, b3M, b3N, pM, pN, colwalk3, h->timeline.as<unsigned long long>())
     if (h->gemm_variant == 63) {                  // the product kernel + clock stamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       B3L(16);

@@ -56,6 +56,27 @@ def test_bf16x3_uniform_and_mixed_vs_oracle(monkeypatch, oracle, d, m, nt):
     assert (np.abs(got - ref) <= score_tol(ref)).all(), np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("d,m,nt", [(72, 5300, 4200), (96, 1100, 19000), (200, 400, 35000)])
+def test_bf16x3_patch_walks_bit_identical(monkeypatch, d, m, nt):
+    """The arm's static walk of the 1024 x 2048 patches, along the rows (PLDA_GEMM_VARIANT=48) or down the columns (49; queue x
+    owns columns x, x + 8, ..., the remainder dealt patch by patch -- score.hip: bt4_patch): the order only decides which
+    workgroup computes a tile.  Shapes with 3, 10 and 18 patch columns, ragged edges."""
+    rng = np.random.default_rng(d + nt)
+    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
+    counts = rng.integers(1, 4, m).astype(np.int32)
+    outs = []
+    for variant in (48, 49):
+        eng, _ = _engine(monkeypatch, d)
+        monkeypatch.setenv("PLDA_GEMM_VARIANT", str(variant))
+        from plda_amd import MPlda
+        eng2 = MPlda(0)
+        eng2.set_model(*_model(d, 3))
+        outs.append((eng2.score_matrix((2, U), (1, V)), eng2.score_matrix((counts, U), (1, V))))
+        assert eng2.score_last_kernel() == "trials_gemm_bf16x3_kernel"
+    for a, b in zip(*outs):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def test_bf16x3_znorm(monkeypatch, oracle):
     d, m, nt = 120, 300, 517
     eng, psi = _engine(monkeypatch, d)
