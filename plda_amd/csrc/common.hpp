@@ -49,7 +49,7 @@ constexpr int CS_MAX = 64;        // more distinct counts than this: the depth-2
 constexpr int CS_NMAX = 4095;     // a count above this: the depth-2D form
 struct CountSet { int G = 0; int32_t vals[CS_MAX] = {}; };
 // One (btM, btN) tile grid of trials_gemm_bt4_kernel: per-XCD queues over a table of tiles (score.hip: bt4_schedule)
-struct Bt4Table { int btM = -1, btN = -1, colwalk = 0; DevBuf tab; int qbase[8] = {}, qlen[8] = {}; unsigned init[8] = {}; uint64_t used = 0; };
+struct Bt4Table { int btM = -1, btN = -1, colwalk = 0; DevBuf tab; int qbase[8] = {}, qlen[8] = {}; uint64_t used = 0; };
 }  // namespace plda
 
 struct plda_handle {
@@ -133,6 +133,7 @@ struct plda_handle {
   int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass; 2: no tail launch (A/B arms)
   int gemm_variant = 0;
   int mixed_variant = 0;   // PLDA_MIXED_VARIANT=1: mixed enrol counts always in the depth-2D form [A1 | A2] x [V | V*V] (A/B arm of the bucketed form)
+  const double *ucoef_ptr = nullptr; uint64_t ucoef_epoch = 0; int ucoef_n = 0, ucoef_D = 0;   // uniform-count coefficients in w[11] (score.hip: prepare_operands)
   int prep_variant = 0;    // PLDA_PREP_VARIANT=1: scoring prep as separate bias / pack / pair kernels (A/B arm of prep_side_kernel)
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament

@@ -218,70 +218,75 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ X,
 // the fp32 operand value into a 64 x 64 LDS tile, from which the k-quad planes leave as 1 KiB pieces.
 //   SIDE 0: enrol  A1 = c u / var (* s_i), r'_i, s_i, rpair        SIDE 1: test  V, q_j, cpair
 // HBM: R D 8 B read + R Kg 4 B written (Kg = D rounded up to 8).
+// RW = rows per wave: 16 (above) for the long sides, where 64-row workgroups fill the chip several times over; 4 for sides of
+// up to 32 768 rows, where they do not -- 8 192 rows are 128 workgroups of lone waves walking their chunks one memory round
+// trip after the other: 17.4 us whatever the row count (256 rows x 512: 25 us), a seventh of an 8192 x 8192 x 200 call.  With
+// 16-row workgroups (256-byte pieces of the planes) the same arithmetic in the same order (bit-identical, tests) takes
+// PLDA_PREP_VARIANT=2 / 3: force 16 / 4.
 // ------------------------------------------------------------------------------------
-template <int SIDE>
-__global__ __launch_bounds__(256) void prep_side_kernel(const double *__restrict__ X, const double *__restrict__ w, const double *__restrict__ Lptr,
-                                                        int n_uniform, const double *__restrict__ psi, int D, int64_t R, int64_t Rpad, int KQ,
-                                                        const double *__restrict__ zmean, const double *__restrict__ zstd,
-                                                        float *__restrict__ P, float *__restrict__ bias, float *__restrict__ rscale,
-                                                        float2 *__restrict__ pair) {
-  __shared__ float tile[2][64][65];
+template <int SIDE, int RW>
+__device__ __forceinline__ void prep_side_body(const int block, const double *__restrict__ X, const double *__restrict__ w, const double *__restrict__ Lptr,
+                                               int n_uniform, const double *__restrict__ psi, int D, int64_t R, int64_t Rpad, int KQ,
+                                               const double *__restrict__ zmean, const double *__restrict__ zstd,
+                                               float *__restrict__ P, float *__restrict__ bias, float *__restrict__ rscale,
+                                               float2 *__restrict__ pair) {
+  constexpr int RPB = 4 * RW;                 // rows of a workgroup
+  __shared__ float tile[2][64][RPB + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
-  const int64_t wrow0 = row0 + wave * 16;
+  const int64_t row0 = (int64_t)block * RPB;
+  const int64_t wrow0 = row0 + wave * RW;
   const int nchunk = (KQ * 4 + 63) >> 6;
   const bool zn = SIDE == 0 && zmean && zstd;
   // per-row scale of the packed A operand (the z-norm map's 1 / zstd_i, rounded to fp32 as pack_kernel reads it)
-  float rsf[16];
+  float rsf[RW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < RW; ++j) {
     rsf[j] = 1.f;
     if (zn && wrow0 + j < R) { const double sd = zstd[wrow0 + j]; rsf[j] = (float)(sd != 0.0 ? 1.0 / sd : 1.0); }
   }
-  double acc[16], xc[16], xn[16];
+  // PF chunks are fetched together, one group ahead of the arithmetic: 1 for the 16-row waves (the next chunk's 16 loads under
+  // this chunk's arithmetic), 4 for the 4-row waves of short sides (a row of up to 256 dimensions is ONE memory round trip)
+  constexpr int PF = RW == 16 ? 1 : 4;
+  double acc[RW], xc[PF][RW], xn[PF][RW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { acc[j] = 0.0; xn[j] = 0.0; }
-  auto fetch = [&](int c, double (&x)[16]) {
+  for (int j = 0; j < RW; ++j) acc[j] = 0.0;
+  auto fetch = [&](int c, double (&x)[RW]) {
     const int d = c * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < RW; ++j) {
       const int64_t row = wrow0 + j;
-      x[j] = (d < D && row < R) ? X[row * (int64_t)D + d] : 0.0;
+      x[j] = (c < nchunk && d < D && row < R) ? X[row * (int64_t)D + d] : 0.0;
     }
   };
-  fetch(0, xn);
-  for (int c = 0; c < nchunk; ++c) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) xc[j] = xn[j];
-    if (c + 1 < nchunk) fetch(c + 1, xn);
+  auto chunk = [&](int c, const double (&x)[RW]) {
     const int d = c * 64 + lane;
     const bool dv = d < D;
     const double wd = dv ? w[d] : 0.0;
     double cc = 0.0, var = 1.0;
     if (SIDE == 0 && dv) llr_coef((double)n_uniform, psi[d], cc, var);
-    float(*const tl)[65] = tile[c & 1];
+    float(*const tl)[RPB + 1] = tile[c & 1];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const double x = xc[j];
+    for (int j = 0; j < RW; ++j) {
+      const double xv = x[j];
       float val = 0.f;
       if (dv && wrow0 + j < R) {
-        acc[j] += wd * x * x;
+        acc[j] += wd * xv * xv;
         if (SIDE == 0) {
-          double v = cc * x / var;
+          double v = cc * xv / var;
           if (zn) v *= (double)rsf[j];
           val = (float)v;
         } else {
-          val = (float)x;
+          val = (float)xv;
         }
       }
-      tl[lane][wave * 16 + j] = val;
+      tl[lane][wave * RW + j] = val;
     }
     __syncthreads();
     {
-      const int r = threadIdx.x & 63;
+      const int r = threadIdx.x % RPB;
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int q = (threadIdx.x >> 6) + pass * 4;   // k-quad of the chunk, 0..15
+      for (int pass = 0; pass < RPB / 16; ++pass) {
+        const int q = threadIdx.x / RPB + pass * (256 / RPB);   // k-quad of the chunk, 0..15
         const int kq = c * 16 + q;
         if (kq < KQ) {
           f32x4 v;
@@ -293,10 +298,25 @@ __global__ __launch_bounds__(256) void prep_side_kernel(const double *__restrict
         }
       }
     }
+  };
+#pragma unroll
+  for (int k = 0; k < PF; ++k) fetch(k, xn[k]);
+  for (int c0 = 0; c0 < nchunk; c0 += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+#pragma unroll
+      for (int j = 0; j < RW; ++j) xc[k][j] = xn[k][j];
+    if (c0 + PF < nchunk) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) fetch(c0 + PF + k, xn[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (c0 + k < nchunk) chunk(c0 + k, xc[k]);
   }
   const double Lc = SIDE == 0 ? *Lptr : 0.0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < RW; ++j) {
     double a = acc[j];
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     const int64_t row = wrow0 + j;
@@ -311,6 +331,25 @@ __global__ __launch_bounds__(256) void prep_side_kernel(const double *__restrict
       else pair[row] = make_float2(1.f, (float)r);
     }
   }
+}
+
+template <int SIDE, int RW>
+__global__ __launch_bounds__(256) void prep_side_kernel(const double *__restrict__ X, const double *__restrict__ w, const double *__restrict__ Lptr,
+                                                        int n_uniform, const double *__restrict__ psi, int D, int64_t R, int64_t Rpad, int KQ,
+                                                        const double *__restrict__ zmean, const double *__restrict__ zstd,
+                                                        float *__restrict__ P, float *__restrict__ bias, float *__restrict__ rscale,
+                                                        float2 *__restrict__ pair) {
+  prep_side_body<SIDE, RW>((int)blockIdx.x, X, w, Lptr, n_uniform, psi, D, R, Rpad, KQ, zmean, zstd, P, bias, rscale, pair);
+}
+// both short sides in one launch (a dependent launch costs ~4.5 us whatever it does): blocks [0, blocksA) the enrol side, the rest the test side
+struct PrepSideArgs { const double *X; const double *w; int64_t R, Rpad; float *P; float *bias; float2 *pair; };
+__global__ __launch_bounds__(256) void prep_both_kernel(const PrepSideArgs a, const PrepSideArgs b, int blocksA, const double *__restrict__ Lptr, int n_uniform,
+                                                        const double *__restrict__ psi, int D, int KQ, const double *__restrict__ zmean,
+                                                        const double *__restrict__ zstd, float *__restrict__ rscale) {
+  if ((int)blockIdx.x < blocksA)
+    prep_side_body<0, 4>((int)blockIdx.x, a.X, a.w, Lptr, n_uniform, psi, D, a.R, a.Rpad, KQ, zmean, zstd, a.P, a.bias, rscale, a.pair);
+  else
+    prep_side_body<1, 4>((int)blockIdx.x - blocksA, b.X, b.w, Lptr, 0, psi, D, b.R, b.Rpad, KQ, nullptr, nullptr, b.P, b.bias, nullptr, b.pair);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1203,9 +1242,8 @@ __device__ __host__ inline void bt4_patch(int x, I k, int pM, int pN, int colwal
 // Round 5: the table is built ON THE DEVICE (one wave per queue, in the order above) from per-queue offsets the host gets
 // by walking the patches -- no host copy and no stream synchronisation, so a change of the tile grid does not stall the
 // host (the sharded form alternates full blocks and a ragged tail; a server scores varying M) -- and the last few grids
-// keep their tables (h->bt4_tabs, least recently used replaced).  The queue counters are (re)set by a one-wave kernel
-// in front of every launch.
-struct Bt4Init { unsigned v[8]; };
+// keep their tables (h->bt4_tabs, least recently used replaced).  The queue counters start every launch at zero: the
+// launch before left them so (score_bt4.inc: bt4_leave).
 __global__ __launch_bounds__(64) void bt4_table_kernel(int2 *__restrict__ tab, int btM, int btN, int pM, int pN, int colwalk, const Bt4Queues qs) {
   const int x = blockIdx.x, lane = threadIdx.x;
   int off = qs.qbase[x];
@@ -1220,12 +1258,12 @@ __global__ __launch_bounds__(64) void bt4_table_kernel(int2 *__restrict__ tab, i
     off += __popcll(mask);
   }
 }
-__global__ void bt4_reset_kernel(unsigned *__restrict__ cnt, const Bt4Init init) {
-  if (threadIdx.x < 8) cnt[threadIdx.x] = init.v[threadIdx.x];
-}
 
 static int bt4_schedule(plda_handle *h, int btM, int btN, int KQ, Bt4Table **out) {
-  PLDA_HIP(h, h->bt4_cnt.reserve(32 * sizeof(unsigned)));
+  if (!h->bt4_cnt.p) {          // the queue counters: zero once, every launch leaves them at zero (score_bt4.inc: bt4_leave)
+    PLDA_HIP(h, h->bt4_cnt.reserve(32 * sizeof(unsigned)));
+    PLDA_HIP(h, hipMemsetAsync(h->bt4_cnt.p, 0, 32 * sizeof(unsigned), h->stream));
+  }
   // Which operand's panels stay in an XCD's L2 from patch to patch, i.e. which operand is fetched again and again (round 5).
   // Along a patch row (rounds 2-5a: always) every B panel is fetched once per patch row; down a patch column every A panel once
   // per patch column.  What decides is where the repeated operand comes from: at C4 the 1.27 GB test side -- five times the
@@ -1257,9 +1295,6 @@ static int bt4_schedule(plda_handle *h, int btM, int btN, int KQ, Bt4Table **out
       total += (int64_t)std::min(BPR, btM - pm * BPR) * std::min(BPC, btN - pn * BPC);
     }
     t.qlen[x] = (int)total - t.qbase[x];
-    // a workgroup's FIRST tile is its own position in its XCD's queue (no round trip before the first DMA): the
-    // counters start behind those
-    t.init[x] = (unsigned)std::min(32, t.qlen[x]);
     qs.qbase[x] = t.qbase[x]; qs.qlen[x] = t.qlen[x];
   }
   t.btM = t.btN = -1;
@@ -1378,13 +1413,14 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
     const int G = cs->G, KQm = Dp / 4, KQx = op.KQ - KQm;
     PLDA_HIP(h, h->w[11].reserve((size_t)G * (2 * D + 1) * 8));
     double *coefG = h->w[11].as<double>();
+    h->ucoef_ptr = nullptr;          // (the uniform path's cached coefficients live in the same buffer)
     bucket_coef_kernel<<<G, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, *cs, coefG);
     if (doA)
       prep_enrol_buckets_kernel<<<(unsigned)(op.Mpad / 64), 256, 0, h->stream>>>(
           dU, dn, *cs, coefG, h->d_psi.as<double>(), D, M, op.Mpad, KQm, KQx, dzmean, dzstd, h->s_Apk.as<float>(),
           h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
     if (doB) {
-      prep_side_kernel<1><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
+      prep_side_kernel<1, 16><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
           dV, coefG + D, coefG + 2 * D, 0, h->d_psi.as<double>(), D, Nt, op.Npad, KQm, nullptr, nullptr, h->s_Bpk.as<float>(),
           h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
       prep_test_buckets_kernel<<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(dV, coefG, G, D, Nt, op.Npad, KQm, KQx, h->s_Bpk.as<float>());
@@ -1406,18 +1442,41 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
   } else {
     PLDA_HIP(h, h->w[11].reserve((size_t)(2 * D + 1) * 8));
     double *coef = h->w[11].as<double>();
-    uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
+    // the per-dimension coefficients depend on (model, count) only: kept across calls (4.7 us of launch otherwise)
+    if (!(h->ucoef_ptr == coef && h->ucoef_epoch == h->model_epoch && h->ucoef_n == n_uniform && h->ucoef_D == D)) {
+      uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
+      h->ucoef_ptr = coef; h->ucoef_epoch = h->model_epoch; h->ucoef_n = n_uniform; h->ucoef_D = D;
+    }
     if (h->prep_variant == 0) {
       // one pass per side: bias, bias pair and packed operand together (prep_side_kernel; PLDA_PREP_VARIANT=1: the
       // separate kernels below, kept as the A/B arm and the reference the bit-identity test compares with)
-      if (doA)
-        prep_side_kernel<0><<<(unsigned)(op.Mpad / 64), 256, 0, h->stream>>>(
-            dU, coef, coef + 2 * D, n_uniform, psi, D, M, op.Mpad, op.KQ, dzmean, dzstd, h->s_Apk.as<float>(),
-            h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
-      if (doB)
-        prep_side_kernel<1><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
-            dV, coef + D, coef + 2 * D, 0, psi, D, Nt, op.Npad, op.KQ, nullptr, nullptr, h->s_Bpk.as<float>(),
-            h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+      auto few_rows = [&](int64_t rpad) { return h->prep_variant == 3 || (h->prep_variant != 2 && rpad <= 32768); };
+#define PREP_SIDE(SIDE_, RW_, RPAD_, ...) prep_side_kernel<SIDE_, RW_><<<(unsigned)((RPAD_) / (4 * RW_)), 256, 0, h->stream>>>(__VA_ARGS__)
+      if (doA && doB && few_rows(op.Mpad) && few_rows(op.Npad)) {
+        const PrepSideArgs a{dU, coef, M, op.Mpad, h->s_Apk.as<float>(), h->s_rbias.as<float>(), h->s_rpair.as<float2>()};
+        const PrepSideArgs b{dV, coef + D, Nt, op.Npad, h->s_Bpk.as<float>(), h->s_cbias.as<float>(), h->s_cpair.as<float2>()};
+        prep_both_kernel<<<(unsigned)((op.Mpad + op.Npad) / 16), 256, 0, h->stream>>>(a, b, (int)(op.Mpad / 16), coef + 2 * D, n_uniform, psi, D, op.KQ,
+                                                                                     dzmean, dzstd, h->s_rscale.as<float>());
+        PLDA_LAUNCH_CHECK(h);
+        return PLDA_OK;
+      }
+      if (doA) {
+        if (few_rows(op.Mpad))
+          PREP_SIDE(0, 4, op.Mpad, dU, coef, coef + 2 * D, n_uniform, psi, D, M, op.Mpad, op.KQ, dzmean, dzstd, h->s_Apk.as<float>(),
+                    h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+        else
+          PREP_SIDE(0, 16, op.Mpad, dU, coef, coef + 2 * D, n_uniform, psi, D, M, op.Mpad, op.KQ, dzmean, dzstd, h->s_Apk.as<float>(),
+                    h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+      }
+      if (doB) {
+        if (few_rows(op.Npad))
+          PREP_SIDE(1, 4, op.Npad, dV, coef + D, coef + 2 * D, 0, psi, D, Nt, op.Npad, op.KQ, nullptr, nullptr, h->s_Bpk.as<float>(),
+                    h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+        else
+          PREP_SIDE(1, 16, op.Npad, dV, coef + D, coef + 2 * D, 0, psi, D, Nt, op.Npad, op.KQ, nullptr, nullptr, h->s_Bpk.as<float>(),
+                    h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+      }
+#undef PREP_SIDE
       PLDA_LAUNCH_CHECK(h);
       return PLDA_OK;
     }
@@ -1538,12 +1597,6 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       h->last_kernel = "trials_gemm_bt4_kernel";
       Bt4Table *tb = nullptr;
       PLDA_TRY(bt4_schedule(h, btM, btN, op.KQ, &tb));
-      // the queues' counters start behind every workgroup's first tile
-      {
-        Bt4Init bi;
-        for (int x = 0; x < 8; ++x) bi.v[x] = tb->init[x];
-        bt4_reset_kernel<<<1, 64, 0, h->stream>>>(h->bt4_cnt.as<unsigned>(), bi);
-      }
       // tiles that cross the matrix edge are written whole into scratch slots and copied out behind the launch
       const int rag_m = (M & 255) != 0, rag_n = (Nt & 255) != 0;
       const int fslots = (rag_m || rag_n) ? btM + btN : 0;

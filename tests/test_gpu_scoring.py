@@ -413,7 +413,7 @@ def test_prepared_test_side_is_reused_and_invalidated():
 
 
 @pytest.mark.parametrize("d,m,nt,n_enrol", [(200, 300, 517, 1), (200, 2049, 1100, 7), (7, 65, 64, 3), (1, 5, 700, 1), (129, 64, 1, 2),
-                                            (512, 130, 257, 100), (263, 1000, 129, 4)])
+                                            (512, 130, 257, 100), (263, 1000, 129, 4), (64, 200, 33000, 2), (40, 33000, 100, 1)])
 @pytest.mark.parametrize("znorm", [False, True])
 def test_one_pass_prep_bit_identical(monkeypatch, d, m, nt, n_enrol, znorm):
     """prep_side_kernel (one pass over a side's rows: bias, bias pair and packed operand) against the separate
@@ -432,7 +432,9 @@ def test_one_pass_prep_bit_identical(monkeypatch, d, m, nt, n_enrol, znorm):
     zs = torch.from_numpy(rng.random(m) + 0.5).to(dev)
     zs[m // 2] = 0.0
     outs = []
-    for variant in ("0", "1"):
+    # 2 / 3: prep_side_kernel with 16 / 4 rows per wave; the product (0) picks by row count -- two short sides (<= 32 768 rows) share
+    # ONE launch (prep_both_kernel), a short and a long side take one kernel each
+    for variant in ("0", "1", "2", "3"):
         monkeypatch.setenv("PLDA_PREP_VARIANT", variant)
         eng = MPlda(0)
         eng.set_model(*model)
@@ -441,8 +443,37 @@ def test_one_pass_prep_bit_identical(monkeypatch, d, m, nt, n_enrol, znorm):
                              zm.data_ptr() if znorm else None, zs.data_ptr() if znorm else None)
         torch.cuda.synchronize()
         outs.append(o)
-    assert torch.equal(outs[0], outs[1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
     assert bool((outs[0][:, nt:] == -7.0).all()) and bool(torch.isfinite(outs[0][:, :nt]).all())
+
+
+def test_uniform_coefficients_follow_count_and_model(oracle):
+    """The per-dimension coefficients of the uniform-count path are kept on the device across calls, keyed by (model, count,
+    dimension): a call with another count, a mixed-count call in between (its tables share the buffer), set_model and smooth
+    each must be seen -- every call equals the oracle, and a fresh engine's bits."""
+    from plda_amd import MPlda
+    d, m, nt = 72, 300, 517
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
+    counts = rng.integers(1, 4, m).astype(np.int32)
+    eng = MPlda(0)
+    models = [(rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy()) for _ in range(2)]
+    for mean, T, psi in models:
+        eng.set_model(mean, T, psi)
+        for n in (2, 2, 5, counts, 5, 2):
+            got = eng.score_matrix((n, U), (1, V))
+            ref = oracle.score_block(psi, U, n, V)
+            assert (np.abs(got - ref) <= score_tol(ref)).all(), (n if np.isscalar(n) else "mixed", np.abs(got - ref).max())
+            fresh = MPlda(0)
+            fresh.set_model(mean, T, psi)
+            assert np.array_equal(fresh.score_matrix((n, U), (1, V)), got)
+    eng.smooth(0.3)
+    fresh = MPlda(0)
+    fresh.set_model(*models[1])
+    fresh.smooth(0.3)
+    assert np.array_equal(fresh.score_matrix((2, U), (1, V)), eng.score_matrix((2, U), (1, V)))
 
 
 @pytest.mark.parametrize("dout", [200, 197, 193])
