@@ -133,6 +133,7 @@ struct plda_handle {
   int transform_variant = 0;   // PLDA_TRANSFORM_VARIANT=1: general GEMM + separate length-norm pass; 2: no tail launch (A/B arms)
   int gemm_variant = 0;
   int mixed_variant = 0;   // PLDA_MIXED_VARIANT=1: mixed enrol counts always in the depth-2D form [A1 | A2] x [V | V*V] (A/B arm of the bucketed form)
+  const double *gcoef_ptr = nullptr; uint64_t gcoef_epoch = 0; int gcoef_D = 0; plda::CountSet gcoef_set;   // bucket tables in w[11], same rule
   const double *ucoef_ptr = nullptr; uint64_t ucoef_epoch = 0; int ucoef_n = 0, ucoef_D = 0;   // uniform-count coefficients in w[11] (score.hip: prepare_operands)
   int prep_variant = 0;    // PLDA_PREP_VARIANT=1: scoring prep as separate bias / pack / pair kernels (A/B arm of prep_side_kernel)
   int gemm64_variant = 0;  // PLDA_GEMM64_VARIANT=1: fp64 GEMM always on 64 x 64 tiles (A/B arm)
@@ -150,7 +151,7 @@ struct plda_handle {
   uint64_t bt4_clock = 0;
   // distinct enrol counts of a mixed-count call: presence bytes + result on the device, pinned landing area
   plda::DevBuf cs_work;
-  void *cs_pin = nullptr;
+  void *cs_pin = nullptr; int cs_seq = 0;   // pinned words of the count-set result + the sequence number its kernel stores last (score.hip)
   bool timeline_valid = false;   // `timeline` holds the stamps of a PLDA_GEMM_VARIANT=31 launch
   plda::DevBuf timeline;
 

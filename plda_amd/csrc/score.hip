@@ -22,6 +22,9 @@
 // one contiguous 1 KiB burst and lands lane-linear in LDS, and (2) the MFMA
 // fragment read is one conflict-free ds_read_b128 per lane that feeds 4 MFMAs.
 #include "common.hpp"
+#include <atomic>
+#include <chrono>
+#include <cstring>
 
 #include <algorithm>
 
@@ -395,26 +398,65 @@ __global__ __launch_bounds__(256) void count_compact_kernel(const unsigned char 
   if (lane == 0) { out->G = total; out->overflow = (flags[0] != 0 || total > CS_MAX) ? 1 : 0; }
 }
 
+// Both steps in ONE workgroup for up to CS_ONE_WG counts, the result written straight into the caller's pinned host words
+// behind a system-scope fence, `seq` last: the host needs the set before it can size the operands, and memset + two
+// kernels + a copy + a stream synchronisation were 40 us of a 154 us call at 4096 x 4096 x 200 with counts 1..5.
+constexpr int64_t CS_ONE_WG = 131072;
+struct CountSetHost { CountSetDev set; int seq; };
+__global__ __launch_bounds__(1024) void count_set_one_wg_kernel(const int32_t *__restrict__ n, int M, int seq, CountSetHost *__restrict__ out /*pinned host*/) {
+  __shared__ unsigned char pr[CS_NMAX + 1];
+  __shared__ int bad;
+  for (int i = threadIdx.x; i <= CS_NMAX; i += 1024) pr[i] = 0;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < M; i0 += 4096) {
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024 + (int)threadIdx.x; v[u] = i < M ? n[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (v[u] >= 1 && v[u] <= CS_NMAX) pr[v[u]] = 1;            // (racing stores of the same byte value)
+      else if (i0 + u * 1024 + (int)threadIdx.x < M) bad = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  int cnt = 0;
+  for (int k = 0; k < 64; ++k) cnt += pr[lane * 64 + k] ? 1 : 0;
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int total = __shfl(incl, 63);
+  int pos = incl - cnt;
+  for (int k = 0; k < 64; ++k)
+    if (pr[lane * 64 + k]) { if (pos < CS_MAX) out->set.vals[pos] = lane * 64 + k; ++pos; }
+  if (lane == 0) { out->set.G = total; out->set.overflow = (bad != 0 || total > CS_MAX) ? 1 : 0; }
+  __threadfence_system();
+  if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // enrol side of the bucketed form, one pass over the fp64 rows (the structure of prep_side_kernel<0>; the coefficients
 // are the row's own): A1 = c u / var (* s_i), r'_i, s_i, rpair, and the KQx extra k-quad planes s_i x onehot(b_i - 1)
+template <int RW>
 __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *__restrict__ X, const int32_t *__restrict__ n_arr, const CountSet cs,
                                                                  const double *__restrict__ coefG /*[G][2 D + 1]*/, const double *__restrict__ psi, int D,
                                                                  int64_t R, int64_t Rpad, int KQm, int KQx, const double *__restrict__ zmean,
                                                                  const double *__restrict__ zstd, float *__restrict__ P, float *__restrict__ bias,
                                                                  float *__restrict__ rscale, float2 *__restrict__ pair) {
-  __shared__ float tile[2][64][65];
-  __shared__ int sb[64];
-  __shared__ float ss[64];
+  constexpr int RPB = 4 * RW;                 // rows of a workgroup (RW rows per wave: 16, or 4 for short sides -- see prep_side_kernel)
+  __shared__ float tile[2][64][RPB + 1];
+  __shared__ int sb[RPB];
+  __shared__ float ss[RPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
-  const int64_t wrow0 = row0 + wave * 16;
+  const int64_t row0 = (int64_t)blockIdx.x * RPB;
+  const int64_t wrow0 = row0 + wave * RW;
   const int nchunk = (KQm * 4 + 63) >> 6;
   const bool zn = zmean && zstd;
   const int S = 2 * D + 1;
-  float rsf[16];
-  double nn[16], Lr[16];
+  float rsf[RW];
+  double nn[RW], Lr[RW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < RW; ++j) {
     const int64_t row = wrow0 + j;
     rsf[j] = 1.f;
     if (zn && row < R) { const double sd = zstd[row]; rsf[j] = (float)(sd != 0.0 ? 1.0 / sd : 1.0); }
@@ -423,15 +465,15 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
     for (int g = 1; g < cs.G; ++g) b = cs.vals[g] == n ? g : b;
     nn[j] = (double)n;
     Lr[j] = coefG[(size_t)b * S + 2 * D];
-    if (lane == 0) { sb[wave * 16 + j] = row < R ? b : 0; ss[wave * 16 + j] = rsf[j]; }
+    if (lane == 0) { sb[wave * RW + j] = row < R ? b : 0; ss[wave * RW + j] = rsf[j]; }
   }
-  double acc[16], xc[16], xn[16];
+  double acc[RW], xc[RW], xn[RW];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { acc[j] = 0.0; xn[j] = 0.0; }
-  auto fetch = [&](int c, double (&x)[16]) {
+  for (int j = 0; j < RW; ++j) { acc[j] = 0.0; xn[j] = 0.0; }
+  auto fetch = [&](int c, double (&x)[RW]) {
     const int d = c * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < RW; ++j) {
       const int64_t row = wrow0 + j;
       x[j] = (d < D && row < R) ? X[row * (int64_t)D + d] : 0.0;
     }
@@ -439,14 +481,14 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
   fetch(0, xn);
   for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xc[j] = xn[j];
+    for (int j = 0; j < RW; ++j) xc[j] = xn[j];
     if (c + 1 < nchunk) fetch(c + 1, xn);
     const int d = c * 64 + lane;
     const bool dv = d < D;
     const double p = dv ? psi[d] : 0.0;
-    float(*const tl)[65] = tile[c & 1];
+    float(*const tl)[RPB + 1] = tile[c & 1];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < RW; ++j) {
       const double x = xc[j];
       float val = 0.f;
       if (dv && wrow0 + j < R) {
@@ -457,14 +499,14 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
         if (zn) v *= (double)rsf[j];
         val = (float)v;
       }
-      tl[lane][wave * 16 + j] = val;
+      tl[lane][wave * RW + j] = val;
     }
     __syncthreads();
     {
-      const int r = threadIdx.x & 63;
+      const int r = threadIdx.x % RPB;
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int q = (threadIdx.x >> 6) + pass * 4;   // k-quad of the chunk, 0..15
+      for (int pass = 0; pass < RPB / 16; ++pass) {
+        const int q = threadIdx.x / RPB + pass * (256 / RPB);   // k-quad of the chunk, 0..15
         const int kq = c * 16 + q;
         if (kq < KQm) {
           f32x4 v;
@@ -479,16 +521,16 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
   }
   // (sb / ss were written before the loop's first barrier; nchunk >= 1)
   {
-    const int r = threadIdx.x & 63;
+    const int r = threadIdx.x % RPB;
     const int pcol = sb[r] - 1;
-    for (int e = threadIdx.x >> 6; e < KQx; e += 4) {
+    for (int e = threadIdx.x / RPB; e < KQx; e += 256 / RPB) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pcol >= 0 && (pcol >> 2) == e) v[pcol & 3] = ss[r];
       reinterpret_cast<f32x4 *>(P)[(int64_t)(KQm + e) * Rpad + row0 + r] = v;
     }
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < RW; ++j) {
     double a = acc[j];
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     const int64_t row = wrow0 + j;
@@ -511,15 +553,17 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
 // (round 5, second version: the coefficient differences of a group of four buckets live in REGISTERS for the 16 rows a wave
 //  handles -- per lane eight chunks of 64 dimensions, D <= 512 -- so that the inner loop is one 8-byte load and four FMAs per
 //  element; the first version re-read five coefficients from L1 per element and took 1.26 ms for C4's 2.4 GB of test rows.)
+template <int RW>
 __global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__restrict__ V, const double *__restrict__ coefG, int G, int D,
                                                                 int64_t R, int64_t Rpad, int KQm, int KQx, float *__restrict__ P) {
-  __shared__ float q[CS_MAX][65];
+  constexpr int RPB = 4 * RW;
+  __shared__ float q[CS_MAX][RPB + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
-  for (int i = threadIdx.x; i < CS_MAX * 65; i += 256) (&q[0][0])[i] = 0.f;
+  const int64_t row0 = (int64_t)blockIdx.x * RPB;
+  for (int i = threadIdx.x; i < CS_MAX * (RPB + 1); i += 256) (&q[0][0])[i] = 0.f;
   __syncthreads();
   const int S = 2 * D + 1;
-  const int64_t wrow0 = row0 + wave * 16;
+  const int64_t wrow0 = row0 + wave * RW;
   const bool cached = D <= 512;
   for (int g0 = 1; g0 < G && wrow0 < R; g0 += 4) {
     const bool h1 = g0 + 1 < G, h2 = g0 + 2 < G, h3 = g0 + 3 < G;
@@ -537,7 +581,7 @@ __global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__
         dc[3][c] = ok && h3 ? c0[3 * S + d] - gb : 0.0;
       }
     }
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < RW; ++j) {
       const int64_t row = wrow0 + j;
       if (row >= R) break;
       const double *v = V + row * (int64_t)D;
@@ -560,16 +604,16 @@ __global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__
       }
       a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2); a3 = wave_sum_f64(a3);
       if (lane == 0) {
-        q[g0 - 1][wave * 16 + j] = (float)(-0.5 * a0);
-        if (h1) q[g0][wave * 16 + j] = (float)(-0.5 * a1);
-        if (h2) q[g0 + 1][wave * 16 + j] = (float)(-0.5 * a2);
-        if (h3) q[g0 + 2][wave * 16 + j] = (float)(-0.5 * a3);
+        q[g0 - 1][wave * RW + j] = (float)(-0.5 * a0);
+        if (h1) q[g0][wave * RW + j] = (float)(-0.5 * a1);
+        if (h2) q[g0 + 1][wave * RW + j] = (float)(-0.5 * a2);
+        if (h3) q[g0 + 2][wave * RW + j] = (float)(-0.5 * a3);
       }
     }
   }
   __syncthreads();
-  const int r = threadIdx.x & 63;
-  for (int e = threadIdx.x >> 6; e < KQx; e += 4) {
+  const int r = threadIdx.x % RPB;
+  for (int e = threadIdx.x / RPB; e < KQx; e += 256 / RPB) {
     f32x4 v;
     v.x = q[4 * e + 0][r];
     v.y = q[4 * e + 1][r];
@@ -1414,16 +1458,35 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
     PLDA_HIP(h, h->w[11].reserve((size_t)G * (2 * D + 1) * 8));
     double *coefG = h->w[11].as<double>();
     h->ucoef_ptr = nullptr;          // (the uniform path's cached coefficients live in the same buffer)
-    bucket_coef_kernel<<<G, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, *cs, coefG);
-    if (doA)
-      prep_enrol_buckets_kernel<<<(unsigned)(op.Mpad / 64), 256, 0, h->stream>>>(
-          dU, dn, *cs, coefG, h->d_psi.as<double>(), D, M, op.Mpad, KQm, KQx, dzmean, dzstd, h->s_Apk.as<float>(),
-          h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+    // the tables depend on (model, dimension, the set of counts) only: kept across calls like the uniform path's
+    if (!(h->gcoef_ptr == coefG && h->gcoef_epoch == h->model_epoch && h->gcoef_D == D && h->gcoef_set.G == G &&
+          std::memcmp(h->gcoef_set.vals, cs->vals, (size_t)G * sizeof(int32_t)) == 0)) {
+      bucket_coef_kernel<<<G, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, *cs, coefG);
+      h->gcoef_ptr = coefG; h->gcoef_epoch = h->model_epoch; h->gcoef_D = D; h->gcoef_set = *cs;
+    }
+    auto few = [&](int64_t rpad) { return h->prep_variant == 3 || (h->prep_variant != 2 && rpad <= 32768); };   // (as the uniform path below)
+    if (doA) {
+      if (few(op.Mpad))
+        prep_enrol_buckets_kernel<4><<<(unsigned)(op.Mpad / 16), 256, 0, h->stream>>>(
+            dU, dn, *cs, coefG, h->d_psi.as<double>(), D, M, op.Mpad, KQm, KQx, dzmean, dzstd, h->s_Apk.as<float>(),
+            h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+      else
+        prep_enrol_buckets_kernel<16><<<(unsigned)(op.Mpad / 64), 256, 0, h->stream>>>(
+            dU, dn, *cs, coefG, h->d_psi.as<double>(), D, M, op.Mpad, KQm, KQx, dzmean, dzstd, h->s_Apk.as<float>(),
+            h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>());
+    }
     if (doB) {
-      prep_side_kernel<1, 16><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
-          dV, coefG + D, coefG + 2 * D, 0, h->d_psi.as<double>(), D, Nt, op.Npad, KQm, nullptr, nullptr, h->s_Bpk.as<float>(),
-          h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
-      prep_test_buckets_kernel<<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(dV, coefG, G, D, Nt, op.Npad, KQm, KQx, h->s_Bpk.as<float>());
+      if (few(op.Npad)) {
+        prep_side_kernel<1, 4><<<(unsigned)(op.Npad / 16), 256, 0, h->stream>>>(
+            dV, coefG + D, coefG + 2 * D, 0, h->d_psi.as<double>(), D, Nt, op.Npad, KQm, nullptr, nullptr, h->s_Bpk.as<float>(),
+            h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+        prep_test_buckets_kernel<4><<<(unsigned)(op.Npad / 16), 256, 0, h->stream>>>(dV, coefG, G, D, Nt, op.Npad, KQm, KQx, h->s_Bpk.as<float>());
+      } else {
+        prep_side_kernel<1, 16><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(
+            dV, coefG + D, coefG + 2 * D, 0, h->d_psi.as<double>(), D, Nt, op.Npad, KQm, nullptr, nullptr, h->s_Bpk.as<float>(),
+            h->s_cbias.as<float>(), nullptr, h->s_cpair.as<float2>());
+        prep_test_buckets_kernel<16><<<(unsigned)(op.Npad / 64), 256, 0, h->stream>>>(dV, coefG, G, D, Nt, op.Npad, KQm, KQx, h->s_Bpk.as<float>());
+      }
     }
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
@@ -1445,6 +1508,7 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
     // the per-dimension coefficients depend on (model, count) only: kept across calls (4.7 us of launch otherwise)
     if (!(h->ucoef_ptr == coef && h->ucoef_epoch == h->model_epoch && h->ucoef_n == n_uniform && h->ucoef_D == D)) {
       uniform_coef_kernel<<<1, 256, 0, h->stream>>>(psi, D, n_uniform, coef);
+      h->gcoef_ptr = nullptr;
       h->ucoef_ptr = coef; h->ucoef_epoch = h->model_epoch; h->ucoef_n = n_uniform; h->ucoef_D = D;
     }
     if (h->prep_variant == 0) {
@@ -1770,18 +1834,37 @@ int score_count_set_device(plda_handle *h, const int32_t *dn, int64_t M, CountSe
   cs->G = 0;
   if (h->mixed_variant == 1) return PLDA_OK;
   TraceScope ts(h, "score.count_set");
-  const size_t off_flags = round_up(CS_NMAX + 1, 16), off_out = off_flags + 16;
-  PLDA_HIP(h, h->cs_work.reserve(off_out + sizeof(CountSetDev)));
-  if (!h->cs_pin) PLDA_HIP(h, hipHostMalloc(&h->cs_pin, sizeof(CountSetDev), hipHostMallocDefault));
-  unsigned char *present = h->cs_work.as<unsigned char>();
-  int *flags = reinterpret_cast<int *>(present + off_flags);
-  CountSetDev *dres = reinterpret_cast<CountSetDev *>(present + off_out);
-  PLDA_HIP(h, hipMemsetAsync(present, 0, off_out, h->stream));
-  count_presence_kernel<<<(unsigned)std::min<int64_t>(ceil_div(M, 256), 1024), 256, 0, h->stream>>>(dn, M, present, flags);
-  count_compact_kernel<<<1, 256, 0, h->stream>>>(present, flags, dres);
-  PLDA_LAUNCH_CHECK(h);
-  PLDA_HIP(h, hipMemcpyAsync(h->cs_pin, dres, sizeof(CountSetDev), hipMemcpyDeviceToHost, h->stream));
-  PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  if (!h->cs_pin) {
+    PLDA_HIP(h, hipHostMalloc(&h->cs_pin, sizeof(CountSetHost), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(h->cs_pin, 0, sizeof(CountSetHost));
+  }
+  if (M <= CS_ONE_WG) {
+    CountSetHost *hp = static_cast<CountSetHost *>(h->cs_pin);
+    const int seq = ++h->cs_seq;
+    count_set_one_wg_kernel<<<1, 1024, 0, h->stream>>>(dn, (int)M, seq, hp);
+    PLDA_LAUNCH_CHECK(h);
+    // the kernel's last store is `seq`: poll it for a while (a few us after the kernel ends), then fall back to the stream
+    volatile int *const flag = &hp->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(300)) {
+      if (*flag == seq) { seen = true; break; }
+    }
+    if (!seen) PLDA_HIP(h, hipStreamSynchronize(h->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    const size_t off_flags = round_up(CS_NMAX + 1, 16), off_out = off_flags + 16;
+    PLDA_HIP(h, h->cs_work.reserve(off_out + sizeof(CountSetDev)));
+    unsigned char *present = h->cs_work.as<unsigned char>();
+    int *flags = reinterpret_cast<int *>(present + off_flags);
+    CountSetDev *dres = reinterpret_cast<CountSetDev *>(present + off_out);
+    PLDA_HIP(h, hipMemsetAsync(present, 0, off_out, h->stream));
+    count_presence_kernel<<<(unsigned)std::min<int64_t>(ceil_div(M, 256), 1024), 256, 0, h->stream>>>(dn, M, present, flags);
+    count_compact_kernel<<<1, 256, 0, h->stream>>>(present, flags, dres);
+    PLDA_LAUNCH_CHECK(h);
+    PLDA_HIP(h, hipMemcpyAsync(h->cs_pin, dres, sizeof(CountSetDev), hipMemcpyDeviceToHost, h->stream));
+    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+  }
   const CountSetDev *r = static_cast<const CountSetDev *>(h->cs_pin);
   if (r->overflow || r->G < 1 || r->G > CS_MAX) return PLDA_OK;
   cs->G = r->G;

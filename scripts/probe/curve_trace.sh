@@ -1,8 +1,10 @@
+# kernel trace of the last dispatches of scripts/score_size_curve.py calls.  TRACES="D MxNt;D MxNt" EXTRA=mixed
 cd /tmp; export TMPDIR=/tmp
-for T in "200 8192x8192" "512 256x256" "200 4096x4096"; do
+IFS=";" read -ra LIST <<< "${TRACES:-200 8192x8192;512 256x256;200 4096x4096}"
+for T in "${LIST[@]}"; do
  set -- $T
  OUT=$GRAFT_REPO_ROOT/gpurun_out/curve_trace_$1_$2; rm -rf $OUT
- timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $GRAFT_REPO_ROOT/scripts/score_size_curve.py $1 - $2 > $OUT.log 2>&1
+ timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $GRAFT_REPO_ROOT/scripts/score_size_curve.py $1 - $2 $EXTRA > $OUT.log 2>&1
  python - <<PY
 import csv,glob
 rows=[]

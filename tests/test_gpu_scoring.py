@@ -450,8 +450,8 @@ def test_one_pass_prep_bit_identical(monkeypatch, d, m, nt, n_enrol, znorm):
 
 def test_uniform_coefficients_follow_count_and_model(oracle):
     """The per-dimension coefficients of the uniform-count path are kept on the device across calls, keyed by (model, count,
-    dimension): a call with another count, a mixed-count call in between (its tables share the buffer), set_model and smooth
-    each must be seen -- every call equals the oracle, and a fresh engine's bits."""
+    dimension), and so are the bucket tables of a mixed-count call, keyed by the set of counts; both live in one buffer: another
+    count, another set, the other kind of call in between, set_model and smooth each must be seen -- every call equals the oracle, and a fresh engine's bits."""
     from plda_amd import MPlda
     d, m, nt = 72, 300, 517
     rng = np.random.default_rng(5)
@@ -462,7 +462,8 @@ def test_uniform_coefficients_follow_count_and_model(oracle):
     models = [(rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy()) for _ in range(2)]
     for mean, T, psi in models:
         eng.set_model(mean, T, psi)
-        for n in (2, 2, 5, counts, 5, 2):
+        counts2 = np.where(counts == 2, 7, counts).astype(np.int32)      # another set of distinct counts: {1, 3, 7}
+        for n in (2, 2, 5, counts, counts, 5, counts2, counts, 2):
             got = eng.score_matrix((n, U), (1, V))
             ref = oracle.score_block(psi, U, n, V)
             assert (np.abs(got - ref) <= score_tol(ref)).all(), (n if np.isscalar(n) else "mixed", np.abs(got - ref).max())
