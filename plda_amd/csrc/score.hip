@@ -1644,18 +1644,29 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   // persistent 256 x 256 kernel: when there are enough tiles to keep 256 CUs busy (PLDA_GEMM_VARIANT=20
   // forces the 128 x 128 kernel, 30 the 256 x 256 one, 31 its timeline-instrumented instantiation)
   const int btM = (int)ceil_div(M, 256), btN = (int)(op.Npad / 256);
-  const bool big = EPI == 0 && (int64_t)btM * btN >= 1024;
+  // Which kernel (round 5: measured over sizes with scripts/gemm_sweep.py and scripts/score_size_curve.py under PLDA_GEMM_VARIANT
+  // 20 / 30 / 40).  The one-wave-per-SIMD kernel is the fastest per tile but pays ~30 us per launch (cold first stages, the
+  // last tiles' 64 MB of stores, all workgroups ending together): it wins from ~1 700 tiles of 256 x 256.  Between 512 and
+  // 1 700 tiles the two-waves kernel is 3-9 % ahead of both others (8192 x 8192 x 200: 0.237 ms against 0.249 / 0.252;
+  // 2048 x 40000: 0.284 against 0.311 / 0.310) -- when its static 4 x 8 patches are mostly full: 512 x 200000 (two tile rows)
+  // takes 0.73 ms on it and 0.49 on the others.  Below 512 tiles the 128 x 128 kernel.  PLDA_GEMM_VARIANT=50: the thresholds
+  // of rounds 4-5a (1 024 tiles for both 256 x 256 kernels).
+  const int64_t tiles = (int64_t)btM * btN;
+  const bool patches_full = (double)tiles >= 0.85 * (double)(round_up(btM, BPR) * round_up(btN, BPC));
+  const bool old_rule = h->gemm_variant == 50;
+  const bool big = EPI == 0 && tiles >= (old_rule ? 1024 : 1700);                       // -> one wave per SIMD (given K >= 72)
+  const bool big2 = EPI == 0 && (old_rule ? tiles >= 1024 : (tiles >= 1700 || (tiles >= 512 && patches_full)));   // -> two waves per SIMD otherwise
   // it needs 32-bit byte offsets into each packed operand and into a tile's output rows
   const bool fits4g = (int64_t)(op.KQ + 8) * op.Mpad * 16 < (1ll << 32) && (int64_t)(op.KQ + 8) * op.Npad * 16 < (1ll << 32);
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
-                       ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || (h->gemm_variant == 0 && big));
+                       ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || ((h->gemm_variant == 0 || old_rule) && big2));
   // one wave per SIMD, 128 x 128 per wave (score_bt4.inc) -- the product path of every BASELINE configuration since round 4
   // (>= 1024 tiles of 256 x 256 and K >= 104); PLDA_GEMM_VARIANT 40 forces it, 30 forces the round-2/3 kernel, 41 its timeline
   // instantiation, 44 / 45 / 46 its bounding arms (no DMA / no stores / neither); needs >= 3 stages per tile (K >= 72).
   {
     const int nsteps = op.KQ >> 1, nst = (nsteps + 3) >> 2;
     const bool use_bt4 = EPI == 0 && fits4g && ld < (1ll << 22) && nst >= 3 && M < (1ll << 31) && Nt < (1ll << 31) &&
-                         (h->gemm_variant == 40 || h->gemm_variant == 41 || h->gemm_variant == 48 || h->gemm_variant == 49 || (h->gemm_variant >= 44 && h->gemm_variant <= 47) || (h->gemm_variant == 0 && big));
+                         (h->gemm_variant == 40 || h->gemm_variant == 41 || h->gemm_variant == 48 || h->gemm_variant == 49 || (h->gemm_variant >= 44 && h->gemm_variant <= 47) || ((h->gemm_variant == 0 || old_rule) && big));
     if (use_bt4) {
       const int sbase = nsteps / nst, fs = sbase + (nsteps - sbase * nst > 0 ? 1 : 0);
       h->last_kernel = "trials_gemm_bt4_kernel";

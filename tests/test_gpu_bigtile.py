@@ -274,7 +274,7 @@ def test_alternating_tile_grids_do_not_stall_the_host(monkeypatch):
     import torch
     dev = torch.device("cuda", 0)
     d = 512
-    eng, _ = _engine(monkeypatch, None, d, 41)
+    eng, _ = _engine(monkeypatch, 40, d, 41)       # (the one-wave-per-SIMD kernel whatever the size: the product takes it from ~1 700 tiles)
     # (a stream of its own, as bench.py uses: launches on the legacy null stream are ordered against every other stream of
     #  the process, and what else the test process has in flight then shows up in the enqueue time)
     stream = torch.cuda.Stream(device=dev)
