@@ -85,6 +85,45 @@ def _compact_labels(Y):
     return np.ascontiguousarray(inv.astype(np.uint64)), int(uniq.shape[0])
 
 
+class Transformed(dict):
+    """What `transform()` returns: the reference's dict {label: (n, ndarray f64[D])} (pldamodule.cpp:162-191), which also
+    remembers the three arrays it was built from -- labels, counts and the [Ku, D] block the row views point into -- so that
+    `score_matrix` / `score_trials` / `norm` take them as they are instead of re-stacking Ku rows in Python (2 000 entries: ~1 ms,
+    more than the GPU call).  Any change of the KEYS drops the memory and the dict is unpacked like any other; the rows are
+    views, so writing into a vector is seen either way."""
+    __slots__ = ("_packed",)
+
+    def _forget(self):
+        self._packed = None
+
+    def __setitem__(self, k, v):
+        self._forget(); dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._forget(); dict.__delitem__(self, k)
+
+    def pop(self, *a):
+        self._forget(); return dict.pop(self, *a)
+
+    def popitem(self):
+        self._forget(); return dict.popitem(self)
+
+    def clear(self):
+        self._forget(); dict.clear(self)
+
+    def update(self, *a, **kw):
+        self._forget(); dict.update(self, *a, **kw)
+
+    def setdefault(self, *a):
+        self._forget(); return dict.setdefault(self, *a)
+
+    def __ior__(self, other):
+        self._forget(); return dict.__ior__(self, other)
+
+    def __reduce__(self):          # pickles and deep copies are ordinary dicts (the block and its row views would part)
+        return (dict, (dict(self),))
+
+
 class MPlda(object):
     """GPU-resident PLDA model + z-norm statistics (MPlda struct, pldamodule.cpp:27-34)."""
 
@@ -238,7 +277,9 @@ class MPlda(object):
         g = cap.value
         vecs = out_vecs[:g].copy()
         # keys / counts as Python ints and one row view per label, all built by C-level iteration
-        return dict(zip(out_labels[:g].tolist(), zip(out_counts[:g].tolist(), vecs)))
+        res = Transformed(zip(out_labels[:g].tolist(), zip(out_counts[:g].tolist(), vecs)))
+        res._packed = (out_labels[:g].astype(np.int64), out_counts[:g].astype(np.int32), vecs)
+        return res
 
     def transform_array(self, xbar, num_examples=1):
         """Batched Plda::TransformIvector on already-averaged rows -> ndarray [R, D]."""
@@ -275,11 +316,15 @@ class MPlda(object):
         ids = list(transformedvecs.keys())
         if not ids:
             return None
-        for k in ids:
-            if not isinstance(k, (int, np.integer)) or not isinstance(transformedvecs[k], tuple):
-                return None  # the reference bails out with NULL (:229-230)
-        models = self._check_dim(np.ascontiguousarray(np.stack([np.asarray(transformedvecs[k][1], np.float64) for k in ids])),
-                                 "norm: model vectors")
+        packed = getattr(transformedvecs, "_packed", None) if isinstance(transformedvecs, Transformed) else None
+        if packed is not None and packed[0].shape[0] == len(ids):
+            models = self._check_dim(packed[2], "norm: model vectors")       # transform()'s own block, as it is
+        else:
+            for k in ids:
+                if not isinstance(k, (int, np.integer)) or not isinstance(transformedvecs[k], tuple):
+                    return None  # the reference bails out with NULL (:229-230)
+            models = self._check_dim(np.ascontiguousarray(np.stack([np.asarray(transformedvecs[k][1], np.float64) for k in ids])),
+                                     "norm: model vectors")
         if d != self.dims()[1]:
             raise ValueError("norm: cohort vectors have %d features, the model expects %d" % (d, self.dims()[1]))
         mean, std = np.zeros(len(ids)), np.zeros(len(ids))
@@ -352,6 +397,10 @@ class MPlda(object):
 
     def _unpack(self, side):
         """dict {id: (n, vec)} or (counts, vecs[, ids]) -> ids, counts(int32), vecs."""
+        if isinstance(side, Transformed):
+            packed = getattr(side, "_packed", None)
+            if packed is not None and packed[0].shape[0] == len(side):
+                return packed[0], packed[1], self._check_dim(packed[2])
         if isinstance(side, dict):
             ids = np.array(list(side.keys()), dtype=np.int64)
             counts = np.array([int(side[k][0]) for k in side], np.int32)

@@ -289,3 +289,42 @@ def test_trace_spans_cover_the_fit_stages():
     eng.trace_enable(False)
     eng.fit(X, y, 1)
     assert eng.trace_read() == []
+
+
+def test_transform_result_is_a_dict_that_remembers_its_arrays(oracle):
+    """transform() returns the reference's dict {label: (n, vec)} (pldamodule.cpp:162-191) as a dict SUBCLASS that keeps the
+    arrays it was built from, so score_matrix / score_trials / norm skip the per-entry re-stacking.  It must behave as the plain
+    dict in every use: same scores as a plain copy; a change of the keys (delete, insert, pop, update) falls back to unpacking;
+    writing into a vector is seen by both; copies and pickles are ordinary dicts again."""
+    import copy
+    import pickle
+    from liblda import PLDA
+    from plda_amd.libplda import Transformed
+    x, y = make_data(12, 900, 24, 30)
+    p = PLDA()
+    p.fit(x, y, 3)
+    enrol = p.transform(x[:600], y[:600])
+    test = p.transform(x[600:], np.arange(300, dtype=np.uint64))
+    assert isinstance(enrol, dict) and isinstance(enrol, Transformed) and enrol._packed is not None
+    k0 = next(iter(enrol))
+    assert isinstance(k0, int) and isinstance(enrol[k0], tuple) and isinstance(enrol[k0][0], int)
+    S = p.score_matrix(enrol, test)
+    assert np.array_equal(S, p.score_matrix(dict(enrol), dict(test)))             # plain copies: the generic path
+    assert np.array_equal(S, p.score_matrix(copy.copy(enrol), pickle.loads(pickle.dumps(test))))
+    # writing into a vector (a view of the remembered block) is seen by both paths
+    enrol[k0][1][:] *= 0.5
+    S2 = p.score_matrix(enrol, test)
+    assert not np.array_equal(S2[0], S[0]) and np.array_equal(S2, p.score_matrix(dict(enrol), test))
+    # z-norm statistics from the remembered block and from a plain dict
+    q = PLDA(); q._instance.set_model(*[p._instance.get_model()[k] for k in ("mean", "transform", "psi")])
+    p.norm(x[:200], enrol); q.norm(x[:200], dict(enrol))
+    assert p._instance.znorm_stats() == q._instance.znorm_stats()
+    # a change of the keys drops the memory
+    removed = enrol.pop(k0)
+    assert enrol._packed is None and p.score_matrix(enrol, test, znorm=False).shape == (len(enrol), len(test))
+    assert np.array_equal(p.score_matrix(enrol, test, znorm=False), S2x := p.score_matrix(dict(enrol), test, znorm=False)) and S2x.shape[0] == S.shape[0] - 1
+    test2 = p.transform(x[600:], np.arange(300, dtype=np.uint64))
+    test2[10 ** 6] = removed
+    assert test2._packed is None and p.score_matrix(enrol, test2, znorm=False).shape == (len(enrol), 301)
+    del test2[10 ** 6]
+    assert np.array_equal(p.score_matrix(enrol, test2, znorm=False), S2x)
