@@ -51,7 +51,7 @@ int model_to_device(plda_handle *h) {
 // implemented in score.hip / fit.hip
 int score_pairs_device(plda_handle *h, const double *dU, const int32_t *dn, const double *dV,
                        const int64_t *de, const int64_t *dt, int64_t P, const double *dzmean,
-                       const double *dzstd, double *dout);
+                       const double *dzstd, double *dout, int64_t M = 0, const plda::CountSet *cs = nullptr);
 int znorm_stats_device(plda_handle *h, const double *dbkg, int64_t Nb, int num_examples, int Din,
                        const double *dmodels, int64_t M, double *dmean, double *dstd);
 int group_means_device(plda_handle *h, const double *dX, int64_t N, int D, const uint64_t *ddense,
@@ -968,9 +968,11 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
     if (!h->fitted) return fail(h, PLDA_E_NOT_FITTED, "score: model not fitted");
     if (P <= 0) return PLDA_OK;
     if (!U || !n_enrol || !V || !e_idx || !t_idx || !out || M <= 0 || Nt <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: bad argument");
-    for (int64_t p = 0; p < P; ++p)
-      if (e_idx[p] < 0 || e_idx[p] >= M || t_idx[p] < 0 || t_idx[p] >= Nt)
-        return fail(h, PLDA_E_INVAL, "score_pairs: trial %lld indexes outside the enrol/test sets", (long long)p);
+    const bool long_list = P >= 16384;      // (long lists: the indices are checked on the device, below -- 10^7 pairs are 10 ms of this loop)
+    if (!long_list)
+      for (int64_t p = 0; p < P; ++p)
+        if (e_idx[p] < 0 || e_idx[p] >= M || t_idx[p] < 0 || t_idx[p] >= Nt)
+          return fail(h, PLDA_E_INVAL, "score_pairs: trial %lld indexes outside the enrol/test sets", (long long)p);
     for (int64_t i = 0; i < M; ++i)
       if (n_enrol[i] <= 0) return fail(h, PLDA_E_INVAL, "score_pairs: num_examples must be > 0");
     PLDA_TRY(set_device(h));
@@ -1015,11 +1017,17 @@ int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, in
     const bool zn = zmean && zstd;
     if (zn) { PLDA_TRY(upload(h, dZm, zmean, (size_t)M * 8)); PLDA_TRY(upload(h, dZs, zstd, (size_t)M * 8)); }
     PLDA_HIP(h, dO.alloc((size_t)P * 8));
+    if (long_list) {
+      long long bad = -1;
+      PLDA_TRY(plda::pairs_validate_device(h, dE.as<int64_t>(), dT.as<int64_t>(), P, M, Nt, &bad));
+      if (bad >= 0) return fail(h, PLDA_E_INVAL, "score_pairs: trial %lld indexes outside the enrol/test sets", bad);
+    }
+    plda::CountSet cs;                                   // the distinct enrol counts: long lists run on per-count tables (score.hip)
+    if (P >= 16384) plda::score_count_set_host(n_enrol, M, &cs);
     PLDA_TRY(score_pairs_device(h, dU.as<double>(), dN.as<int32_t>(), dV.as<double>(), dE.as<int64_t>(),
                                 dT.as<int64_t>(), P, zn ? dZm.as<double>() : nullptr,
-                                zn ? dZs.as<double>() : nullptr, dO.as<double>()));
-    PLDA_HIP(h, hipMemcpyAsync(out, dO.p, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
-    PLDA_HIP(h, hipStreamSynchronize(h->stream));
+                                zn ? dZs.as<double>() : nullptr, dO.as<double>(), M, &cs));
+    PLDA_TRY(download(h, out, dO.p, (size_t)P * 8));
     return PLDA_OK;
   });
 }

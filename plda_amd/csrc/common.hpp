@@ -335,6 +335,7 @@ int score_matrix_device(plda_handle *h, const double *dU, const int32_t *dn, int
                         const double *dV, int64_t Nt, const double *dzmean, const double *dzstd,
                         float *dout, int64_t ld, bool reuse_packed_B = false, const CountSet *cs = nullptr);
 void score_count_set_host(const int32_t *n, int64_t M, CountSet *cs);
+int pairs_validate_device(plda_handle *h, const int64_t *de, const int64_t *dt, int64_t P, int64_t M, int64_t Nt, long long *bad);
 int score_count_set_device(plda_handle *h, const int32_t *dn, int64_t M, CountSet *cs);
 int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, int kind, int n_uniform, const CountSet *cs);
 int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din,

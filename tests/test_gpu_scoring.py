@@ -507,3 +507,52 @@ def test_transform_with_the_matrix_resident_in_registers(dout, monkeypatch):
         ref = onp.transform_ivector(model, x, ne)
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(got, old, rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("d,kind", [(50, "mixed"), (200, "uniform"), (129, "many"), (64, "beyond")])
+def test_long_trial_lists_run_on_per_count_tables(monkeypatch, oracle, d, kind):
+    """plda_score_pairs on a list of >= 16 384 trials: the terms of Plda::LogLikelihoodRatio (pldamodule.cpp:266) that depend on
+    (enrol count, dimension) only come from per-count tables instead of four divisions and two logarithms per element.  Same
+    numbers: against the oracle's per-trial LLR on a sample (1e-10 relative, as the short lists are held to), against the
+    verbatim kernel (PLDA_MIXED_VARIANT=1 keeps it) on the whole list, with and without z-norm statistics; counts the tables do
+    not take (> 4095) stay verbatim."""
+    from plda_amd import MPlda
+    rng = np.random.default_rng(d)
+    m, nt, p = 700, 3000, 40000
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    model = (rng.random(d), q * (1.0 + rng.random(d))[:, None], np.sort(rng.random(d) * 4.0 + 0.05)[::-1].copy())
+    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
+    vals = {"mixed": np.arange(1, 6), "uniform": np.array([3]), "many": rng.choice(np.arange(1, 300), 40, replace=False),
+            "beyond": np.array([1, 5000])}[kind]
+    counts = vals[rng.integers(0, len(vals), m)].astype(np.int32)
+    e, t = np.sort(rng.integers(0, m, p)), rng.integers(0, nt, p)
+    ids = np.arange(m, dtype=np.int64)
+    outs = {}
+    for arm in ("", "1"):
+        if arm:
+            monkeypatch.setenv("PLDA_MIXED_VARIANT", arm)
+        else:
+            monkeypatch.delenv("PLDA_MIXED_VARIANT", raising=False)
+        eng = MPlda(0)
+        eng.set_model(*model)
+        plain = eng.score_trials((counts, U, ids), (1, V), e, t)
+        eng._meanz = {int(k): -30.0 + 0.01 * k for k in ids}
+        eng._stdvz = {int(k): 2.0 + 0.001 * k for k in ids}
+        eng._stdvz[5] = 0.0                       # (a zero std leaves the row's trials un-normalised)
+        outs[arm] = (plain, eng.score_trials((counts, U, ids), (1, V), e, t))
+    for a, b in zip(outs[""], outs["1"]):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11)
+    sel = rng.integers(0, p, 300)
+    ref = np.array([oracle.llr(model[2], U[e[i]], counts[e[i]], V[t[i]]) for i in sel])
+    np.testing.assert_allclose(outs[""][0][sel], ref, rtol=1e-10, atol=1e-11)
+    zref = np.array([r if e[i] == 5 else (r - (-30.0 + 0.01 * e[i])) / (2.0 + 0.001 * e[i]) for r, i in zip(ref, sel)])
+    np.testing.assert_allclose(outs[""][1][sel], zref, rtol=1e-10, atol=1e-11)
+    # an index outside the sets is an error code (found on the device for long lists), never a fault; the handle stays usable
+    bad_t = t.copy(); bad_t[31000] = nt
+    from plda_amd._native import PldaError
+    with pytest.raises(PldaError, match="31000"):
+        eng.score_trials((counts, U, ids), (1, V), e, bad_t)
+    bad_e = e.copy(); bad_e[7] = -1
+    with pytest.raises(PldaError, match="trial 7 "):
+        eng.score_trials((counts, U, ids), (1, V), bad_e, t)
+    np.testing.assert_array_equal(eng.score_trials((counts, U, ids), (1, V), e, t), outs["1"][1])
