@@ -231,13 +231,14 @@ def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant
 
 
 @pytest.mark.parametrize("d", [1, 24, 200])
-def test_llr_with_mixed_counts_against_the_closed_form_gaussian_ratio(d):
+def test_llr_with_mixed_counts_against_the_closed_form_gaussian_ratio(monkeypatch, d):
     """The same known answer (scipy.stats, neither the oracle nor the engine's kernels) for enrol models with DIFFERENT
     utterance counts -- the bucketed form of the trials GEMM (one column-bias vector per distinct count) and the fp64
     trial-list kernel: per dimension the joint covariance of (enrol mean of n_i vectors, test vector) is
     [[psi + 1/n_i, psi], [psi, psi + 1]]."""
     from scipy.stats import norm
     from plda_amd import MPlda
+    monkeypatch.delenv("PLDA_MIXED_VARIANT", raising=False)       # (the depth asserted below is the bucketed form's)
     rng = np.random.default_rng(300 + d)
     psi = np.sort(rng.random(d) * 5.0 + 1e-3)[::-1].copy()
     eng = MPlda(0)
