@@ -438,17 +438,17 @@ __global__ __launch_bounds__(1024) void count_set_one_wg_kernel(const int32_t *_
 // enrol side of the bucketed form, one pass over the fp64 rows (the structure of prep_side_kernel<0>; the coefficients
 // are the row's own): A1 = c u / var (* s_i), r'_i, s_i, rpair, and the KQx extra k-quad planes s_i x onehot(b_i - 1)
 template <int RW>
-__global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *__restrict__ X, const int32_t *__restrict__ n_arr, const CountSet cs,
-                                                                 const double *__restrict__ coefG /*[G][2 D + 1]*/, const double *__restrict__ psi, int D,
-                                                                 int64_t R, int64_t Rpad, int KQm, int KQx, const double *__restrict__ zmean,
-                                                                 const double *__restrict__ zstd, float *__restrict__ P, float *__restrict__ bias,
-                                                                 float *__restrict__ rscale, float2 *__restrict__ pair) {
+__device__ __forceinline__ void prep_enrol_buckets_body(const int block, const double *__restrict__ X, const int32_t *__restrict__ n_arr, const CountSet &cs,
+                                                        const double *__restrict__ coefG /*[G][2 D + 1]*/, const double *__restrict__ psi, int D,
+                                                        int64_t R, int64_t Rpad, int KQm, int KQx, const double *__restrict__ zmean,
+                                                        const double *__restrict__ zstd, float *__restrict__ P, float *__restrict__ bias,
+                                                        float *__restrict__ rscale, float2 *__restrict__ pair) {
   constexpr int RPB = 4 * RW;                 // rows of a workgroup (RW rows per wave: 16, or 4 for short sides -- see prep_side_kernel)
   __shared__ float tile[2][64][RPB + 1];
   __shared__ int sb[RPB];
   __shared__ float ss[RPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * RPB;
+  const int64_t row0 = (int64_t)block * RPB;
   const int64_t wrow0 = row0 + wave * RW;
   const int nchunk = (KQm * 4 + 63) >> 6;
   const bool zn = zmean && zstd;
@@ -547,6 +547,15 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
   }
 }
 
+template <int RW>
+__global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *__restrict__ X, const int32_t *__restrict__ n_arr, const CountSet cs,
+                                                                 const double *__restrict__ coefG, const double *__restrict__ psi, int D,
+                                                                 int64_t R, int64_t Rpad, int KQm, int KQx, const double *__restrict__ zmean,
+                                                                 const double *__restrict__ zstd, float *__restrict__ P, float *__restrict__ bias,
+                                                                 float *__restrict__ rscale, float2 *__restrict__ pair) {
+  prep_enrol_buckets_body<RW>((int)blockIdx.x, X, n_arr, cs, coefG, psi, D, R, Rpad, KQm, KQx, zmean, zstd, P, bias, rscale, pair);
+}
+
 // test side of the bucketed form, the extra planes: dq_g[j] = -1/2 sum_d (g_gd - g_0d) v_jd^2 for g = 1 .. G - 1 (fp64, rounded
 // once), zero beyond.  The D main planes, q_0 and cpair come from prep_side_kernel<1> with bucket 0's coefficients.  A
 // second read of the rows (L2 mostly): Nt D 8 B against the GEMM's Nt M (D + G) flop.
@@ -554,12 +563,12 @@ __global__ __launch_bounds__(256) void prep_enrol_buckets_kernel(const double *_
 //  handles -- per lane eight chunks of 64 dimensions, D <= 512 -- so that the inner loop is one 8-byte load and four FMAs per
 //  element; the first version re-read five coefficients from L1 per element and took 1.26 ms for C4's 2.4 GB of test rows.)
 template <int RW>
-__global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__restrict__ V, const double *__restrict__ coefG, int G, int D,
-                                                                int64_t R, int64_t Rpad, int KQm, int KQx, float *__restrict__ P) {
+__device__ __forceinline__ void prep_test_buckets_body(const int block, const double *__restrict__ V, const double *__restrict__ coefG, int G, int D,
+                                                       int64_t R, int64_t Rpad, int KQm, int KQx, float *__restrict__ P) {
   constexpr int RPB = 4 * RW;
   __shared__ float q[CS_MAX][RPB + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * RPB;
+  const int64_t row0 = (int64_t)block * RPB;
   for (int i = threadIdx.x; i < CS_MAX * (RPB + 1); i += 256) (&q[0][0])[i] = 0.f;
   __syncthreads();
   const int S = 2 * D + 1;
@@ -620,6 +629,27 @@ __global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__
     v.z = q[4 * e + 2][r];
     v.w = q[4 * e + 3][r];
     reinterpret_cast<f32x4 *>(P)[(int64_t)(KQm + e) * Rpad + row0 + r] = v;
+  }
+}
+
+template <int RW>
+__global__ __launch_bounds__(256) void prep_test_buckets_kernel(const double *__restrict__ V, const double *__restrict__ coefG, int G, int D,
+                                                                int64_t R, int64_t Rpad, int KQm, int KQx, float *__restrict__ P) {
+  prep_test_buckets_body<RW>((int)blockIdx.x, V, coefG, G, D, R, Rpad, KQm, KQx, P);
+}
+// the bucketed form's three packing kernels of two SHORT sides in one launch (as prep_both_kernel for the uniform path): blocks
+// [0, blocksA) the enrol side; the rest the test side -- its D main planes with bucket 0's coefficients, then its dq planes
+struct PrepBucketArgs { const double *U; const int32_t *n; int64_t M, Mpad; float *Apk; float *rbias; float *rscale; float2 *rpair;
+                        const double *V; int64_t Nt, Npad; float *Bpk; float *cbias; float2 *cpair; };
+__global__ __launch_bounds__(256) void prep_buckets_both_kernel(const PrepBucketArgs a, int blocksA, const CountSet cs, const double *__restrict__ coefG,
+                                                                const double *__restrict__ psi, int D, int KQm, int KQx,
+                                                                const double *__restrict__ zmean, const double *__restrict__ zstd) {
+  if ((int)blockIdx.x < blocksA) {
+    prep_enrol_buckets_body<4>((int)blockIdx.x, a.U, a.n, cs, coefG, psi, D, a.M, a.Mpad, KQm, KQx, zmean, zstd, a.Apk, a.rbias, a.rscale, a.rpair);
+  } else {
+    const int b = (int)blockIdx.x - blocksA;
+    prep_side_body<1, 4>(b, a.V, coefG + D, coefG + 2 * D, 0, psi, D, a.Nt, a.Npad, KQm, nullptr, nullptr, a.Bpk, a.cbias, nullptr, a.cpair);
+    prep_test_buckets_body<4>(b, a.V, coefG, cs.G, D, a.Nt, a.Npad, KQm, KQx, a.Bpk);
   }
 }
 
@@ -1569,6 +1599,14 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
       h->gcoef_ptr = coefG; h->gcoef_epoch = h->model_epoch; h->gcoef_D = D; h->gcoef_set = *cs;
     }
     auto few = [&](int64_t rpad) { return h->prep_variant == 3 || (h->prep_variant != 2 && rpad <= 32768); };   // (as the uniform path below)
+    if (doA && doB && few(op.Mpad) && few(op.Npad)) {
+      const PrepBucketArgs a{dU, dn, M, op.Mpad, h->s_Apk.as<float>(), h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_rpair.as<float2>(),
+                             dV, Nt, op.Npad, h->s_Bpk.as<float>(), h->s_cbias.as<float>(), h->s_cpair.as<float2>()};
+      prep_buckets_both_kernel<<<(unsigned)((op.Mpad + op.Npad) / 16), 256, 0, h->stream>>>(a, (int)(op.Mpad / 16), *cs, coefG, h->d_psi.as<double>(), D,
+                                                                                           KQm, KQx, dzmean, dzstd);
+      PLDA_LAUNCH_CHECK(h);
+      return PLDA_OK;
+    }
     if (doA) {
       if (few(op.Mpad))
         prep_enrol_buckets_kernel<4><<<(unsigned)(op.Mpad / 16), 256, 0, h->stream>>>(
