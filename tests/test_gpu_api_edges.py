@@ -328,3 +328,34 @@ def test_transform_result_is_a_dict_that_remembers_its_arrays(oracle):
     assert test2._packed is None and p.score_matrix(enrol, test2, znorm=False).shape == (len(enrol), 301)
     del test2[10 ** 6]
     assert np.array_equal(p.score_matrix(enrol, test2, znorm=False), S2x)
+
+
+def test_znorm_lookup_for_many_models_matches_the_per_key_lookup(oracle):
+    """score_matrix with z-norm statistics for >= 256 models takes the statistics from one sorted copy (vectorised lookup)
+    instead of two dict probes per model: same rows normalised, same values, models without statistics left as they are, a
+    second norm() (insert-once: pldamodule.cpp:245,250) adds only the new labels and is seen by the next call."""
+    from liblda import PLDA
+    x, y = make_data(21, 1200, 16, 40, scale_between=0.3)
+    p = PLDA()
+    p.fit(x, y, 3)
+    enrol = p.transform(x[:600], np.arange(600, dtype=np.uint64) * 7 + 3)       # 600 models, sparse labels
+    test = p.transform(x[600:900], np.arange(300, dtype=np.uint64))
+    first = {k: enrol[k] for k in list(enrol)[:350]}
+    p.norm(x[900:1100], first)
+    zm, zs = p._instance.znorm_stats()
+    assert len(zm) == 350
+    raw = p.score_matrix(enrol, test, znorm=False)
+    got = p.score_matrix(enrol, test)
+    keys = list(enrol)
+    for i in (0, 1, 349, 350, 599):
+        k = keys[i]
+        want = (raw[i] - zm[k]) / zs[k] if k in zm else raw[i]
+        np.testing.assert_allclose(got[i], want, rtol=2e-5, atol=2e-5)
+    small = {k: enrol[k] for k in keys[340:360]}                                 # < 256 models: the per-key path
+    np.testing.assert_array_equal(p.score_matrix(small, test), got[340:360])
+    p.norm(x[1000:1200], enrol)                                                  # the other 250 labels; the first 350 keep theirs
+    zm2, zs2 = p._instance.znorm_stats()
+    assert len(zm2) == 600 and all(zm2[k] == zm[k] and zs2[k] == zs[k] for k in zm)
+    got2 = p.score_matrix(enrol, test)
+    np.testing.assert_array_equal(got2[:350], got[:350])
+    np.testing.assert_allclose(got2[599], (raw[599] - zm2[keys[599]]) / zs2[keys[599]], rtol=2e-5, atol=2e-5)
