@@ -1803,7 +1803,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   const bool use_bt2 = EPI == 0 && fits4g && ld < (1ll << 22) &&
                        ((h->gemm_variant >= 30 && h->gemm_variant <= 37) || ((h->gemm_variant == 0 || old_rule) && big2));
   // one wave per SIMD, 128 x 128 per wave (score_bt4.inc) -- the product path of every BASELINE configuration since round 4
-  // (>= 1024 tiles of 256 x 256 and K >= 104); PLDA_GEMM_VARIANT 40 forces it, 30 forces the round-2/3 kernel, 41 its timeline
+  // (>= 1 700 tiles of 256 x 256 -- see above -- and K >= 72); PLDA_GEMM_VARIANT 40 forces it, 30 forces the round-2/3 kernel, 41 its timeline
   // instantiation, 44 / 45 / 46 its bounding arms (no DMA / no stores / neither); needs >= 3 stages per tile (K >= 72).
   {
     const int nsteps = op.KQ >> 1, nst = (nsteps + 3) >> 2;
