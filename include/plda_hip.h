@@ -140,7 +140,10 @@ int plda_transform_rows_dev(plda_handle *h, const double *dXbar, int64_t R, int3
  * Trial list: P pairs (enrol row e_idx[p] of U, test row t_idx[p] of V), each
  * Plda::LogLikelihoodRatio(U[e], n[e], V[t]) (:266) in fp64, then the optional
  * z-norm (s - zmean[e]) / zstd[e] (:269-273) where zmean/zstd are non-NULL and
- * zstd[e] != 0.  plda.score() is the P == 1 case. */
+ * zstd[e] != 0.  plda.score() is the P == 1 case.
+ * Lists of >= 16 384 trials (a trials file: scoring/scorePLDA.py:299-321) run on per-count tables -- the terms of the LLR that
+ * depend on (n[e], dimension) only are tabulated per distinct count -- in fp64, equal to the per-element form to 1e-11; their
+ * indices are checked on the device.  An index outside [0, M) x [0, Nt) is PLDA_E_INVAL naming the first such trial. */
 int plda_score_pairs(plda_handle *h, const double *U, const int32_t *n_enrol, int64_t M,
                      const double *V, int64_t Nt, const int64_t *e_idx,
                      const int64_t *t_idx, int64_t P, const double *zmean,
