@@ -21,7 +21,7 @@ for name, lo, hi in (("uniform 20", 20, 20), ("n_k in [15, 25]", 15, 25), ("n_k 
     else:
         nk = rng.integers(lo, hi + 1, K).astype(np.float64)
         nk = np.maximum(1, np.floor(nk * N / nk.sum())).astype(np.int64)
-        nk[0] += N - nk.sum()
+        nk[: N - nk.sum()] += 1                       # (the rows the rounding left over, one each: no giant class)
         y = np.repeat(np.arange(K), nk)[:N]
         if y.shape[0] < N:
             y = np.concatenate([y, np.zeros(N - y.shape[0], np.int64)])
