@@ -272,6 +272,10 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
 // C = X^T diag(kw) X + w2 X2^T X2 (one launch for D <= 208)
 int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ldx, const double *kw, int64_t K2,
                   const double *X2, int64_t ldx2, double w2, double *C, int64_t ldc);
+// the row-form EM's two rank-k sums + M-step in two launches (D <= 208; *used = false otherwise)
+int em_syrk2_mstep_f64(plda_handle *h, int D, int64_t K1, const double *X, const double *kw1, const double *kw2, int64_t K2,
+                       const double *Z, const double *Wn, const double *S, double sumK, double cw, double cntW, double cntB,
+                       double *W, double *B, bool *used);
 int syrk_znorm_f64(plda_handle *h, int D0, int64_t K, const double *X, const double *zc, const double *zs, double *C, bool *used);
 int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
              int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,
@@ -287,6 +291,9 @@ int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const doub
                     int *dflag, int batch);
 int spd_inverse_via_whitening_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T,
                                   double *out, int *dflag, int batch);
+// T_g = chol(W + gn[g] B)^-1 (lower triangular) for g < batch; scr: 3 D^2 doubles per group
+int whiten_groups_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T, double *scr,
+                      int *dflag, int batch);
 // [batch] SPD inverses of any size (A^-1 = T^T T, T = blocked whitening); out may be A itself; scr: 3 n^2 doubles each
 int spd_inverse_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, double *out, int ldo,
                         int64_t so, double *scr, int64_t sscr, int *dflag, int batch);

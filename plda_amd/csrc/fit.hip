@@ -320,6 +320,202 @@ __global__ void em_group_mstep_kernel(const double *__restrict__ S, const double
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Grouped EM in the ROW form (round 6; the default).  With T_g the whitening factor of A_g = W + n_g B (lower triangular,
+// T_g A_g T_g^T = I, so A_g^-1 = T_g^T T_g) and X_g = T_g B:
+//   posterior mean of class k of group g:  w_k = n_g y_k,  y_k = B A_g^-1 m_k = X_g^T (T_g m_k)          (rows: Y = (M T_g^T) X_g)
+//   posterior covariance of the group:     Mx_g = (B^-1 + n_g W^-1)^-1 = B - n_g X_g^T X_g
+//   W_stats = S + sum_k (m_k - w_k)(m_k - w_k)^T + sum_g K_g Mx_g   = S + Z^T Z   + K B       - sum_g K_g n_g X_g^T X_g
+//   B_stats =     sum_k (1/n_k) w_k w_k^T + sum_g (K_g / n_g) Mx_g  =     Wn^T Wn + (sum_k 1/n_k) B - sum_g K_g X_g^T X_g
+// with Z = M - n Y and Wn = sqrt(n) Y.  Per group this is ONE D^3 product (X_g) beside the factorisation; everything else is
+// work on the K class means (two products per row tile) and two symmetric rank-k sums over the stacked rows [X_1; ..; X_G | Z]
+// and [X_1; ..; X_G | Wn] -- where the form of rounds 2-5 (per-group second moments C_g, kept as PLDA_EM_VARIANT=3 for one
+// round of A/B) ran seven batched D^3 products per iteration.  Numerically the T-forms lose sqrt(cond(A_g)) where an explicit
+// A_g^-1 loses cond(A_g): against the x87 EM (N = 149, D = 200, six iterations, cond(W) = 3e8) W 1.3e-14, B 2.6e-13 without any
+// refinement step (rounds 2-5 with one: 3e-14, 2e-13; the reference's own formulation: 4e-12, 6e-9).
+// ------------------------------------------------------------------------------------
+typedef double f64x4_fit __attribute__((ext_vector_type(4)));
+
+// T_g of the FIRST iteration: W = B = I there, so chol(W + n B)^-1 = I / sqrt(1 + n).  grid (ceil(D^2 / 256), groups)
+__global__ void em_first_T_kernel(const double *__restrict__ gn, int D, int64_t stride, double *__restrict__ T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * D) return;
+  T[(int64_t)blockIdx.y * stride + idx] = (idx / D == idx % D) ? 1.0 / sqrt(1.0 + gn[blockIdx.y]) : 0.0;
+}
+
+// row weights of the stacked X_g in the two rank-k sums: kw1 = -K_g n_g, kw2 = -K_g (row i of group g at g D + i)
+__global__ void em_row_weights_kernel(const double *__restrict__ gn, const double *__restrict__ gk, int D, int64_t GD,
+                                      double *__restrict__ kw1, double *__restrict__ kw2) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= GD) return;
+  const int g = (int)(idx / D);
+  kw1[idx] = -gk[g] * gn[g];
+  kw2[idx] = -gk[g];
+}
+
+// RB stacked 16 x 16 blocks (16 RB rows of the left operand, one column block) of a product whose left operand (k-contiguous,
+// leading dimension ld) sits in LDS and whose right operand comes from global memory through `bload(k)` (this lane's element for k
+// index k + fk).  `a` = the lane's position (row fi, k offset fk) in the LDS tile; nch chunks of 16 k.  Per trip the 16 fragments of
+// four chunks are requested, then multiplied; the other waves of the SIMD (eight with two workgroups per CU) cover the round trip.
+//  * What bounds these kernels is the CU's vector-memory path, not latency: a fragment load is four 128-byte rows, ~20 cycles of
+//    the L1, and with ONE MFMA per fragment the four SIMDs ask for one every 16 cycles.  RB = 2 halves that (two MFMAs per fragment).
+//  * Software pipelining across trips did not survive the compiler (round 6; rotating fragment sets by moves, by renamed slots, by
+//    fixed slots between scheduling barriers, and a compile-time recursion over the rounds): the register allocator copies the sets
+//    at the loop's back edge and a copy waits for the load it copies, or the recursion spills.  All four measured slower than this.
+//  * bload must be BRANCH-FREE (clamped addresses): a guard per load puts every load under its own exec branch with a vmcnt(0)
+//    behind it.  What a clamped load brings in beyond the operands' extent meets zeros of the LDS tile.
+template <int RB, typename BL>
+__device__ __forceinline__ void em_block_product(const double *a, int ld, int nch, BL bload, f64x4_fit (&out)[RB]) {
+  f64x4_fit acc[RB][2];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) acc[b][0] = acc[b][1] = f64x4_fit{0.0, 0.0, 0.0, 0.0};
+  const int last = 16 * (nch - 1);
+  for (int c = 0; c < nch; c += 4) {
+    double q[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[p][u] = bload(min(16 * (c + p), last) + 4 * u);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (c + p < nch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int b = 0; b < RB; ++b)
+            acc[b][u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b * 16 * ld + 16 * (c + p) + 4 * u], q[p][u], acc[b][u & 1], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int b = 0; b < RB; ++b) out[b] = acc[b][0] + acc[b][1];
+}
+
+// X_g = T_g B and the transposed copy TT_g = T_g^T: workgroup (x, g) takes the 16 RB rows of T_g that END with block
+// i = NT - 1 - RB x (the long rows first) -- T_g is lower triangular, so they end at k < 16 (i + 1) -- into LDS with
+// row-contiguous loads, writes them out transposed, and multiplies: sixteen waves, a column block each, B's fragments straight
+// from L2 (B is shared by every group).  The batched 16 x 16-tile kernel of linalg.hip read T_g's fragments as sixteen 32-byte
+// pieces per load and the whole k extent: 34 us for 36 groups at D = 200.  D <= 512.
+template <int RB>
+__global__ __launch_bounds__(1024) void em_xtb_kernel(const double *__restrict__ T, const double *__restrict__ B, int D,
+                                                      double *__restrict__ X, double *__restrict__ TT) {
+  extern __shared__ __attribute__((aligned(16))) double em_xtb_lds[];
+  const int NT = (D + 15) >> 4, ld = 16 * NT + 4;
+  const int i = NT - 1 - RB * (int)blockIdx.x, g = blockIdx.y, kext = 16 * (i + 1);
+  const int m0 = 16 * (i - (RB - 1));              // (may be negative for the last workgroup of a group: those rows are skipped)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
+  const double *__restrict__ Tg = T + (int64_t)g * D * D;
+  double *__restrict__ Xg = X + (int64_t)g * D * D, *__restrict__ TTg = TT + (int64_t)g * D * D;
+  double *Ts = em_xtb_lds;
+  for (int idx = t; idx < 16 * RB * kext; idx += 1024) {
+    const int r = idx / kext, c = idx - r * kext, row = m0 + r;
+    Ts[r * ld + c] = (row >= 0 && row < D && c < D) ? Tg[(int64_t)row * D + c] : 0.0;
+  }
+  __syncthreads();
+  for (int idx = t; idx < 16 * RB * kext; idx += 1024) {
+    const int r = idx & (16 * RB - 1), c = idx / (16 * RB), row = m0 + r;
+    if (row >= 0 && row < D && c < D) TTg[(int64_t)c * D + row] = Ts[r * ld + c];
+  }
+  for (int j = wave; j < NT; j += 16) {
+    const int col = 16 * j + fi;
+    const bool okc = col < D;
+    const double *__restrict__ bcol = B + (okc ? col : D - 1);
+    f64x4_fit x[RB];
+    em_block_product<RB>(Ts + fi * ld + fk, ld, i + 1, [&](int k) { return bcol[(int64_t)min(k + fk, D - 1) * D]; }, x);
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * b + fk + 4 * r;
+        if (row >= 0 && row < D && okc) Xg[(int64_t)row * D + col] = x[b][r];
+      }
+  }
+}
+
+// The class means' share of an iteration: a workgroup takes 16 RB centred means of ONE group (tiles: {first row, rows, group}),
+//   V = M T_g^T  (T_g lower triangular: column block j needs k < 16 (j + 1); read from the TRANSPOSED copy em_xtb_kernel leaves,
+//                 so that a fragment is four 128-byte rows like X_g's and not sixteen 32-byte pieces)          ->  LDS
+//   Y = V X_g,   Z = M - n_g Y,   Wn = sqrt(n_g) Y                                                          ->  global
+// Sixteen waves, a column block each in both phases.  LDS: two [16 RB][16 NT + 4] tiles (the +4 doubles spread the 16 rows of a
+// fragment read over all banks): RB = 2 for D <= 256, RB = 1 up to D = 512.
+template <int RB>
+__global__ __launch_bounds__(1024) void em_rows_kernel(const double *__restrict__ Mg, const int4 *__restrict__ tiles,
+                                                       const double *__restrict__ T /*transposed: [k][j]*/, const double *__restrict__ X,
+                                                       const double *__restrict__ gn, int D, double *__restrict__ Z,
+                                                       double *__restrict__ Wn) {
+  extern __shared__ __attribute__((aligned(16))) double em_rows_lds[];
+  const int NT = (D + 15) >> 4, ld = 16 * NT + 4;
+  double *Ms = em_rows_lds, *Vs = Ms + 16 * RB * ld;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
+  const int4 tile = tiles[blockIdx.x];
+  const int row0 = tile.x, nrows = tile.y, g = tile.z;
+  const double n = gn[g];
+  const double *__restrict__ Tg = T + (int64_t)g * D * D, *__restrict__ Xg = X + (int64_t)g * D * D;
+  for (int idx = t; idx < 16 * RB * 16 * NT; idx += 1024) {
+    const int r = idx / (16 * NT), c = idx - r * 16 * NT;
+    Ms[r * ld + c] = (r < nrows && c < D) ? Mg[(int64_t)(row0 + r) * D + c] : 0.0;
+  }
+  __syncthreads();
+  for (int j = NT - 1 - wave; j >= 0; j -= 16) {       // (the long blocks on the low waves)
+    const int col = 16 * j + fi;
+    const bool okc = col < D;
+    const double *__restrict__ tcol = Tg + (okc ? col : D - 1);
+    f64x4_fit v[RB];
+    em_block_product<RB>(Ms + fi * ld + fk, ld, j + 1, [&](int k) { return tcol[(int64_t)min(k + fk, D - 1) * D]; }, v);
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Vs[(16 * b + fk + 4 * r) * ld + col] = okc ? v[b][r] : 0.0;   // (columns past D: zeros for phase 2's k extent)
+  }
+  __syncthreads();
+  const double sn = sqrt(n);
+  for (int j = wave; j < NT; j += 16) {
+    const int col = 16 * j + fi;
+    const bool okc = col < D;
+    const double *__restrict__ xcol = Xg + (okc ? col : D - 1);
+    f64x4_fit y[RB];
+    em_block_product<RB>(Vs + fi * ld + fk, ld, NT, [&](int k) { return xcol[(int64_t)min(k + fk, D - 1) * D]; }, y);
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * b + fk + 4 * r;
+        if (row < nrows && okc) {
+          const int64_t o = (int64_t)(row0 + row) * D + col;
+          Z[o] = fma(-n, y[b][r], Ms[row * ld + col]);
+          Wn[o] = sn * y[b][r];
+        }
+      }
+  }
+}
+
+// D > 512 (the row tiles above do not fit in LDS): Y from two plain products per group, then Z = M - n Y and Wn = sqrt(n) Y
+// here; n of sorted row r = counts[cls[r]].  Y arrives in Z.
+__global__ void em_rows_finish_kernel(const double *__restrict__ Mg, const int *__restrict__ cls, const int64_t *__restrict__ counts,
+                                      int64_t K, int D, double *__restrict__ Z, double *__restrict__ Wn) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= K * D) return;
+  const double n = (double)counts[cls[idx / D]], y = Z[idx];
+  Z[idx] = fma(-n, y, Mg[idx]);
+  Wn[idx] = sqrt(n) * y;
+}
+
+// W = (S + K B + P1) / cntW,  B = (cw B + P2) / cntB  (cw = sum_k 1/n_k), symmetrised like Kaldi's CopyToSp
+__global__ void em_rows_mstep_kernel(const double *__restrict__ S, const double *__restrict__ P1, const double *__restrict__ P2,
+                                     int D, double sumK, double cw, double cntW, double cntB, double *__restrict__ W,
+                                     double *__restrict__ B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D * D) return;
+  const int i = idx / D, j = idx % D;
+  if (i > j) return;
+  const size_t ij = (size_t)i * D + j, ji = (size_t)j * D + i;
+  const double bij = B[ij], bji = B[ji];
+  const double wij = S[ij] + fma(sumK, bij, P1[ij]), wji = S[ji] + fma(sumK, bji, P1[ji]);
+  const double vij = fma(cw, bij, P2[ij]), vji = fma(cw, bji, P2[ji]);
+  const double w = 0.5 * (wij / cntW + wji / cntW), b = 0.5 * (vij / cntB + vji / cntB);
+  W[ij] = w; W[ji] = w;
+  B[ij] = b; B[ji] = b;
+}
+
 __global__ void set_identity2_kernel(double *W, double *B, int D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < D * D) { const double v = (idx / D == idx % D) ? 1.0 : 0.0; W[idx] = v; B[idx] = v; }
@@ -662,7 +858,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   // (+ the EM's planning traffic: class counts, count check and class weight coming back, the classes' order by count and
   //  the groups' counts going out -- pageable, each of those six copies was a blocking 20-40 us)
   const size_t pin_model_bytes = (3 * (size_t)D + DD) * 8 + 64;
-  const size_t pin_need = pin_model_bytes + (size_t)K * (8 + 4 + 8 + 8) + 96;
+  const size_t pin_need = pin_model_bytes + (size_t)K * (8 + 4 + 8 + 8 + 16) + 96 + 16;
   if (h->pin_model_cap < pin_need) {
     if (h->pin_model) (void)hipHostFree(h->pin_model);
     h->pin_model = nullptr; h->pin_model_cap = 0;
@@ -695,6 +891,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   int *const pin_bad = reinterpret_cast<int *>(pin_cw + 1);                            // then the statistics pass's two label words
   int *const pin_lab = reinterpret_cast<int *>(pin_cw + 2);
   int *const pin_cls = reinterpret_cast<int *>(pin_cw + 3);                            // [K]
+  int4 *const pin_tiles = reinterpret_cast<int4 *>((reinterpret_cast<uintptr_t>(pin_cls + K) + 15) & ~(uintptr_t)15);   // [<= K] row tiles of the EM
   pin_lab[0] = pin_lab[1] = 0;
   // one host round trip for everything the group planning needs: the count check, the class weight and the counts
   int *bad = offsets + K + 1;
@@ -766,7 +963,83 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   const size_t group_bytes = (size_t)G * DD * 8 * 5;
   const bool grouped = h->em_variant != 1 && group_bytes <= ((size_t)24 << 30) && G <= 16384;
   h->em_groups = grouped ? G : 0;
-  if (grouped) {
+  if (grouped && h->em_variant != 3) {
+    // ---- row form (the kernels' header above) ----
+    const int64_t sDD = (int64_t)DD, GD = (int64_t)G * D;
+    const int RB = D <= 256 ? 2 : 1;    // row blocks per tile of em_rows_kernel / em_xtb_kernel (LDS)
+    size_t ntiles = 0;                  // (at most K: every tile holds a row)
+    for (int g = 0; g < G; ++g)
+      for (int64_t r = goff[g]; r < goff[g + 1]; r += 16 * RB)
+        pin_tiles[ntiles++] = make_int4((int)r, (int)std::min<int64_t>(16 * RB, goff[g + 1] - r), g, 0);
+    PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3 + (size_t)K * 4 + ntiles * 16 + 64));
+    PLDA_HIP(h, h->w[6].reserve(group_bytes + DD * 8 * 2 + (size_t)G * 16 + (size_t)GD * 16 + 64));
+    double *Mg = h->w[5].as<double>(), *Zr = Mg + (size_t)K * D, *Wn = Zr + (size_t)K * D;
+    int4 *dtiles = reinterpret_cast<int4 *>(Wn + (size_t)K * D);
+    int *dcls = reinterpret_cast<int *>(dtiles + ntiles);
+    double *Tg = h->w[6].as<double>(), *Xg = Tg + (size_t)G * DD, *scr = Xg + (size_t)G * DD, *P1 = scr + 3 * (size_t)G * DD,
+           *P2 = P1 + DD, *dgn = P2 + DD, *dgk = dgn + G, *kw1 = dgk + G, *kw2 = kw1 + GD;
+    int *dflag = h->fit_flag.as<int>();          // (its own buffer: the export kernel that ends the fit reads it)
+    std::copy(gn.begin(), gn.end(), pin_gn);
+    std::copy(gk.begin(), gk.end(), pin_gk);
+    PLDA_HIP(h, hipMemcpyAsync(dcls, cls, (size_t)K * 4, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dgn, pin_gn, (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dgk, pin_gk, (size_t)G * 8, hipMemcpyHostToDevice, h->stream));
+    PLDA_HIP(h, hipMemcpyAsync(dtiles, pin_tiles, ntiles * 16, hipMemcpyHostToDevice, h->stream));
+    gather_center_kernel<<<gKD, 256, 0, h->stream>>>(means, mu, dcls, K, D, Mg);
+    em_row_weights_kernel<<<(unsigned)ceil_div(GD, 256), 256, 0, h->stream>>>(dgn, dgk, D, GD, kw1, kw2);
+    PLDA_LAUNCH_CHECK(h);
+    const int NT = (int)ceil_div(D, 16);
+    const size_t rows_lds = (size_t)2 * 16 * RB * (16 * NT + 4) * 8, xtb_lds = (size_t)16 * RB * (16 * NT + 4) * 8;
+    double *TTg = scr;                    // T_g^T (D <= 512; the blocked whitening's scratch is dead by then)
+    if (D <= 512) {
+      static DeviceOnce attr;
+      if (attr.needed(h->device)) {
+        PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&em_rows_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * (16 * 32 + 4) * 8));
+        PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&em_xtb_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 16 * (16 * 32 + 4) * 8));
+        PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&em_rows_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * (16 * 16 + 4) * 8));
+        PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&em_xtb_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (16 * 16 + 4) * 8));
+        attr.done(h->device);
+      }
+    }
+    for (int it = 0; it < iters; ++it) {
+      if (it == 0) em_first_T_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(dgn, D, sDD, Tg);
+      else PLDA_TRY(whiten_groups_f64(h, W, B, dgn, D, Tg, scr, dflag, G));
+      PLDA_LAUNCH_CHECK(h);
+      if (D <= 512) {
+        if (RB == 2) {
+          em_xtb_kernel<2><<<dim3((unsigned)ceil_div(NT, 2), (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg);
+          em_rows_kernel<2><<<(unsigned)ntiles, 1024, rows_lds, h->stream>>>(Mg, dtiles, TTg, Xg, dgn, D, Zr, Wn);
+        } else {
+          em_xtb_kernel<1><<<dim3((unsigned)NT, (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg);
+          em_rows_kernel<1><<<(unsigned)ntiles, 1024, rows_lds, h->stream>>>(Mg, dtiles, TTg, Xg, dgn, D, Zr, Wn);
+        }
+        PLDA_LAUNCH_CHECK(h);
+      } else {
+        PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, Tg, D, 1, sDD, B, D, 1, 0, nullptr, 0.0, Xg, D, sDD, G));
+        for (int g = 0; g < G; ++g) {
+          const int64_t kg = goff[g + 1] - goff[g];
+          const double *rows = Mg + (size_t)goff[g] * D;
+          double *V = Wn + (size_t)goff[g] * D, *Y = Zr + (size_t)goff[g] * D;
+          PLDA_TRY(gemm_f64(h, kg, D, D, 1.0, rows, D, 1, Tg + (size_t)g * DD, 1, D, nullptr, 0.0, V, D));
+          PLDA_TRY(gemm_f64(h, kg, D, D, 1.0, V, D, 1, Xg + (size_t)g * DD, D, 1, nullptr, 0.0, Y, D));
+        }
+        em_rows_finish_kernel<<<gKD, 256, 0, h->stream>>>(Mg, dcls, h->f_counts.as<int64_t>(), K, D, Zr, Wn);
+        PLDA_LAUNCH_CHECK(h);
+      }
+      bool fused = false;
+      PLDA_TRY(em_syrk2_mstep_f64(h, D, GD, Xg, kw1, kw2, K, Zr, Wn, S, (double)K, class_weight, cntW, cntB, W, B, &fused));
+      if (!fused) {
+        PLDA_TRY(syrk_pair_f64(h, D, GD, Xg, D, kw1, K, Zr, D, 1.0, P1, D));
+        PLDA_TRY(syrk_pair_f64(h, D, GD, Xg, D, kw2, K, Wn, D, 1.0, P2, D));
+        em_rows_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, P1, P2, D, (double)K, class_weight, cntW, cntB, W, B);
+        PLDA_LAUNCH_CHECK(h);
+      }
+    }
+  } else if (grouped) {
     PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 + (size_t)K * 4 + 64));
     PLDA_HIP(h, h->w[6].reserve(group_bytes + DD * 8 + (size_t)G * 16 + 64));
     double *Mg = h->w[5].as<double>();

@@ -423,10 +423,14 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
                                                        int64_t ldx, const double *__restrict__ kw, int64_t K1,
                                                        const double *__restrict__ X2, int64_t ldx2, double w2,
                                                        double *__restrict__ part, const double *__restrict__ zc,
-                                                       const double *__restrict__ zs) {
+                                                       const double *__restrict__ zs, const double *__restrict__ kw_y1 = nullptr,
+                                                       const double *__restrict__ X2_y1 = nullptr, int64_t part_y1 = 0) {
   __shared__ double Xs[2][GK * TRI_LD];
   __shared__ double Ws[2][GK];
   __shared__ double Rs[2][GK * 4];
+  // blockIdx.y == 1: a second product over the same first row set in the same launch -- other weights, other second set,
+  // partial slabs `part_y1` doubles further on (the EM's two sums, em_syrk2_mstep_f64)
+  if (blockIdx.y) { kw = kw_y1; X2 = X2_y1; part += part_y1; }
   const int D0 = ZN ? D - 2 : D;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -780,6 +784,80 @@ __global__ __launch_bounds__(1024) void syrk_tri_reduce_kernel(const double *__r
   const double v2 = alpha * sum + (beta != 0.0 ? beta * *c2 : 0.0);
   *c1 = v1;
   if (gr != gcol) *c2 = v2;
+}
+
+// The reduction above for the EM's two sums at once, with the M-step as its epilogue (em_rows_mstep_kernel's formula):
+//   W = (S + sumK B + P1) / cntW,   B = (cw B + P2) / cntB,     P1, P2 = the two sums of partial slabs (part, part + part_y1)
+// Every element (and its mirror) is read and written by one thread only, so B is updated in place.
+__global__ __launch_bounds__(1024) void em_syrk_reduce_mstep_kernel(const double *__restrict__ part, int64_t part_y1, int splits,
+                                                                    int D, const double *__restrict__ S, double sumK, double cw,
+                                                                    double cntW, double cntB, double *__restrict__ W,
+                                                                    double *__restrict__ B) {
+  __shared__ double qs[2][4][256];
+  const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
+  int tr = 0, tcol = (int)blockIdx.x;
+  while (tcol > tr) { tcol -= tr + 1; ++tr; }
+  const int e = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int lane = e & 63, reg = e >> 6;
+  const int gr = tr * 16 + (lane >> 4) + 4 * reg, gcol = tcol * 16 + (lane & 15);
+  const bool live = gr < D && gcol < D && gcol <= gr;
+  const int per = (splits + 3) >> 2, z0 = q * per, z1 = min(splits, z0 + per);
+  const int64_t zs = (int64_t)ntri * 256;
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const double *p = part + y * part_y1 + (int64_t)blockIdx.x * 256 + e;
+    double s16[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s16[u] = 0.0;
+    if (live) {
+      int z = z0;
+      for (; z + 16 <= z1; z += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s16[u] += p[(int64_t)(z + u) * zs];
+      }
+      for (int u = 0; z < z1; ++z, ++u) s16[u] += p[(int64_t)z * zs];
+    }
+    qs[y][q][e] = (((s16[0] + s16[1]) + (s16[2] + s16[3])) + ((s16[4] + s16[5]) + (s16[6] + s16[7]))) +
+                  (((s16[8] + s16[9]) + (s16[10] + s16[11])) + ((s16[12] + s16[13]) + (s16[14] + s16[15])));
+  }
+  __syncthreads();
+  if (q != 0 || !live) return;
+  const double p1 = (qs[0][0][e] + qs[0][1][e]) + (qs[0][2][e] + qs[0][3][e]);
+  const double p2 = (qs[1][0][e] + qs[1][1][e]) + (qs[1][2][e] + qs[1][3][e]);
+  const size_t ij = (size_t)gr * D + gcol, ji = (size_t)gcol * D + gr;
+  const double bij = B[ij], bji = B[ji];
+  const double wij = S[ij] + fma(sumK, bij, p1), wji = S[ji] + fma(sumK, bji, p1);
+  const double vij = fma(cw, bij, p2), vji = fma(cw, bji, p2);
+  const double w = 0.5 * (wij / cntW + wji / cntW), b = 0.5 * (vij / cntB + vji / cntB);
+  W[ij] = w; W[ji] = w;
+  B[ij] = b; B[ji] = b;
+}
+
+// The grouped EM's two rank-k sums and its M-step (fit.hip, row form), D <= 208:
+//   P1 = X^T diag(kw1) X + Z^T Z,   P2 = X^T diag(kw2) X + Wn^T Wn      (X: K1 stacked rows; Z, Wn: K2 rows each)
+// in ONE launch of the triangle kernel (blockIdx.y picks the sum) and one reduction that applies the M-step.  The rows are cut
+// into chunks of >= 64 (syrk_pair_f64's 128-row chunks left 3/4 of the chip idle at 5 000 rows).
+// *used = false: D > 208, the caller takes two syrk_pair_f64 and its own M-step.
+int em_syrk2_mstep_f64(plda_handle *h, int D, int64_t K1, const double *X, const double *kw1, const double *kw2, int64_t K2,
+                       const double *Z, const double *Wn, const double *S, double sumK, double cw, double cntW, double cntB,
+                       double *W, double *B, bool *used) {
+  *used = false;
+  if (D > TRI_NT * 16 || !(h->gemm64_variant == 0 || h->gemm64_variant == 6)) return PLDA_OK;
+  const int nt = (int)ceil_div(D, 16), ntri = nt * (nt + 1) / 2;
+  const int64_t K = K1 + K2;
+  // 128 chunks per sum at most: the 256 workgroups of the two sums are ONE round on the chip's 256 CUs (136 + 136 were two)
+  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(128, ceil_div(K, 64)));
+  const int64_t kchunk = round_up(ceil_div(K, splits), GK);
+  splits = (int)ceil_div(K, kchunk);
+  const int64_t part_y1 = (int64_t)splits * ntri * 256;
+  PLDA_HIP(h, h->w[15].reserve((size_t)2 * part_y1 * 8));
+  double *part = h->w[15].as<double>();
+  syrk_tri_kernel<false><<<dim3((unsigned)splits, 2), 512, 0, h->stream>>>(D, K, kchunk, X, D, kw1, K1, Z, D, 1.0, part, nullptr,
+                                                                           nullptr, kw2, Wn, part_y1);
+  em_syrk_reduce_mstep_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, part_y1, splits, D, S, sumK, cw, cntW, cntB, W, B);
+  PLDA_LAUNCH_CHECK(h);
+  *used = true;
+  return PLDA_OK;
 }
 
 #include "syrk_blk.inc"
@@ -1684,6 +1762,24 @@ int whiten_blocked(plda_handle *h, const double *A, int n, int lda, int64_t sa, 
   zero_block_kernel<<<dim3((unsigned)ceil_div((int64_t)n1 * n2, 256), ub), 256, 0, h->stream>>>(T12, ldt, st, n1, n2);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
+}
+
+// A_g = W + n_g B for the whitening of the grouped EM outside 64 < D <= 256 (inside that range the kernel forms it itself)
+__global__ void group_sum_kernel(const double *__restrict__ W, const double *__restrict__ B, const double *__restrict__ gn,
+                                 int64_t DD, double *__restrict__ A, int64_t sa) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx < DD) A[(int64_t)blockIdx.y * sa + idx] = fma(gn[blockIdx.y], B[idx], W[idx]);
+}
+
+// T_g = chol(W + gn[g] B)^-1 (lower triangular, zeros above the diagonal; T_g (W + n_g B) T_g^T = I) for g < batch, T_g at
+// T + g D^2.  `scr`: 3 D^2 doubles per group (A_g and the blocked whitening's scratch), touched only outside 64 < D <= 256.
+int whiten_groups_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T, double *scr,
+                      int *dflag, int batch) {
+  const int64_t sDD = (int64_t)D * D;
+  if (h->sweep_variant == 0 && D > 64 && D <= 256) return spd_block_mfma(h, 1, W, B, gn, D, D, 0, T, D, sDD, dflag, batch);
+  group_sum_kernel<<<dim3((unsigned)ceil_div(sDD, 256), (unsigned)batch), 256, 0, h->stream>>>(W, B, gn, sDD, scr, 3 * sDD);
+  PLDA_LAUNCH_CHECK(h);
+  return whiten_blocked(h, scr, D, D, 3 * sDD, T, D, sDD, scr + sDD, 3 * sDD, dflag, batch);
 }
 
 // SPD inverse of [batch] matrices of any size: A^-1 = T^T T with T = whiten(A).  out may be A (dead once T exists), not scr;

@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+for v in "PLDA_EM_ROWS_VARIANT=1 PLDA_EM_SYRK_ROWS=64" "PLDA_EM_ROWS_VARIANT=0 PLDA_EM_SYRK_ROWS=96" "PLDA_EM_ROWS_VARIANT=0 PLDA_EM_SYRK_ROWS=128" "PLDA_EM_ROWS_VARIANT=0 PLDA_EM_SYRK_ROWS=192"; do
+echo "=== $v"
+rm -rf gpurun_out/fitgroups_r6
+env $v rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fitgroups_r6 -o t -- python scripts/fit_groups_probe.py 2>&1 | grep -v "^[WE]2026" | tail -4
+f=$(find gpurun_out/fitgroups_r6 -name "*kernel_trace.csv" | head -1)
+echo "G=36:"; python scripts/em_iter_trace.py $f 4 | cut -c1-80
+echo "G=1:"; python scripts/em_iter_trace.py $f 10 | cut -c1-80
+done
