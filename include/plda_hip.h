@@ -95,6 +95,11 @@ int plda_fit_em_dev(plda_handle *h, const double *dmeans, const int64_t *dcounts
  * export of the model and status words to the host mirror, the one synchronisation); [3] = iterations run.
  * [1] + [2] = wall clock of plda_fit_em_dev; [0] + [1] + [2] = wall clock of plda_fit. */
 int plda_fit_timings(plda_handle *h, double out_ms[4]);
+/* how the EM of the last fit ran (pldamodule.cpp:102-105 is one loop over the classes; here the classes are grouped by
+ * their utterance count, the reason the reference sorts them, pldamodule.cpp:94-100): out[0] = number of distinct counts G
+ * (0: not grouped), out[1] = 0 EM in the simultaneously-diagonalised basis, 1 grouped on per-group second moments
+ * (few groups of many classes), 2 grouped on the class means (many groups). */
+int plda_fit_plan(plda_handle *h, int32_t out[2]);
 /* staged access to the fit internals (parity tests of SURVEY.md rows a3-a7):
  * any pointer may be NULL.  means[K*D] in label order, counts[K], scatter[D*D],
  * sum[D], W[D*D], B[D*D] (final within/between covariances before GetOutput). */

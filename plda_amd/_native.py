@@ -48,6 +48,7 @@ SIGNATURES = {
     "plda_htk_frames": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
     "plda_htk_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "plda_fit_timings": (C.c_int, [_vp, _vp]),
+    "plda_fit_plan": (C.c_int, [_vp, _vp]),
     "plda_fit_get_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plda_fit_num_classes": (C.c_int, [_vp, C.POINTER(_i64)]),
     "plda_get_dims": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),

@@ -384,6 +384,16 @@ int plda_fit_timings(plda_handle *h, double out_ms[4]) {
   });
 }
 
+int plda_fit_plan(plda_handle *h, int32_t out[2]) {
+  return guarded(h, "plda_fit_plan", [&]() -> int {
+    if (!h || !out) return PLDA_E_INVAL;
+    PLDA_LOCK(h);
+    out[0] = h->em_groups;
+    out[1] = h->em_form;
+    return PLDA_OK;
+  });
+}
+
 int plda_fit_num_classes(plda_handle *h, int64_t *K) {
   return guarded(h, "plda_fit_num_classes", [&]() -> int {
     if (!h || !K) return PLDA_E_INVAL;

@@ -140,8 +140,9 @@ struct plda_handle {
   int jacobi_variant = 0;  // 0: Gram-form block Jacobi round; 1: rotation-by-rotation inner tournament
   int sweep_variant = 0;  // PLDA_SWEEP_VARIANT=1: the 16-wave register kernels of round 2 (SPD inverse, tridiagonalisation); 2: the four-wave scalar sweep at every size (no matrix-core block sweep)
   bool sweep_mfma_attr[17] = {};   // dynamic-LDS attribute of spd_inverse_mfma_kernel<NT> set
-  int em_variant = 0;     // 0: grouped closed-form EM; 1: EM in the simultaneously-diagonalised basis
+  int em_variant = 0;     // 0: grouped closed-form EM (moment or row form by shape); 3 / 4: the moment / the row form always; 1: EM in the simultaneously-diagonalised basis
   int em_groups = 0;      // groups (distinct class counts) of the last grouped EM, 0 if the other path ran
+  int em_form = 0;        // EM of the last fit: 0 simultaneously-diagonalised basis, 1 grouped moment form, 2 grouped row form
   bool bt2_attr_set = false;
   bool bt4_attr_set = false;
   // tile schedule of the one-wave-per-SIMD trials GEMM (score.hip: bt4_schedule): per XCD a queue of tiles, consumed

@@ -329,8 +329,8 @@ __global__ void em_group_mstep_kernel(const double *__restrict__ S, const double
 //   B_stats =     sum_k (1/n_k) w_k w_k^T + sum_g (K_g / n_g) Mx_g  =     Wn^T Wn + (sum_k 1/n_k) B - sum_g K_g X_g^T X_g
 // with Z = M - n Y and Wn = sqrt(n) Y.  Per group this is ONE D^3 product (X_g) beside the factorisation; everything else is
 // work on the K class means (two products per row tile) and two symmetric rank-k sums over the stacked rows [X_1; ..; X_G | Z]
-// and [X_1; ..; X_G | Wn] -- where the form of rounds 2-5 (per-group second moments C_g, kept as PLDA_EM_VARIANT=3 for one
-// round of A/B) ran seven batched D^3 products per iteration.  Numerically the T-forms lose sqrt(cond(A_g)) where an explicit
+// and [X_1; ..; X_G | Wn] -- where the moment form of rounds 2-5 (per-group second moments C_g; still the faster one for FEW groups of
+// MANY classes, see fit_em_device) runs seven batched D^3 products per iteration.  Numerically the T-forms lose sqrt(cond(A_g)) where an explicit
 // A_g^-1 loses cond(A_g): against the x87 EM (N = 149, D = 200, six iterations, cond(W) = 3e8) W 1.3e-14, B 2.6e-13 without any
 // refinement step (rounds 2-5 with one: 3e-14, 2e-13; the reference's own formulation: 4e-12, 6e-9).
 // ------------------------------------------------------------------------------------
@@ -963,7 +963,13 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   const size_t group_bytes = (size_t)G * DD * 8 * 5;
   const bool grouped = h->em_variant != 1 && group_bytes <= ((size_t)24 << 30) && G <= 16384;
   h->em_groups = grouped ? G : 0;
-  if (grouped && h->em_variant != 3) {
+  // Two closed forms of the grouped EM.  The moment form (rounds 2-5) runs seven D^3 products per group and iteration on per-group
+  // second moments and never touches the K means again; the row form (round 6) runs one D^3 product per group and works on the K
+  // means every iteration.  At D = 200: moment ~ 98 + 8 G us, row ~ 112 + 0.0096 K + 0.64 G us per iteration -- the row form when
+  // there are enough groups for the means they stand for (PLDA_EM_VARIANT=3 / 4 force the moment / the row form).
+  const bool row_form = h->em_variant == 4 || (h->em_variant == 0 && G >= 4 && 4 * (int64_t)G * D >= K);
+  h->em_form = !grouped ? 0 : row_form ? 2 : 1;
+  if (grouped && row_form) {
     // ---- row form (the kernels' header above) ----
     const int64_t sDD = (int64_t)DD, GD = (int64_t)G * D;
     const int RB = D <= 256 ? 2 : 1;    // row blocks per tile of em_rows_kernel / em_xtb_kernel (LDS)
@@ -1065,14 +1071,13 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     for (int it = 0; it < iters; ++it) {
       // inv = A^-1 ; Q = B A^-1 ; b1 = Mx = W Q^T ; QC = Q C_g (over inv) ; b3 = QCQ = QC Q^T
       double *inv = b2, *Q = b0;
-      if (it == 0 && h->em_variant != 2) {
+      if (it == 0) {
         if (D > 256) { inv = b0; Q = b2; }
         em_first_inverse_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(dgn, D, sDD, inv);
         PLDA_LAUNCH_CHECK(h);
       } else if (D <= 256) {
-        // registers, one CU per group (PLDA_EM_VARIANT=2: the full sweep instead of whitening + T^T T)
-        if (h->em_variant == 2) PLDA_TRY(spd_inverse_f64(h, W, B, dgn, D, inv, dflag, G));
-        else PLDA_TRY(spd_inverse_via_whitening_f64(h, W, B, dgn, D, Q, inv, dflag, G));   // (Q is free until the next line)
+        // registers, one CU per group
+        PLDA_TRY(spd_inverse_via_whitening_f64(h, W, B, dgn, D, Q, inv, dflag, G));   // (Q is free until the next line)
       } else {
         // A^-1 = T^T T from the blocked whitening; A is dead once T exists, so the inverse replaces it in b0,
         // and b1 .. b3 (contiguous) are the 3 D^2 doubles of scratch per group

@@ -175,6 +175,12 @@ class MPlda(object):
         self._ck(self._lib.plda_fit_timings(self._h, _ptr(t)))
         return dict(stats_ms=t[0], em_ms=t[1], output_ms=t[2], iters=int(t[3]))
 
+    def fit_plan(self):
+        """How the EM of the last fit ran: dict(groups = distinct utterance counts, form = "basis" | "moments" | "rows")."""
+        p = np.zeros(2, np.int32)
+        self._ck(self._lib.plda_fit_plan(self._h, _ptr(p)))
+        return dict(groups=int(p[0]), form=("basis", "moments", "rows")[int(p[1])])
+
     def fit_internals(self):
         """means/counts/scatter/sum/W/B of the last fit (parity tests)."""
         k = C.c_int64()

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_fit.py -x -q 2>&1 | tail -3
-for v in "PLDA_EM_SYRK_ROWS=96"; do
+timeout 1200 python -m pytest tests/test_gpu_fit.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -5
+for v in "A=1"; do
 echo "=== $v"
 rm -rf gpurun_out/fitgroups_r6
 env $v rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fitgroups_r6 -o t -- python scripts/fit_groups_probe.py 2>&1 | grep -v "^[WE]2026" | tail -4

@@ -316,14 +316,20 @@ def test_fit_em_dev_rejects_bad_statistics():
         eng.fit_em_dev(means.data_ptr(), one.data_ptr(), 1, scatter.data_ptr(), 4, 2)
 
 
+@pytest.mark.parametrize("form", ["3", "4"])
 @pytest.mark.parametrize("d,k", [(288, 40), (512, 30), (700, 24)])
-def test_fit_large_dim_blocked_inverse(oracle, d, k):
-    """D > 256: (W + nB)^-1 = T^T T from the blocked whitening (one and two levels of block elimination over the
-    register-resident Cholesky); skewed counts give several groups in the batch."""
+def test_fit_large_dim_blocked_inverse(oracle, monkeypatch, d, k, form):
+    """D > 256: the whitening factor of W + nB from the blocked whitening (one and two levels of block elimination over the
+    register-resident Cholesky); skewed counts give several groups in the batch.  Both closed forms of the grouped EM
+    (PLDA_EM_VARIANT=3 per-group second moments, 4 class means: 16-row tiles at D = 288 and 512, plain products per group
+    above 512)."""
     from plda_amd import MPlda
     x, y = make_data(40 + d, 3 * d, d, k, skew=True, scale_between=0.3)
+    monkeypatch.setenv("PLDA_EM_VARIANT", form)
     eng = MPlda(0)
+    monkeypatch.delenv("PLDA_EM_VARIANT")
     eng.fit(x, y, 3)
+    assert eng.fit_plan()["form"] == ("moments" if form == "3" else "rows")
     ref = oracle.fit(x, y, 3)
     it = eng.fit_internals()
     assert _rel(it["W"], ref["W"]) < 1e-9, _rel(it["W"], ref["W"])
@@ -332,15 +338,18 @@ def test_fit_large_dim_blocked_inverse(oracle, d, k):
     assert np.abs(g["psi"] - ref["psi"]).max() <= 1e-9 * max(ref["psi"].max(), 1e-12)
 
 
+@pytest.mark.parametrize("form", ["3", "4"])
 @pytest.mark.parametrize("n,d,k", [(150, 200, 4), (150, 257, 4), (150, 300, 4), (300, 512, 8)])
-def test_fit_with_fewer_samples_than_dimensions(oracle, n, d, k):
+def test_fit_with_fewer_samples_than_dimensions(oracle, monkeypatch, n, d, k, form):
     """N - K < D: the within-class scatter is singular and every EM iteration multiplies cond(W) by ~40 (1e9 after
     six).  Any two fp64 implementations then differ by about cond * eps -- the C and NumPy oracles by 5e-7 in psi --
     and the engine has to stay at that level.  (Regression: block elimination with the explicit inverse of the
     leading block gave 6.5e-4 at D = 257 and 300, where that block is itself ill conditioned.)"""
     from plda_amd import MPlda
     x, y = make_data(5000, n, d, k, scale_between=0.2)
+    monkeypatch.setenv("PLDA_EM_VARIANT", form)
     eng = MPlda(0)
+    monkeypatch.delenv("PLDA_EM_VARIANT")
     eng.fit(x, y, 6)
     ref = oracle.fit(x, y, 6)
     assert np.linalg.cond(ref["W"]) > 1e8
@@ -351,12 +360,14 @@ def test_fit_with_fewer_samples_than_dimensions(oracle, n, d, k):
     assert e_psi < 2e-5, e_psi
 
 
+@pytest.mark.parametrize("form", ["3", "4"])
 @pytest.mark.parametrize("n,d,k,skew", [(48, 64, 4, False), (90, 128, 6, True), (149, 200, 5, True)])
-def test_em_against_extended_precision_when_ill_conditioned(oracle, n, d, k, skew):
+def test_em_against_extended_precision_when_ill_conditioned(oracle, monkeypatch, n, d, k, skew, form):
     """Fewer samples than dimensions, six iterations: W and B against the same EM run in x87 extended precision
-    (oracle/plda_oracle_np.py:fit_wb_longdouble).  The grouped EM with its refinement step of Q has to be at least
-    as close to it as the reference's formulation (the fp64 oracle) is -- without the step it was 500 x (W) and
-    100 x (B) further away."""
+    (oracle/plda_oracle_np.py:fit_wb_longdouble).  Both grouped forms have to be at least as close to it as the
+    reference's formulation (the fp64 oracle) is: the moment form (PLDA_EM_VARIANT=3) with its refinement step of Q --
+    without the step it was 500 x (W) and 100 x (B) further away --, the row form (4) because it multiplies by the
+    whitening factor T and never by T^T T (sqrt(cond) instead of cond)."""
     from oracle import plda_oracle_np as onp
     from plda_amd import MPlda
     x, y = make_data(777 + d, n, d, k, skew=skew, scale_between=0.5)
@@ -368,7 +379,9 @@ def test_em_against_extended_precision_when_ill_conditioned(oracle, n, d, k, ske
     def err(a, t):
         return float(np.abs(a.astype(np.longdouble) - t).max() / np.abs(t).max())
 
+    monkeypatch.setenv("PLDA_EM_VARIANT", form)
     eng = MPlda(0)
+    monkeypatch.delenv("PLDA_EM_VARIANT")
     eng.fit(x, y, 6)
     it = eng.fit_internals()
     e_w, e_b = err(it["W"], Wt), err(it["B"], Bt)
@@ -377,7 +390,8 @@ def test_em_against_extended_precision_when_ill_conditioned(oracle, n, d, k, ske
     assert e_b <= max(2 * o_b, 1e-12), (e_b, o_b)
 
 
-@pytest.mark.parametrize("env", [{"PLDA_EM_VARIANT": "1"}, {"PLDA_JACOBI_VARIANT": "1"}, {"PLDA_GEMM64_VARIANT": "1"}])
+@pytest.mark.parametrize("env", [{"PLDA_EM_VARIANT": "1"}, {"PLDA_EM_VARIANT": "3"}, {"PLDA_EM_VARIANT": "4"}, {"PLDA_JACOBI_VARIANT": "1"},
+                                 {"PLDA_GEMM64_VARIANT": "1"}])
 def test_fit_alternative_arms_agree(oracle, monkeypatch, env):
     """The non-default arms kept in the library -- EM in the simultaneously-diagonalised basis (also the
     fallback when the per-group matrices would not fit), the rotation-by-rotation Jacobi round, 64 x 64
@@ -476,3 +490,33 @@ def test_statistics_pass_block_scatter_kernel(oracle, d, n, k):
     assert np.abs(S - st["scatter"]).max() <= 1e-11 * np.abs(st["scatter"]).max(), np.abs(S - st["scatter"]).max() / np.abs(st["scatter"]).max()
     assert np.array_equal(S, S.T)
     eng.set_stream(None)
+
+
+def test_em_form_follows_the_shape_and_the_forms_agree(oracle, monkeypatch):
+    """Real data has speakers with different utterance counts (the reason the reference sorts its classes,
+    pldamodule.cpp:94-100): many distinct counts take the row form of the grouped EM, few groups of many classes the
+    moment form; forced either way (PLDA_EM_VARIANT=3 / 4) they give the same W and B, and both the oracle's."""
+    from plda_amd import MPlda
+    rng = np.random.default_rng(12)
+    K, D = 600, 48
+    nk = rng.integers(2, 30, K)                          # ~28 distinct counts
+    y = np.repeat(np.arange(K), nk).astype(np.uint64)
+    x = rng.random((y.shape[0], D)) + 0.4 * rng.standard_normal((K, D))[y.astype(np.int64)]
+    ref = oracle.fit(x, y, 5)
+    got = {}
+    for form in ("0", "3", "4"):
+        monkeypatch.setenv("PLDA_EM_VARIANT", form)
+        eng = MPlda(0)
+        monkeypatch.delenv("PLDA_EM_VARIANT")
+        eng.fit(x, y, 5)
+        plan = eng.fit_plan()
+        assert plan["groups"] == len(np.unique(nk))
+        assert plan["form"] == {"0": "rows", "3": "moments", "4": "rows"}[form]
+        got[form] = eng.fit_internals()
+        assert _rel(got[form]["W"], ref["W"]) < 1e-10 and _rel(got[form]["B"], ref["B"]) < 1e-10
+    assert _rel(got["3"]["W"], got["4"]["W"]) < 1e-12 and _rel(got["3"]["B"], got["4"]["B"]) < 1e-12
+    # few groups of many classes: the moment form
+    y2 = (np.arange(4000) % 100).astype(np.uint64)
+    eng = MPlda(0)
+    eng.fit(rng.random((4000, D)), y2, 2)
+    assert eng.fit_plan() == dict(groups=1, form="moments")
