@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 flop/clk
 PEAK_FP64_MFMA_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: half of that
-CURRENT_ROUND = 5               # profiles/rNN_* files a bench line may cite
+CURRENT_ROUND = 6               # profiles/rNN_* files a bench line may cite
 
 CONFIGS = {
     # name: fit rows, featdim, speakers, enrol models, enrol counts, test vectors
@@ -121,6 +121,51 @@ def cpu_em_baseline(X, y, gpu_one_iter=None):
     return res
 
 
+def skewed_labels(N, K, lo=5, hi=60, seed=2):
+    """C2's rows labelled as real data is (BASELINE.md C2 "skewed-n_k variant"; the reason the reference sorts its classes by
+    count, pldamodule.cpp:94-100): utterance counts drawn from [lo, hi], rescaled to N rows, the rounding's leftover one row each."""
+    rng = np.random.default_rng(seed)
+    nk = rng.integers(lo, hi + 1, K).astype(np.float64)
+    nk = np.maximum(1, np.floor(nk * N / nk.sum())).astype(np.int64)
+    nk[: N - nk.sum()] += 1
+    return np.repeat(np.arange(K), nk)[:N].astype(np.uint64), nk
+
+
+def fit_skewed(eng, dX, N, D, K, iters, X_host, with_cpu):
+    """fit on C2's rows with unequal speaker counts (n_k in [5, 60]): the number of distinct counts G, which closed form of the
+    grouped EM ran, statistics / EM / GetOutput ms, EM iterations/s, and W / B after ONE iteration against the oracle's."""
+    import torch
+    y, nk = skewed_labels(N, K)
+    dy = torch.from_numpy(y.astype(np.int64)).to(dX.device)
+    res = {"labels": "n_k in [5, 60], seed 2 (skewed_labels)", "distinct_counts_G": int(len(np.unique(nk))), "N": N, "D": D, "K": K}
+    one = None
+    if with_cpu:
+        eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, 1)
+        torch.cuda.synchronize(dX.device)
+        one = eng.fit_internals()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, iters)
+        torch.cuda.synchronize(dX.device)
+        w = time.perf_counter() - t0
+        ft = eng.fit_timings()
+        if best is None or w < best[0]:
+            best = (w, ft)
+    w, ft = best
+    plan = eng.fit_plan()
+    res.update({"em_form": plan["form"], "groups": plan["groups"], "fit_wall_s": round(w, 5), "timing": "min of 3",
+                "stats_ms": round(ft["stats_ms"], 3), "em_ms": round(ft["em_ms"], 3), "output_ms": round(ft["output_ms"], 3),
+                "iters": ft["iters"], "em_ms_per_iter": round(ft["em_ms"] / max(ft["iters"], 1), 4),
+                "em_iters_per_s": round(ft["iters"] / (ft["em_ms"] / 1e3), 2) if ft["em_ms"] > 0 else None})
+    if with_cpu and X_host is not None:
+        try:
+            res["cpu_oracle"] = cpu_em_baseline(X_host, y, one)
+        except Exception as e:   # noqa: BLE001 -- informative leg
+            res["cpu_oracle"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
 def end_to_end(eng, X, y, D, dout):
     """The reference user's view (SURVEY.md section 8d "also report end-to-end incl. H2D"): NumPy arrays in, NumPy
     arrays out through the drop-in API -- pageable host memory on both sides, PCIe inclusive.  Never `value`."""
@@ -178,6 +223,21 @@ def latest_traffic(M, Nt, dout):
         except Exception:
             pass
     return best if best else (None, None)
+
+
+def describe_ranks(descs, scores_numel=0):
+    """`multi_gpu` of the printed line from the ranks' own plda_comm_describe answers.  `comm_nranks` is what the transport in use
+    reports; `rccl_nranks` / `rccl_version` appear ONLY when that transport is RCCL (then they come from ncclCommCount /
+    ncclGetVersion inside the library) -- a peer / host / custom line must not carry a key that reads as "RCCL saw N ranks"."""
+    d0 = descs[0]
+    multi = {"transport": d0["transport"], "comm_nranks": d0["nranks"],
+             "ranks": [{"rank": d_["rank"], "device": d_["device"], "pci_bus_id": d_["pci_bus_id"]} for d_ in descs],
+             "distinct_devices": len({d_["pci_bus_id"] for d_ in descs}),
+             "scores_per_rank_GB": round(scores_numel * 4 / 1e9, 2)}
+    if d0["transport"] == "rccl":
+        multi["rccl_nranks"] = d0["nranks"]
+        multi["rccl_version"] = d0.get("rccl_version")
+    return multi
 
 
 def launch_command(n, argv, port=None):
@@ -311,6 +371,7 @@ def main():
 
     # ---- fit: rank 0 + broadcast of the model, or sharded by speaker over the library's RCCL communicator ----
     fit_info = None
+    fit_skew = None
     gpu_one_iter = None
     if args.shard_fit and world > 1:
         dX, dy = fit_rows()
@@ -375,9 +436,17 @@ def main():
                     # K2 = 2 N D^2 algorithmic flop on the fp64 MFMA pipe (78.6 TFLOP/s); stage times are HIP-event
                     # spans and include the stage's small helper kernels
                     "stages": stages}
-        del dX, dy
+        fit_info["em_form"] = eng.fit_plan()["form"]
         model = eng.get_model()
         packed = np.concatenate([model["mean"], model["transform"].ravel(), model["psi"]])
+        if args.config == "C2":
+            # the same rows labelled as real data is (unequal speaker counts); the model scored below stays the uniform fit's
+            try:
+                fit_skew = fit_skewed(eng, dX, N, D, K, args.iters, X, not args.no_cpu)
+            except Exception as e:   # noqa: BLE001 -- informative leg
+                fit_skew = {"error": "%s: %s" % (type(e).__name__, e)}
+            eng.set_model(model["mean"], model["transform"], model["psi"])
+        del dX, dy
     else:
         packed = np.zeros(D + D * D + D)
     if world > 1 and not args.shard_fit:
@@ -514,10 +583,7 @@ def main():
     if world > 1:
         descs = [None] * world
         dist.all_gather_object(descs, eng.comm_describe())
-        multi = {"transport": descs[0]["transport"], "rccl_nranks": descs[0]["nranks"], "rccl_version": descs[0].get("rccl_version"),
-                 "ranks": [{"rank": d_["rank"], "device": d_["device"], "pci_bus_id": d_["pci_bus_id"]} for d_ in descs],
-                 "distinct_devices": len({d_["pci_bus_id"] for d_ in descs}),
-                 "scores_per_rank_GB": round(out.numel() * 4 / 1e9, 2)}
+        multi = describe_ranks(descs, out.numel())
     if world > 1 and not args.no_gather:
         try:   # the second leg must not cost the run its (already measured) main line
             err_g = None
@@ -813,6 +879,9 @@ def main():
                        "trials_per_step": M * Nt, "enrol_models": M, "test_vectors": Nt,
                        "parallelism": "enrol rows block-cyclic over %d rank(s) (%s scaling: %d enrol models in all), scores left sharded in compact slabs"
                                       % (world, args.scaling, M) if world > 1 else "one GPU",
+                       **({"value_excludes": "scores left row-sharded in compact [M/N, Nt] slabs: NO collective in the timed region; the "
+                                             "matrix assembled on every rank by the all-gather over xGMI is gather_trials_per_s, beside value"}
+                          if world > 1 else {}),
                        "score_dtype": "f32 (fp64 bias terms, fp32 MFMA contraction)", "fit_dtype": "f64"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -830,6 +899,12 @@ def main():
                          **({"clock": clock_info} if clock_info else {})},
             "fit": fit_info, "spot_check_max_abs_err": spot, "oracle_check": oracle_check,
         }
+        if fit_info and fit_info.get("em_iters_per_s"):
+            res["fit_em_iters_per_s"] = fit_info["em_iters_per_s"]           # equal speaker counts (G = 1)
+        if fit_skew:
+            res["fit_skewed"] = fit_skew
+            if fit_skew.get("em_iters_per_s"):
+                res["fit_skewed_em_iters_per_s"] = fit_skew["em_iters_per_s"]   # n_k in [5, 60]: what real data looks like
         if multi:
             res["multi_gpu"] = multi
         if eer_info:
@@ -855,7 +930,11 @@ def main():
                 res["gather_peer_trials_per_s"] = pdw["value"]
                 res["gather_peer_ingest_GBps_per_rank"] = pdw.get("ingest_GBps_per_rank")
         if multi:
-            res["rccl_nranks"] = multi.get("rccl_nranks")
+            res["transport"] = multi["transport"]
+            res["comm_nranks"] = multi["comm_nranks"]
+            if "rccl_nranks" in multi:                       # only ever from ncclCommCount (describe_ranks)
+                res["rccl_nranks"] = multi["rccl_nranks"]
+                res["rccl_version"] = multi["rccl_version"]
             res["distinct_devices"] = multi.get("distinct_devices")
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(dout, psi[:dout])

@@ -199,7 +199,34 @@ def test_bench_gpus_2_launches_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["rccl_nranks"] == 2 and j["multi_gpu"]["transport"] == "peer"
+    assert j["n_gpus"] == 2 and j["comm_nranks"] == 2 and j["transport"] == "peer" and j["multi_gpu"]["transport"] == "peer"
+    assert "rccl_nranks" not in j and "rccl_nranks" not in j["multi_gpu"]      # that key only ever comes from ncclCommCount
+    assert "NO collective" in j["config"]["value_excludes"]
     assert j["oracle_check"]["within_1e-4_on_every_rank"] is True
     assert j["gather_inclusive"]["gathered_blocks_bit_identical_to_their_owners"] is True
     assert j["gather_trials_per_s"] == j["gather_inclusive"]["value"] > 0 and j["gather_transport"] == "peer"
+
+
+def test_bench_gpus_2_c4_strong_scaling_over_the_peer_provider():
+    """The code path of BASELINE's 8-GPU configuration (C4: enrol models with n in 1..5, found once per call; strong scaling:
+    ONE matrix split block-cyclically; a ragged tail -- 20 003 rows are no multiple of the 256-row block) on two ranks that
+    share this box's GPU, self-launched: `bench.py --gpus 2 --config C4 --scaling strong --rows 20003` is DESIGN.md
+    section 5's recipe with a smaller matrix."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--transport", "peer",
+                        "--config", "C4", "--scaling", "strong", "--rows", "20003", "--speakers", "700", "--steps", "2",
+                        "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["comm_nranks"] == 2 and "rccl_nranks" not in j
+    assert j["config"]["enrol_models"] == 20003 and j["config"]["test_vectors"] == 20003
+    assert j["roofline"]["flop_per_trial"] == 2 * (256 + 5 - 1)             # mixed counts: depth D + G - 1
+    assert j["oracle_check"]["within_1e-4_on_every_rank"] is True
+    assert j["gather_inclusive"]["gathered_blocks_bit_identical_to_their_owners"] is True

@@ -193,3 +193,20 @@ def test_bench_launches_its_own_ranks(monkeypatch):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "n_gpus" not in r.stdout and "needs 2 GPUs" in r.stderr
+
+
+def test_bench_line_names_rccl_only_when_rccl_ran():
+    """`rccl_nranks` answers "did RCCL see N ranks?": it may only come from a communicator that IS RCCL (ncclCommCount inside
+    plda_comm_describe).  A peer / host / custom transport reports `comm_nranks` and no rccl_* key (round-5 review: a peer line
+    printed rccl_nranks: 2, rccl_version: 0)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    ranks = [dict(transport="peer", nranks=2, rank=r, device=0, pci_bus_id="0000:05:00.0", rccl_version=0) for r in range(2)]
+    m = bench.describe_ranks(ranks, 1000)
+    assert m["transport"] == "peer" and m["comm_nranks"] == 2 and m["distinct_devices"] == 1
+    assert not any(k.startswith("rccl") for k in m)
+    host = bench.describe_ranks([dict(r, transport="host") for r in ranks])
+    assert not any(k.startswith("rccl") for k in host)
+    rc = [dict(transport="rccl", nranks=8, rank=r, device=r, pci_bus_id="0000:%02x:00.0" % r, rccl_version=22606) for r in range(8)]
+    m = bench.describe_ranks(rc)
+    assert m["comm_nranks"] == m["rccl_nranks"] == 8 and m["rccl_version"] == 22606 and m["distinct_devices"] == 8
