@@ -726,7 +726,7 @@ def main():
             import ctypes as C
             old_env = os.environ.get("PLDA_GEMM_VARIANT")
             os.environ["PLDA_GEMM_VARIANT"] = "47"
-            e2 = MPlda(local_rank)
+            e2 = MPlda(local_rank, diag=True)      # the diagnostic build: the product library does not contain this arm
             if old_env is None:
                 del os.environ["PLDA_GEMM_VARIANT"]
             else:
@@ -757,9 +757,15 @@ def main():
                           "mfma_busy_in_cycles": round(float(ideal_tile / np.median(cpt)), 4),
                           "workgroup0": {"cycles": cyc, "ticks_100MHz": real, "tiles": tiles, "MHz": round(mhz, 1)},
                           "end_spread_of_workgroups_us": round(end_spread_us, 1),
-                          "how": "PLDA_GEMM_VARIANT=47 (the product kernel + s_memtime / s_memrealtime stamps per workgroup), last of 3 launches on the timed operands"}
+                          "how": "libplda_hip_diag.so, PLDA_GEMM_VARIANT=47 (the product kernel + s_memtime / s_memrealtime stamps per workgroup), last of 3 launches on the timed operands"}
             e2.set_stream(None)
             del e2
+        except ImportError as ex:    # the diagnostic library was not built (python -m plda_amd.build --diag)
+            if old_env is None:
+                os.environ.pop("PLDA_GEMM_VARIANT", None)
+            else:
+                os.environ["PLDA_GEMM_VARIANT"] = old_env
+            clock_info = {"skipped": str(ex)[:200]}
         except Exception as ex:      # a diagnostic: never fails the bench line
             clock_info = {"error": str(ex)[:200]}
 

@@ -59,6 +59,9 @@ int plda_create(int device, plda_handle **out);
 int plda_destroy(plda_handle *h);
 const char *plda_last_error(const plda_handle *h);
 int plda_abi_version(void);
+/* bit 0: built with -DPLDA_DIAG=1 (libplda_hip_diag.so: + the measurement arms of the trials GEMM, some of which return
+ * garbage scores; selected by PLDA_GEMM_VARIANT).  The product library returns 0 and plda_create refuses those variants. */
+int plda_build_flags(void);
 /* enqueue on exactly this hipStream_t (e.g. torch's current stream; NULL is HIP's default
  * stream, with its implicit-synchronisation rules); plda_reset_stream goes back to the
  * handle's own non-blocking stream */

@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libplda_hip.so")
+SO_DIAG_PATH = os.path.join(_HERE, "lib", "libplda_hip_diag.so")   # -DPLDA_DIAG=1: + the measurement arms (build.py --diag)
 
 PLDA_OK = 0
 PLDA_E_INVAL = -1
@@ -25,6 +26,7 @@ _i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
 # or a device address), exactly the plain-pointer ABI of include/plda_hip.h
 SIGNATURES = {
     "plda_abi_version": (C.c_int, []),
+    "plda_build_flags": (C.c_int, []),
     "plda_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "plda_destroy": (C.c_int, [_vp]),
     "plda_last_error": (C.c_char_p, [_vp]),
@@ -124,24 +126,30 @@ class Collectives(C.Structure):
                 ("all_reduce", DEV_ALL_REDUCE), ("destroy", DESTROY_FN)]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libplda_hip.so and bind every symbol of include/plda_hip.h."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(SO_PATH):
+def load(diag=None):
+    """Load libplda_hip.so and bind every symbol of include/plda_hip.h.  diag=True (or PLDA_LIB_DIAG=1 when diag is None): the
+    diagnostic build libplda_hip_diag.so, which additionally holds the measurement arms (profiling scripts only)."""
+    if diag is None:
+        diag = os.environ.get("PLDA_LIB_DIAG", "0") == "1"
+    diag = bool(diag)
+    if diag in _libs:
+        return _libs[diag]
+    path = SO_DIAG_PATH if diag else SO_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            "plda_amd: %s not found -- build it with `python -m plda_amd.build` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
-    lib = C.CDLL(SO_PATH)
+            "plda_amd: %s not found -- build it with `python -m plda_amd.build%s` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % (path, " --diag" if diag else ""))
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if bool(lib.plda_build_flags() & 1) != diag:
+        raise ImportError("plda_amd: %s was built with%s -DPLDA_DIAG=1" % (path, "out" if diag else ""))
+    _libs[diag] = lib
     return lib
 
 

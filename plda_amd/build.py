@@ -2,6 +2,11 @@
 
 hipcc cross-compiles without a GPU; the .so is kept in-tree (git-ignored) so it
 travels to the GPU box with the snapshot.
+
+`--diag` (build(diag=True)) builds the DIAGNOSTIC library plda_amd/lib/libplda_hip_diag.so from the same sources with
+-DPLDA_DIAG=1 (objects under lib/diag/): it additionally contains the measurement arms of the trials GEMM (bounding arms
+that return garbage scores, clock-stamp and stage-depth arms; csrc/common.hpp).  The profiling scripts and bench.py's
+shader-clock reading load it (plda_amd._native.load(diag=True) / PLDA_LIB_DIAG=1); nothing else does.
 """
 import os
 import subprocess
@@ -11,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libplda_hip.so")
+SO_DIAG = os.path.join(LIBDIR, "libplda_hip_diag.so")
 SOURCES = ["api.hip", "score.hip", "linalg.hip", "fit.hip", "frontend.hip", "eer.hip", "lda.hip", "comm.hip", "eig_dc.hip", "hostio.hip", "transform.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "hostio.hpp"), os.path.join(CSRC, "sweep_mfma.inc"), os.path.join(CSRC, "score_bt4.inc"), os.path.join(CSRC, "score_bf16x3.inc"), os.path.join(CSRC, "syrk_blk.inc"), os.path.join(HERE, "..", "include", "plda_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
@@ -31,17 +37,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, diag=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "diag") if diag else LIBDIR
+    so = SO_DIAG if diag else SO
+    flags = FLAGS + (["-DPLDA_DIAG=1"] if diag else [])
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + EXTRA.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -55,13 +64,13 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    if force or procs or _stale(SO, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl", "-lpthread"]   # librccl is opened lazily by plda_comm_init (csrc/comm.hip)
+    if force or procs or _stale(so, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl", "-lpthread"]   # librccl is opened lazily by plda_comm_init (csrc/comm.hip)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -173,6 +173,7 @@ template <typename F> int guarded(plda_handle *h, const char *fn, F &&body) noex
 extern "C" {
 
 int plda_abi_version(void) { return 2; }
+int plda_build_flags(void) { return PLDA_DIAG ? 1 : 0; }
 
 int plda_create(int device, plda_handle **out) {
   return guarded(nullptr, "plda_create", [&]() -> int {
@@ -201,6 +202,17 @@ int plda_create(int device, plda_handle **out) {
     if (e != hipSuccess) { delete h; return fail(nullptr, PLDA_E_HIP, "plda_create: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
     if (const char *v = std::getenv("PLDA_GEMM_VARIANT")) h->gemm_variant = std::atoi(v);
+#if !PLDA_DIAG
+    {   // measurement arms (garbage scores or clock stamps): not in this build
+      static const int diag_only[] = {1, 2, 3, 4, 9, 10, 11, 12, 31, 33, 34, 35, 36, 37, 41, 44, 45, 46, 47, 54, 58, 62, 63};
+      for (int d : diag_only)
+        if (h->gemm_variant == d) {
+          delete h;
+          return fail(nullptr, PLDA_E_INVAL, "plda_create: PLDA_GEMM_VARIANT=%d is a measurement arm of the diagnostic build (PLDA_DIAG=1, "
+                                             "libplda_hip_diag.so); this library does not contain it", d);
+        }
+    }
+#endif
     if (const char *v = std::getenv("PLDA_PREP_VARIANT")) h->prep_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_MIXED_VARIANT")) h->mixed_variant = std::atoi(v);
     if (const char *v = std::getenv("PLDA_SCORE_DTYPE")) {

@@ -13,6 +13,14 @@
 
 #include "../../include/plda_hip.h"
 
+// PLDA_DIAG=1 (plda_amd/build.py --diag -> libplda_hip_diag.so): the measurement arms of the trials GEMM -- bounding arms that
+// skip the operand DMA or the stores and return GARBAGE scores, per-wave clock stamps, stage-depth sweeps -- are compiled in and
+// selectable through PLDA_GEMM_VARIANT.  The product library is built without it: those kernels are not instantiated and
+// plda_create refuses their variant numbers (round-5 review: a stray environment variable must not be able to corrupt scores).
+#ifndef PLDA_DIAG
+#define PLDA_DIAG 0
+#endif
+
 namespace plda {
 
 struct DevBuf {

@@ -568,181 +568,14 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
 }
 
 // ------------------------------------------------------------------------------------
-// Round 5, A/B ARM ONLY (PLDA_GEMM64_VARIANT=7; measured SLOWER, kept for the record): the same product on FOUR waves, one
-// per SIMD (syrk_tri4_kernel).  The idea: the eight-wave kernel above keeps two waves per SIMD at 230 registers each -- no
-// room for a second set of operand fragments, every k-step reads its 15 fragments and only then issues its 14 MFMAs -- so
-// give a lone wave 23 of the 91 tiles (tile q of the row-major triangle -> wave q mod 4), 184 accumulator registers in its
-// 512, all 13 fragments of a k-step read one k-step AHEAD into a second register set, 23 MFMAs per 13 LDS reads in one
-// branch-free run (the tile count is a template parameter: with a run-time count every MFMA sat behind its own branch
-// and the compiler sank each fragment read to its MFMA).  Result (scripts/k2_size_probe.py, D = 200, executed flop):
-// steady state 0.35 of the fp64 MFMA peak against 0.43 for the eight-wave kernel, 0.166 against 0.151 ms at 100k rows.
-// Why: what K4 found (transform.hip) holds here too -- a lone wave's own vector, scalar, LDS and memory instructions do NOT
-// run in the shadow of its own fp64 MFMAs, so a stage's 16 loads, 16 LDS writes, 52 fragment reads, 52 weight multiplies and
-// the address arithmetic ADD to its 92 MFMAs; with two waves per SIMD one wave's staging overlaps the other's MFMAs.  The
-// eight-wave kernel stays the product; its steady state (0.43) is that overlap's efficiency, and at C2 a fixed ~26 us
-// (launch, first stages, 48 MB of partial slabs) sits under it.  Same partial layout, reduction kernel and ZN form.
+// Tried in round 5 and REMOVED in round 6 (it was PLDA_GEMM64_VARIANT=7): the same product on FOUR waves, one per SIMD, a
+// lone wave holding 23 of the 91 tiles (184 accumulator registers), all 13 fragments of a k-step read one k-step ahead,
+// 23 MFMAs per 13 LDS reads in one branch-free run.  Steady state 0.35 of the fp64 MFMA peak against 0.43 for the
+// eight-wave kernel above, 0.166 against 0.151 ms at 100k rows (D = 200).  Why: a lone wave's own vector, scalar, LDS and
+// memory instructions do NOT run in the shadow of its own fp64 MFMAs (K4's finding, transform.hip), so a stage's 16 loads,
+// 16 LDS writes, 52 fragment reads, 52 weight multiplies and the address arithmetic ADD to its 92 MFMAs; with two waves per
+// SIMD one wave's staging overlaps the other's MFMAs.
 // ------------------------------------------------------------------------------------
-template <typename F, int... Q>
-__device__ __forceinline__ void tri4_static_for(F &&f, std::integer_sequence<int, Q...>) { (f(std::integral_constant<int, Q>{}), ...); }
-struct Tri4Tile { int r, c; };
-constexpr Tri4Tile tri4_tile(int q) {            // tile q of the row-major lower triangle: (r, c), c <= r
-  int r = 0;
-  while ((r + 1) * (r + 2) / 2 <= q) ++r;
-  return Tri4Tile{r, q - r * (r + 1) / 2};
-}
-constexpr int TRI4_TPW = (TRI_NT * (TRI_NT + 1) / 2 + 3) / 4;      // tiles per wave: 23
-
-template <int W, bool ZN, int NT>
-__device__ __forceinline__ void syrk_tri4_wave(int D, int64_t K, int64_t kchunk, const double *__restrict__ X, int64_t ldx,
-                                               const double *__restrict__ kw, int64_t K1, const double *__restrict__ X2, int64_t ldx2,
-                                               double w2, double *__restrict__ part, const double *__restrict__ zc,
-                                               const double *__restrict__ zs, double (*Xs)[GK * TRI_LD], double (*Ws)[GK], double (*Rs)[GK * 4]) {
-  const int t = threadIdx.x, lane = t & 63;
-  const int D0 = ZN ? D - 2 : D;
-  // (NT = ceil(D / 16) is a TEMPLATE parameter: with a run-time tile count every MFMA sat behind its own branch, and the
-  //  compiler sank each fragment read to its MFMA with a full lgkmcnt(0) wait in front -- level with the eight-wave kernel)
-  constexpr int ntri = NT * (NT + 1) / 2;
-  const int64_t kbeg = (int64_t)blockIdx.x * kchunk;
-  const int64_t kend = min(K, kbeg + kchunk);
-  f64x4 acc[TRI4_TPW];
-#pragma unroll
-  for (int q = 0; q < TRI4_TPW; ++q) acc[q] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const int fi = lane & 15, fk = lane >> 4;
-  const int tc = t;                              // this thread's column of a stage (256 threads, TRI_LD = 224 columns)
-  const int gc = min(tc, D0 - 1);
-  double z_cs = 1.0, z_sh = 0.0, z_w = 0.0, z_L = 0.0, z_shr = 0.0;
-  if (ZN) {
-    if (tc < D0) { z_cs = zc[tc]; z_sh = zs[tc]; z_w = zc[D0 + tc]; }
-    z_L = zc[3 * D0]; z_shr = zs[D0];
-  }
-  auto fetch = [&](double (&r)[GK], int64_t k0) {
-#pragma unroll
-    for (int row = 0; row < GK; ++row) {
-      const int64_t gk = min(k0 + row, kend - 1);
-      r[row] = gk < K1 ? X[gk * ldx + gc] : X2[(gk - K1) * ldx2 + gc];
-    }
-  };
-  auto fetch_w = [&](int64_t k0) {
-    double w = 0.0;
-    if (t < GK && k0 + t < kend) w = k0 + t < K1 ? (kw ? kw[k0 + t] : 1.0) : w2;
-    return w;
-  };
-  auto store = [&](double *lds, const double (&r)[GK], double *rs) {
-    if (tc < TRI_LD) {
-      const bool ok = tc < D;
-#pragma unroll
-      for (int row = 0; row < GK; ++row) {
-        double v = ok ? r[row] : 0.0;
-        // (rounded product, then the subtraction -- not one fma: a one-row cohort must centre to exactly 0, as the pilot computes p)
-        if (ZN) v = tc < D0 ? __dsub_rn(__dmul_rn(r[row], z_cs), z_sh) : (tc == D0 + 1 ? 1.0 : 0.0);
-        lds[row * TRI_LD + tc] = v;
-      }
-    }
-    if (ZN) {
-#pragma unroll
-      for (int row = 0; row < GK; ++row) {
-        const double sq = wave_sum_f64(z_w * r[row] * r[row]);      // (z_w = 0 beyond column D0)
-        if (lane == 0) rs[row * 4 + W] = sq;
-      }
-    }
-  };
-  auto patch = [&](double *lds, const double *rs) {
-    if (t < GK) lds[t * TRI_LD + D0] = -0.5 * (((rs[t * 4] + rs[t * 4 + 1]) + (rs[t * 4 + 2] + rs[t * 4 + 3])) + z_L) - z_shr;
-  };
-  double r0[GK], r1[GK], w0 = 0.0, w1 = 0.0;
-  if (kbeg < kend) {
-    fetch(r0, kbeg);
-    w0 = fetch_w(kbeg);
-    if (kbeg + GK < kend) {
-      fetch(r1, kbeg + GK);
-      w1 = fetch_w(kbeg + GK);
-    }
-    store(Xs[0], r0, Rs[0]);
-    if (t < GK) Ws[0][t] = w0;
-  }
-  __syncthreads();
-  if (ZN) {
-    if (kbeg < kend) patch(Xs[0], Rs[0]);
-    __syncthreads();
-  }
-  auto stage = [&](int64_t k0, int cur, double (&rn)[GK], double &wn, const double (&rs)[GK], const double &ws) {
-    if (k0 + 2 * GK < kend) {
-      fetch(rn, k0 + 2 * GK);
-      wn = fetch_w(k0 + 2 * GK);
-    }
-    const double *Xr = Xs[cur], *Wr = Ws[cur];
-    double f[NT], g[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b) f[b] = Xr[fk * TRI_LD + b * 16 + fi];
-#pragma unroll
-    for (int kk = 0; kk < GK / 4; ++kk) {
-      if (kk + 1 < GK / 4) {
-#pragma unroll
-        for (int b = 0; b < NT; ++b) g[b] = Xr[((kk + 1) * 4 + fk) * TRI_LD + b * 16 + fi];
-      }
-      const double wk = Wr[kk * 4 + fk];
-      double fw[NT];
-#pragma unroll
-      for (int b = 0; b < NT; ++b) fw[b] = f[b] * wk;
-      __builtin_amdgcn_sched_barrier(0);        // the next k-step's reads are issued; this one's MFMAs follow as one run
-      tri4_static_for([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (W + 4 * q < ntri) {
-          constexpr Tri4Tile tl = tri4_tile(W + 4 * q);
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fw[tl.r], f[tl.c], acc[q], 0, 0, 0);
-        }
-      }, std::make_integer_sequence<int, TRI4_TPW>{});
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk + 1 < GK / 4) {
-#pragma unroll
-        for (int b = 0; b < NT; ++b) f[b] = g[b];
-      }
-    }
-    if (k0 + GK < kend) {
-      store(Xs[cur ^ 1], rs, Rs[cur ^ 1]);
-      if (t < GK) Ws[cur ^ 1][t] = ws;
-    }
-    lds_barrier();
-    if (ZN) {
-      if (k0 + GK < kend) patch(Xs[cur ^ 1], Rs[cur ^ 1]);
-      lds_barrier();
-    }
-  };
-  for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * GK) {
-    stage(k0, 0, r0, w0, r1, w1);
-    if (k0 + GK < kend) stage(k0 + GK, 1, r1, w1, r0, w0);
-  }
-  // partial: tile (r, c) at slot r (r + 1) / 2 + c = its index in the row-major triangle, 256 doubles in the MFMA C layout
-  double *slab = part + (int64_t)blockIdx.x * ntri * 256;
-  tri4_static_for([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    if constexpr (W + 4 * q < ntri) {
-      double *d = slab + (int64_t)(W + 4 * q) * 256 + lane;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d[r * 64] = acc[q][r];
-    }
-  }, std::make_integer_sequence<int, TRI4_TPW>{});
-}
-
-// NT = ceil(D / 16): instantiated for 13 (192 < D <= 208: the i-vector sizes, and C5's D + 2); other widths take the
-// eight-wave kernel
-template <bool ZN, int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void syrk_tri4_kernel(
-    int D, int64_t K, int64_t kchunk, const double *__restrict__ X, int64_t ldx, const double *__restrict__ kw, int64_t K1,
-    const double *__restrict__ X2, int64_t ldx2, double w2, double *__restrict__ part, const double *__restrict__ zc,
-    const double *__restrict__ zs) {
-  __shared__ double Xs[2][GK * TRI_LD];
-  __shared__ double Ws[2][GK];
-  __shared__ double Rs[2][GK * 4];
-  // (one instantiation per wave: a wave's tile list is compile-time, its accumulators never indexed by a runtime value;
-  //  the four run side by side in one workgroup -- s_barrier counts waves, not program counters)
-  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: syrk_tri4_wave<0, ZN, NT>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, zc, zs, Xs, Ws, Rs); break;
-    case 1: syrk_tri4_wave<1, ZN, NT>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, zc, zs, Xs, Ws, Rs); break;
-    case 2: syrk_tri4_wave<2, ZN, NT>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, zc, zs, Xs, Ws, Rs); break;
-    default: syrk_tri4_wave<3, ZN, NT>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, zc, zs, Xs, Ws, Rs); break;
-  }
-}
 
 // Round 5: 1024 threads per tile -- element e = t & 255 of the tile, quarter q = t >> 8 of the splits -- so that a tile's
 // 256 partials are four chains of <= 64 with sixteen loads in flight each instead of one chain of 256 with eight (the
@@ -876,8 +709,7 @@ int syrk_f64(plda_handle *h, int D, int64_t K, double alpha, const double *X, in
     splits = (int)ceil_div(K, kchunk);
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
-    if (h->gemm64_variant == 7 && nt == 13) syrk_tri4_kernel<false, 13><<<(unsigned)splits, 256, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part, nullptr, nullptr);
-    else syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part, nullptr, nullptr);
+    syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K, nullptr, 0, 0.0, part, nullptr, nullptr);
     syrk_tri_reduce_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, splits, D, alpha, beta, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
@@ -918,8 +750,7 @@ int syrk_znorm_f64(plda_handle *h, int D0, int64_t K, const double *X, const dou
   splits = (int)ceil_div(K, kchunk);
   PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
   double *part = h->w[15].as<double>();
-  if (h->gemm64_variant == 7 && nt == 13) syrk_tri4_kernel<true, 13><<<(unsigned)splits, 256, 0, h->stream>>>(D, K, kchunk, X, D0, nullptr, K, nullptr, 0, 0.0, part, zc, zs);
-  else syrk_tri_kernel<true><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, D0, nullptr, K, nullptr, 0, 0.0, part, zc, zs);
+  syrk_tri_kernel<true><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, D0, nullptr, K, nullptr, 0, 0.0, part, zc, zs);
   syrk_tri_reduce_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, D);
   PLDA_LAUNCH_CHECK(h);
   *used = true;
@@ -937,8 +768,7 @@ int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ld
     splits = (int)ceil_div(K, kchunk);
     PLDA_HIP(h, h->w[15].reserve((size_t)splits * ntri * 256 * 8));
     double *part = h->w[15].as<double>();
-    if (h->gemm64_variant == 7 && nt == 13) syrk_tri4_kernel<false, 13><<<(unsigned)splits, 256, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, nullptr, nullptr);
-    else syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, nullptr, nullptr);
+    syrk_tri_kernel<false><<<(unsigned)splits, 512, 0, h->stream>>>(D, K, kchunk, X, ldx, kw, K1, X2, ldx2, w2, part, nullptr, nullptr);
     syrk_tri_reduce_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, splits, D, 1.0, 0.0, C, ldc);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;

@@ -464,7 +464,9 @@ __device__ __forceinline__ void prep_enrol_buckets_body(const int block, const d
     int b = 0;
     for (int g = 1; g < cs.G; ++g) b = cs.vals[g] == n ? g : b;
     nn[j] = (double)n;
-    Lr[j] = coefG[(size_t)b * S + 2 * D];
+    // a count that is NOT in the set handed over (the host builds the set from these very counts; a caller-supplied set has to
+    // cover every slab): the row's bias becomes NaN -- a row of NaN scores, not quietly the scores of another count
+    Lr[j] = (b == 0 && cs.vals[0] != n) ? __longlong_as_double(0x7ff8000000000000ll) : coefG[(size_t)b * S + 2 * D];
     if (lane == 0) { sb[wave * RW + j] = row < R ? b : 0; ss[wave * RW + j] = rsf[j]; }
   }
   double acc[RW], xc[RW], xn[RW];
@@ -1487,7 +1489,7 @@ __global__ void pairs_bucket_kernel(const int32_t *__restrict__ n, int64_t M, co
   const int v = n[i];
   int b = 0;
   for (int g = 1; g < cs.G; ++g) b = cs.vals[g] == v ? g : b;
-  bidx[i] = b;
+  bidx[i] = (b == 0 && cs.vals[0] != v) ? -1 : b;        // -1: not in the set -> NaN scores for this model (score_pairs_tab_kernel)
 }
 // one wave per PPW consecutive trials (their loads in flight together)
 template <int PPW>
@@ -1509,8 +1511,9 @@ __global__ __launch_bounds__(256) void score_pairs_tab_kernel(const double *__re
     e[k] = e_idx[p];
     u[k] = U + e[k] * (int64_t)D;
     v[k] = V + t_idx[p] * (int64_t)D;
-    tb[k] = tab + (size_t)bidx[e[k]] * S;
-    acc[k] = 0.0;
+    const int bk = bidx[e[k]];
+    tb[k] = tab + (size_t)max(bk, 0) * S;
+    acc[k] = bk < 0 ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
   }
   for (int d = lane; d < D; d += 64) {
     const double w1 = i1[d];
@@ -1596,6 +1599,7 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
     if (!(h->gcoef_ptr == coefG && h->gcoef_epoch == h->model_epoch && h->gcoef_D == D && h->gcoef_set.G == G &&
           std::memcmp(h->gcoef_set.vals, cs->vals, (size_t)G * sizeof(int32_t)) == 0)) {
       bucket_coef_kernel<<<G, 256, 0, h->stream>>>(h->d_psi.as<double>(), D, *cs, coefG);
+      PLDA_LAUNCH_CHECK(h);
       h->gcoef_ptr = coefG; h->gcoef_epoch = h->model_epoch; h->gcoef_D = D; h->gcoef_set = *cs;
     }
     auto few = [&](int64_t rpad) { return h->prep_variant == 3 || (h->prep_variant != 2 && rpad <= 32768); };   // (as the uniform path below)
@@ -1653,9 +1657,10 @@ static int prepare_operands(plda_handle *h, const double *dU, const int32_t *dn,
       h->gcoef_ptr = nullptr;
       h->ucoef_ptr = coef; h->ucoef_epoch = h->model_epoch; h->ucoef_n = n_uniform; h->ucoef_D = D;
     }
-    if (h->prep_variant == 0) {
+    if (h->prep_variant != 1) {
       // one pass per side: bias, bias pair and packed operand together (prep_side_kernel; PLDA_PREP_VARIANT=1: the
-      // separate kernels below, kept as the A/B arm and the reference the bit-identity test compares with)
+      // separate kernels below, kept as the A/B arm and the reference the bit-identity test compares with; 2 / 3: this
+      // path with 16 / 4 rows per wave forced)
       auto few_rows = [&](int64_t rpad) { return h->prep_variant == 3 || (h->prep_variant != 2 && rpad <= 32768); };
 #define PREP_SIDE(SIDE_, RW_, RPAD_, ...) prep_side_kernel<SIDE_, RW_><<<(unsigned)((RPAD_) / (4 * RW_)), 256, 0, h->stream>>>(__VA_ARGS__)
       if (doA && doB && few_rows(op.Mpad) && few_rows(op.Npad)) {
@@ -1754,9 +1759,12 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     split_bf16x3_kernel<<<dim3((unsigned)(op.Npad / 256), (unsigned)KO), 256, 0, h->stream>>>(h->s_Bpk.as<f32x4>(), op.Npad, op.KQ, h->s_B16.as<f32x4>());
     static DeviceOnce once;
     if (once.needed(h->device)) {
-      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<4>),
-                           reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<8>), reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<12>),
-                           reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<16>)};
+      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<0>),
+#if PLDA_DIAG
+                           reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<4>), reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<8>),
+                           reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<12>), reinterpret_cast<const void *>(&trials_gemm_bf16x3_kernel<16>),
+#endif
+      };
       for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS));
       once.done(h->device);
     }
@@ -1770,6 +1778,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   trials_gemm_bf16x3_kernel<MODE_><<<256, 512, B3_LDS, h->stream>>>(h->s_A16.as<f32x4>(), h->s_B16.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad,  \
                                                                     nsteps, h->s_rbias.as<float>(), h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout, \
                                                                     ld, M, Nt, b3M, b3N, pM, pN, colwalk3, h->timeline.as<unsigned long long>())
+#if PLDA_DIAG      // measurement arms: only in the diagnostic build (plda_create refuses their variants otherwise)
     if (h->gemm_variant == 63) {                  // the product kernel + clock stamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       B3L(16);
@@ -1777,7 +1786,9 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     } else if (h->gemm_variant == 54) B3L(4);            // bounding arms (timing only): no DMA / no stores / neither
     else if (h->gemm_variant == 58) B3L(8);
     else if (h->gemm_variant == 62) B3L(12);
-    else B3L(0);
+    else
+#endif
+      B3L(0);
 #undef B3L
     PLDA_LAUNCH_CHECK(h);
     if (ev1) PLDA_HIP(h, hipEventRecord(ev1, h->stream));
@@ -1822,10 +1833,13 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       for (int x = 0; x < 8; ++x) { qs.qbase[x] = tb->qbase[x]; qs.qlen[x] = tb->qlen[x]; }
       if (!h->bt4_attr_set) {
         const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 0>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 0>),
+#if PLDA_DIAG
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 1>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 1>),
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 4>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 8>),
                              reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 12>), reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<4, 16>),
-                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 16>)};
+                             reinterpret_cast<const void *>(&trials_gemm_bt4_kernel<3, 16>),
+#endif
+        };
         for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT4_LDS));
         h->bt4_attr_set = true;
       }
@@ -1833,6 +1847,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   trials_gemm_bt4_kernel<FS_, MODE_><<<256, 256, BT4_LDS, h->stream>>>(                                   \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
       h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, (int)M, (int)Nt, h->bt4_fringe.as<float>(), tb->tab.as<int2>(), h->bt4_cnt.as<unsigned>(), qs, DBG_)
+#if PLDA_DIAG
       if (h->gemm_variant == 41) {
         PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
         PLDA_HIP(h, hipMemsetAsync(h->timeline.p, 0, TIMELINE_WORDS * 8, h->stream));
@@ -1848,7 +1863,9 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
         if (h->gemm_variant == 44) BT4L(4, 4, nullptr);
         else if (h->gemm_variant == 45) BT4L(4, 8, nullptr);
         else BT4L(4, 12, nullptr);
-      } else if (fs == 3) {
+      } else
+#endif
+      if (fs == 3) {
         BT4L(3, 0, nullptr);
       } else {
         BT4L(4, 0, nullptr);
@@ -1865,10 +1882,13 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     h->last_kernel = "trials_gemm_bt2_kernel";
     const int pM = (int)ceil_div(btM, BPR), pN = (int)ceil_div(btN, BPC);
     if (!h->bt2_attr_set) {
-      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>),
-                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>),
+      const void *fns[] = {reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<0>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<2>),
+#if PLDA_DIAG
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<1>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<3>),
                            reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<4>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<8>),
-                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<12>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<16>)};
+                           reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<12>), reinterpret_cast<const void *>(&trials_gemm_bt2_kernel<16>),
+#endif
+      };
       for (const void *f : fns) PLDA_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS));
       h->bt2_attr_set = true;
     }
@@ -1876,6 +1896,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
   trials_gemm_bt2_kernel<MODE_><<<256, 512, BT2_LDS, h->stream>>>(                                        \
       h->s_Apk.as<f32x4>(), h->s_Bpk.as<f32x4>(), (unsigned)op.Mpad, (unsigned)op.Npad, op.KQ,            \
       h->s_rpair.as<float2>(), h->s_cpair.as<float2>(), dout, ld, M, Nt, btM, btN, pN, pM * pN, DBG_)
+#if PLDA_DIAG
     if (h->gemm_variant == 31 || h->gemm_variant == 33) {
       // diagnostic: per-wave timestamps of workgroup 0 (plda_profile_timeline)
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
@@ -1887,14 +1908,16 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       PLDA_HIP(h, h->timeline.reserve(TIMELINE_WORDS * 8));
       BT2L(16, h->timeline.as<unsigned long long>());
       h->timeline_valid = true;
-    } else if (h->gemm_variant == 32) {
-      BT2L(2, nullptr);
     } else if (h->gemm_variant == 34) {       // bounding arms: timing only
       BT2L(4, nullptr);
     } else if (h->gemm_variant == 35) {
       BT2L(8, nullptr);
     } else if (h->gemm_variant == 36) {
       BT2L(12, nullptr);
+    } else
+#endif
+    if (h->gemm_variant == 32) {              // the LDS-transpose epilogue (A/B arm with the same scores: test_gpu_bigtile.py)
+      BT2L(2, nullptr);
     } else {
       BT2L(0, nullptr);
     }
@@ -1912,8 +1935,11 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
       h->s_rscale.as<float>(), h->s_cbias.as<float>(), dout,                                           \
       ld, M, Nt, tilesM, tilesN, patchesN, (int)numPatches, shift, colsum, colsq)
   h->last_kernel = "trials_gemm_kernel";
+#if PLDA_DIAG
   constexpr int EPI_NOSTORE = (EPI == 0) ? 2 : EPI;
+#endif
   switch (h->gemm_variant) {
+#if PLDA_DIAG   // tuning / ablation arms of scripts/gemm_sweep.py: diagnostic build only
     case 1: TG(8, EPI, 2, 0); break;             // stage depth 32 k
     case 2: TG(6, EPI, 2, 0); break;             // 24 k
     case 3: TG(6, EPI, 3, 0); break;             // 24 k, 3 workgroups / CU
@@ -1922,6 +1948,7 @@ static int launch_gemm(plda_handle *h, const TrialOperands &op, int64_t M, int64
     case 10: TG(8, EPI_NOSTORE, 2, 1); break;    // ... and no in-loop LDS reads
     case 11: TG(8, EPI_NOSTORE, 2, 2); break;    // ... and no in-loop DMA
     case 12: TG(8, EPI_NOSTORE, 2, 4); break;    // ... and no stage barriers
+#endif
     default: TG(10, EPI, 2, 0); break;           // product: 40 k per stage, 2 workgroups / CU
   }
 #undef TG

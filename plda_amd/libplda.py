@@ -127,12 +127,13 @@ class Transformed(dict):
 class MPlda(object):
     """GPU-resident PLDA model + z-norm statistics (MPlda struct, pldamodule.cpp:27-34)."""
 
-    def __init__(self, device=0):
-        self._lib = N.load()
+    def __init__(self, device=0, diag=None):
+        self._lib = N.load(diag)        # diag=True: the diagnostic build (measurement arms; profiling scripts only)
         h = C.c_void_p()
         rc = self._lib.plda_create(int(device), C.byref(h))
         if rc != N.PLDA_OK:
-            raise N.PldaError(rc, N.last_error(None))
+            msg = self._lib.plda_last_error(None)      # (this library's own thread-local message: it may be the diagnostic build)
+            raise N.PldaError(rc, msg.decode("utf-8", "replace") if msg else "")
         self._h = h
         self.device = int(device)
         # std::unordered_map<long,double> *meanz, *stdvz (pldamodule.cpp:33)
@@ -228,6 +229,7 @@ class MPlda(object):
         self.set_model(z["mean"], z["transform"], z["psi"])
         self._meanz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_mean"])}
         self._stdvz = {int(i): float(v) for i, v in zip(z["zn_ids"], z["zn_std"])}
+        self._zn_tag = None         # the sorted copy of _zn_arrays belongs to the dicts just replaced (id() of a new dict may repeat)
 
     def save_kaldi(self, path, binary=True):
         """Write the model as a Kaldi `Plda` file (plda_amd/kaldi_io.py: format restated, not pinned)."""

@@ -5,6 +5,7 @@ workgroup 0's cycles per tile against the tile's MFMA cycles -> MFMA-busy in CYC
 usage: gemm_clock.py variant N D launches"""
 import ctypes as C
 import os
+os.environ.setdefault("PLDA_LIB_DIAG", "1")      # measurement arms: the diagnostic build (python -m plda_amd.build --diag)
 import sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

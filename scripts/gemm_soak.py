@@ -1,6 +1,7 @@
 """Sustained-clock check: one trials-GEMM variant back to back, per-launch ms (HIP events) printed in
 groups, so that DVFS / thermal drift shows up.  usage: gemm_soak.py variant N D launches"""
 import os, sys
+os.environ.setdefault("PLDA_LIB_DIAG", "1")      # measurement arms: the diagnostic build (python -m plda_amd.build --diag)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PLDA_GEMM_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "0"

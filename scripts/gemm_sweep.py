@@ -1,6 +1,7 @@
 """Interleaved A/B of trials-GEMM variants (PLDA_GEMM_VARIANT) on the C2 shape.
 Tuning tool only (synthetic model, no fit); numbers quoted anywhere come from bench.py."""
 import os
+os.environ.setdefault("PLDA_LIB_DIAG", "1")      # measurement arms: the diagnostic build (python -m plda_amd.build --diag)
 import sys
 import numpy as np
 

@@ -3,6 +3,7 @@ shader-clock stamps at every stage barrier (arrive / leave), at the start of the
 around every tile epilogue.  Diagnostic only.  usage: gemm_timeline.py [N] [D]"""
 import ctypes as C
 import os
+os.environ.setdefault("PLDA_LIB_DIAG", "1")      # measurement arms: the diagnostic build (python -m plda_amd.build --diag)
 import sys
 import numpy as np
 

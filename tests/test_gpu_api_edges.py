@@ -359,3 +359,43 @@ def test_znorm_lookup_for_many_models_matches_the_per_key_lookup(oracle):
     got2 = p.score_matrix(enrol, test)
     np.testing.assert_array_equal(got2[:350], got[:350])
     np.testing.assert_allclose(got2[599], (raw[599] - zm2[keys[599]]) / zs2[keys[599]], rtol=2e-5, atol=2e-5)
+
+
+DIAG_ONLY_VARIANTS = [1, 2, 3, 4, 9, 10, 11, 12, 31, 33, 34, 35, 36, 37, 41, 44, 45, 46, 47, 54, 58, 62, 63]
+
+
+@pytest.mark.parametrize("variant", DIAG_ONLY_VARIANTS)
+def test_measurement_arms_are_not_in_the_product_library(monkeypatch, variant):
+    """PLDA_GEMM_VARIANT selects, among others, bounding arms of the trials GEMM that skip the operand DMA or the stores and
+    return GARBAGE scores with rc = 0 (round-5 review).  They exist only in libplda_hip_diag.so (-DPLDA_DIAG=1); the library
+    every caller gets refuses to create a handle under such a variant instead of silently corrupting scores."""
+    from plda_amd import MPlda, _native
+    from plda_amd._native import PldaError
+    assert _native.load().plda_build_flags() == 0
+    monkeypatch.setenv("PLDA_GEMM_VARIANT", str(variant))
+    with pytest.raises(PldaError, match="measurement arm"):
+        MPlda(0)
+    monkeypatch.delenv("PLDA_GEMM_VARIANT")
+    MPlda(0)                                            # (and nothing sticks)
+
+
+def test_diagnostic_library_still_has_them(monkeypatch):
+    """The diagnostic build accepts the same variants (bench.py's shader-clock reading uses 47: the product kernel + stamps,
+    whose scores are the product's)."""
+    import os
+    from plda_amd import MPlda, _native
+    if not os.path.exists(_native.SO_DIAG_PATH):
+        pytest.skip("libplda_hip_diag.so not built (python -m plda_amd.build --diag)")
+    assert _native.load(diag=True).plda_build_flags() == 1
+    rng = np.random.default_rng(4)
+    d, m, nt = 80, 2304, 49152                          # 9 x 192 tiles of 256 x 256: the one-wave-per-SIMD kernel's range
+    psi = np.sort(rng.random(d) + 0.05)[::-1].copy()
+    U, V = rng.standard_normal((m, d)), rng.standard_normal((nt, d))
+    outs = []
+    for diag in (False, True):
+        if diag:
+            monkeypatch.setenv("PLDA_GEMM_VARIANT", "47")
+        eng = MPlda(0, diag=diag)
+        eng.set_model(np.zeros(d), np.eye(d), psi)
+        outs.append(eng.score_matrix((1, U), (1, V)))
+    assert np.array_equal(outs[0], outs[1])
