@@ -166,6 +166,31 @@ def fit_skewed(eng, dX, N, D, K, iters, X_host, with_cpu):
     return res
 
 
+def fit_large_dim(eng, dev, iters):
+    """The reference's own large test shape (tests/pldatest.py:35-38: 10 000 x 1024 rows, 1 000 speakers of 10): fit wall clock,
+    statistics / EM / GetOutput and the per-stage spans -- the tridiagonalisation's share of GetOutput at D = 1024."""
+    import torch
+    N, D, K = 10000, 1024, 1000
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    dX = torch.rand((N, D), dtype=torch.float64, device=dev, generator=g)
+    dy = torch.div(torch.arange(N, device=dev, dtype=torch.int64), 10, rounding_mode="floor")
+    eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, iters)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, iters)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ft = eng.fit_timings()
+    eng.trace_enable(True)
+    eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, iters)
+    torch.cuda.synchronize(dev)
+    spans = eng.trace_read()
+    eng.trace_enable(False)
+    return {"shape": "tests/pldatest.py:35-38: 10000 x 1024, 1000 speakers of 10", "iters": iters, "fit_wall_ms": round(wall * 1e3, 3),
+            "stats_ms": round(ft["stats_ms"], 3), "em_ms": round(ft["em_ms"], 3), "output_ms": round(ft["output_ms"], 3),
+            "em_form": eng.fit_plan()["form"], "stages": [{"name": sp["name"], "ms": round(sp["ms"], 4)} for sp in spans]}
+
+
 def end_to_end(eng, X, y, D, dout):
     """The reference user's view (SURVEY.md section 8d "also report end-to-end incl. H2D"): NumPy arrays in, NumPy
     arrays out through the drop-in API -- pageable host memory on both sides, PCIe inclusive.  Never `value`."""
@@ -445,6 +470,11 @@ def main():
                 fit_skew = fit_skewed(eng, dX, N, D, K, args.iters, X, not args.no_cpu)
             except Exception as e:   # noqa: BLE001 -- informative leg
                 fit_skew = {"error": "%s: %s" % (type(e).__name__, e)}
+            if not args.no_extra and world == 1:
+                try:
+                    fit_skew["fit_d1024"] = fit_large_dim(eng, dev, args.iters)
+                except Exception as e:   # noqa: BLE001 -- informative leg
+                    fit_skew["fit_d1024"] = {"error": "%s: %s" % (type(e).__name__, e)}
             eng.set_model(model["mean"], model["transform"], model["psi"])
         del dX, dy
     else:
@@ -907,6 +937,8 @@ def main():
         }
         if fit_info and fit_info.get("em_iters_per_s"):
             res["fit_em_iters_per_s"] = fit_info["em_iters_per_s"]           # equal speaker counts (G = 1)
+        if fit_skew and "fit_d1024" in fit_skew:
+            res["fit_d1024"] = fit_skew.pop("fit_d1024")
         if fit_skew:
             res["fit_skewed"] = fit_skew
             if fit_skew.get("em_iters_per_s"):
