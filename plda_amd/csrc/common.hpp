@@ -189,7 +189,7 @@ struct plda_handle {
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
   plda::DevBuf eigdc;            // eig_dc.hip workspace
-  plda::DevBuf zn_rows, zn_y, zn_small;   // z-norm statistics by moments (score.hip)
+  plda::DevBuf zn_rows, zn_y, zn_small, zn_cpad;   // z-norm statistics by moments (score.hip; zn_cpad: the padded covariance of the model pass, transform.hip)
   int znorm_variant = 0;         // PLDA_ZNORM_VARIANT=1: every LLR on the fused fp32 GEMM (A/B arm); 2: moments in five passes
   plda::DevBuf eer_slab, eer_smp; // plda_score_eer_dev: the row slab of scores in flight; the pilot's gathered enrol rows
   plda::DevBuf eer_list[2];      // eer.hip, single-pass form: the impostor / target scores inside the pilot's key window
@@ -354,6 +354,10 @@ void score_count_set_host(const int32_t *n, int64_t M, CountSet *cs);
 int pairs_validate_device(plda_handle *h, const int64_t *de, const int64_t *dt, int64_t P, int64_t M, int64_t Nt, long long *bad);
 int score_count_set_device(plda_handle *h, const int32_t *dn, int64_t M, CountSet *cs);
 int score_prepare_device(plda_handle *h, const double *dV, int64_t Nt, int kind, int n_uniform, const CountSet *cs);
+// norm()'s model pass: per row x, out_mean = sum_c x_c (m_c - q_c x_c / 2) + *mD, out_std = sqrt(max(x^T C x + lin . x + *crr, 0)); D <= 208
+int quadform_rows_device(plda_handle *h, const double *dX, int64_t R, int D, const double *C, int ldc, const double *lin,
+                         const double *m, const double *q, const double *mD, const double *crr, double *out_mean,
+                         double *out_std, bool *used);
 int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din,
                           const int32_t *dn, int n_uniform, double *dout);
 

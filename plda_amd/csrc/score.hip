@@ -2308,6 +2308,12 @@ __global__ void znorm_models_kernel(const double *__restrict__ V, const double *
   }
 }
 
+// lin = 2 cvr: the covariance column between the cohort's [ca x] and its r (quadform_rows_device's linear term)
+__global__ void znorm_lin_kernel(const double *__restrict__ Cov, int D, double *__restrict__ lin) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < D) lin[d] = 2.0 * Cov[(size_t)d * (D + 1) + D];
+}
+
 // Round 5: the cohort's moments from ONE read of the transformed rows.  A pilot shift p (the mean of [ca x ; r] over the
 // first <= 64 rows: one workgroup, every load in flight at once) keeps the single-pass covariance S2 / N - (S1 / N)(S1 / N)^T free of
 // cancellation (the shifted-data form: exact in exact arithmetic for ANY p, and p is within an eighth of a standard
@@ -2408,6 +2414,15 @@ static int znorm_stats_moments(plda_handle *h, const double *dT, int64_t Nb, con
   }
   {
     TraceScope ts(h, "norm.model_statistics", 2.0 * (double)M * D * D, 1);
+    // D <= 208: on the transform kernel's shape (a workgroup owns 128 models and all D columns; v^T Cvv v, the linear terms and
+    // the mean come out of its epilogue -- no Y, no second kernel).  PLDA_ZNORM_VARIANT=3: the GEMM + row kernel below (A/B arm).
+    if (h->znorm_variant != 3) {
+      double *lin = h->zn_y.as<double>();          // (Y's buffer: D doubles of it)
+      znorm_lin_kernel<<<(unsigned)ceil_div(D, 256), 256, 0, h->stream>>>(Cov, D, lin);
+      bool used = false;
+      PLDA_TRY(quadform_rows_device(h, dmodels, M, D, Cov, D1, lin, mom, coef + 2 * D, mom + D, Cov + (size_t)D * D1 + D, dmean, dstd, &used));
+      if (used) return PLDA_OK;
+    }
     // Y = V Cvv  (Cvv = the leading D x D block of Cov, row stride D + 1)
     PLDA_TRY(gemm_f64(h, M, D, D, 1.0, dmodels, D, 1, Cov, D1, 1, nullptr, 0.0, Y, D));
     znorm_models_kernel<<<(unsigned)ceil_div(M, wpb), wpb * 64, 0, h->stream>>>(dmodels, Y, coef, mom, Cov, D, M, dmean, dstd);

@@ -100,13 +100,19 @@ struct TfGeom {
 // RT (round 4, A/B arm only): row tiles per wave.  With one row tile a wave reads 1 + NT fragments per NT MFMAs (D = 200: 14
 // for 13) -- 67 bytes per clock of LDS fragment traffic per CU beside the stage writes; with RT = 2 and half the columns it
 // reads 2 + NT for 2 NT MFMAs (9 for 14), the same block of 128 rows.  Slower (see transform_class).
-template <int NT, int CH, int KS, bool PERROW, int RT = 1>
+// QF (round 6; norm()'s model pass, MPlda_norm pldamodule.cpp:235-250 by moments): the same product with T := C (a symmetric
+// D x D matrix), but the epilogue keeps TWO numbers per row x instead of the normalised row:
+//     s1 = sum_c x_c (C x + lin)_c = x^T C x + lin . x        s2 = sum_c x_c (m_c - q_c x_c / 2)
+// written as out[row] = s2 + *mD (the model's z-norm mean) and out2[row] = sqrt(max(s1 + *crr, 0)) (its std).  `offset` carries
+// lin, `psi` carries q.  The rows' own values are read back from global memory (L2: the stage loop just streamed them).
+struct TfQuad { const double *m; const double *mD; const double *crr; double *out2; };
+template <int NT, int CH, int KS, bool PERROW, int RT = 1, bool QF = false>
 __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__restrict__ X, int64_t R, int Din,
                                                               const double *__restrict__ Tpad, int Dinp, int Dout,
                                                               const double *__restrict__ offset,
                                                               const double *__restrict__ psi,
                                                               const int32_t *__restrict__ n_arr, int n_uniform,
-                                                              double *__restrict__ out) {
+                                                              double *__restrict__ out, const TfQuad qf = TfQuad{}) {
   using G = TfGeom<NT, CH, KS, RT>;
   constexpr int RG = G::RG, ROWS = G::ROWS, COLS = G::COLS, RPP = G::RPP, TP = G::TP, TR = G::TR, XP = G::XP;
   constexpr int LD = G::LD, STAGE = G::STAGE, KSTEPS = KS / 4;
@@ -223,9 +229,85 @@ __global__ __launch_bounds__(512) void transform_fused_kernel(const double *__re
     for (int c = t; c < COLS; c += 512) {
       eo[c] = c < Dout ? offset[c] : 0.0;
       const double ps = c < Dout ? psi[c] : 1.0;
-      ep[c] = PERROW ? ps : tf_rcp(ps + inv_nu);
+      ep[c] = QF ? (c < Dout ? ps : 0.0) : PERROW ? ps : tf_rcp(ps + inv_nu);
+      if constexpr (QF) red[2 * CH * ROWS + c] = c < Dout ? qf.m[c] : 0.0;
     }
     __syncthreads();
+    if constexpr (QF) {
+      const double *em = red + 2 * CH * ROWS;
+      double p1[4], p2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p1[r] = p2[r] = 0.0;
+      // this lane's four rows of the block, as 32-bit element offsets from the block's first row (clamped to the last row)
+      const double *xb = X + r0 * (int64_t)Din;
+      const int rloc = rg * 16 + fk, rmax = (int)min((int64_t)ROWS - 1, R - 1 - r0);
+      unsigned xo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xo[r] = (unsigned)(min(rloc + 4 * r, rmax) * Din);
+      // The rows' values come back from L2 two tiles (eight loads) at a time: left alone the scheduler hoists all 4 NT loads to
+      // the top and the kernel spills 181 registers beside its NT accumulator tiles (a "memory" clobber does not hold back loads
+      // through a const __restrict__ pointer).  `bump` is always 0, but only the empty asm that follows a tile pair's FMAs
+      // knows: the next pair's addresses wait for it.
+      unsigned bump = 0;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int col = (ch * NT + tn) * 16 + fi;
+        const bool cok = col < Dout && col < Din;
+        const unsigned cc = (unsigned)min(col, Din - 1) + bump;
+        const double off = eo[col], q = ep[col], m = em[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double xv = cok ? xb[xo[r] + cc] : 0.0;
+          p1[r] = fma(xv, acc[0][tn][r] + off, p1[r]);
+          p2[r] = fma(xv, fma(-0.5 * q, xv, m), p2[r]);
+        }
+        if ((tn & 1) == 1) asm volatile("" : "+v"(bump), "+v"(p1[0]), "+v"(p1[1]), "+v"(p1[2]), "+v"(p1[3]));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double a = p1[r], b = p2[r];
+        a += dpp_f64<0xB1>(a); b += dpp_f64<0xB1>(b);
+        a += dpp_f64<0x4E>(a); b += dpp_f64<0x4E>(b);
+        a += dpp_f64<0x141>(a); b += dpp_f64<0x141>(b);
+        a += dpp_f64<0x140>(a); b += dpp_f64<0x140>(b);
+        p1[r] = a; p2[r] = b;
+      }
+      if (CH > 1) {
+        if (fi == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            red[ch * ROWS + rloc + 4 * r] = p1[r];
+            red[(CH + ch) * ROWS + rloc + 4 * r] = p2[r];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double a = 0.0, b = 0.0;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) { a += red[c * ROWS + rloc + 4 * r]; b += red[(CH + c) * ROWS + rloc + 4 * r]; }
+          p1[r] = a; p2[r] = b;
+        }
+      }
+      if (fi == 0 && ch == 0) {
+        const double mD = *qf.mD, crr = *qf.crr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t g = r0 + rloc + 4 * r;
+          if (g < R) {
+            const double var = p1[r] + crr;
+            out[g] = p2[r] + mD;
+            qf.out2[g] = sqrt(var > 0.0 ? var : 0.0);
+          }
+        }
+      }
+      if (!has_next) break;
+      stage(tf_lds + cur * STAGE, 0);
+      if (early && Din > KS) fetch(KS, 4);
+      __syncthreads();
+      blk = nblk;
+      continue;
+    }
     // accumulator layout: column = lane & 15 of the tile, row = (lane >> 4) + 4 * reg of the row tile
     double part[RT][4];
     int64_t grow[RT][4];
@@ -943,6 +1025,14 @@ __global__ void pad_transform_kernel(const double *__restrict__ T, int Dout, int
   Tpad[idx] = (r < Dout && c < Din) ? T[(int64_t)r * Din + c] : 0.0;
 }
 
+__global__ void pad_matrix_kernel(const double *__restrict__ A, int lda, int rows_in, int cols_in, double *__restrict__ P, int rows,
+                                  int Dinp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * Dinp) return;
+  const int r = idx / Dinp, c = idx % Dinp;
+  P[idx] = (r < rows_in && c < cols_in) ? A[(int64_t)r * lda + c] : 0.0;
+}
+
 template <int NT, int CH, int KS, bool PERROW, int RT = 1>
 static int launch_transform_fused_t(plda_handle *h, const double *dX, int64_t R, int Din, const int32_t *dn,
                                     int n_uniform, double *dout, int Dinp) {
@@ -997,6 +1087,25 @@ static int launch_transform_fused(plda_handle *h, const double *dX, int64_t R, i
               : launch_transform_dma_t<NT, CH, false>(h, dX, R, Din, dn, n_uniform, dout, Dinp, h->tf_pad_rows);
   return dn ? launch_transform_fused_t<NT, CH, KS, true>(h, dX, R, Din, dn, n_uniform, dout, Dinp)
             : launch_transform_fused_t<NT, CH, KS, false>(h, dX, R, Din, dn, n_uniform, dout, Dinp);
+}
+
+// QF launches (quadform_rows_device below): own padded matrix, uniform epilogue shape, RT = 1
+template <int NT, int CH, int KS>
+static int launch_quadform_t(plda_handle *h, const double *dX, int64_t R, int D, const double *Cpad, int Dinp, const double *lin,
+                             const double *q, const TfQuad &qf, double *out) {
+  using G = TfGeom<NT, CH, KS, 1>;
+  static_assert(G::LDS_BYTES <= 160 * 1024, "stage buffers exceed the LDS of a CU");
+  static_assert((size_t)(3 * G::COLS + 2 * CH * G::ROWS) * 8 <= G::LDS_BYTES / 2, "the epilogue's scratch must fit one stage buffer");
+  static DeviceOnce attr;
+  if (attr.needed(h->device)) {
+    PLDA_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&transform_fused_kernel<NT, CH, KS, false, 1, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+    attr.done(h->device);
+  }
+  transform_fused_kernel<NT, CH, KS, false, 1, true><<<(unsigned)std::min<int64_t>(ceil_div(R, (int64_t)G::ROWS), h->num_cus), 512,
+                                                      G::LDS_BYTES, h->stream>>>(dX, R, D, Cpad, Dinp, D, lin, q, nullptr, 1, out, qf);
+  PLDA_LAUNCH_CHECK(h);
+  return PLDA_OK;
 }
 
 template <int A, int B> constexpr int cmax() { return A > B ? A : B; }
@@ -1095,6 +1204,51 @@ int transform_rows_device(plda_handle *h, const double *dX, int64_t R, int Din, 
       dout, R, h->Dout, h->d_offset.as<double>(), h->d_psi.as<double>(), dn, n_uniform);
   PLDA_LAUNCH_CHECK(h);
   return PLDA_OK;
+}
+
+// norm()'s model pass on K4's kernel shape (round 6): for every row x of dX [R, D]
+//     out_mean = sum_c x_c (m_c - q_c x_c / 2) + *mD,      out_std = sqrt(max(x^T C x + lin . x + *crr, 0))
+// C [D, D] symmetric with leading dimension ldc.  D <= 208 (*used = false otherwise: the caller keeps its GEMM).  The general
+// GEMM + row kernel this replaces ran the 50k x 200 x 200 product of C5 at 0.25 of the fp64 MFMA peak.
+int quadform_rows_device(plda_handle *h, const double *dX, int64_t R, int D, const double *C, int ldc, const double *lin,
+                         const double *m, const double *q, const double *mD, const double *crr, double *out_mean,
+                         double *out_std, bool *used) {
+  *used = false;
+  if (D > 208 || R <= 0) return PLDA_OK;
+  constexpr int KS = 16;
+  const int Dinp = (int)round_up(D, KS);
+  // rows of the padded matrix: the largest stage of the shapes below (the main shape's)
+  const int padrows = D <= 128 ? cmax<TfGeom<8, 1, KS>::TR, cmax<TfGeom<4, 2, KS>::TR, cmax<TfGeom<2, 4, KS>::TR, TfGeom<1, 8, KS>::TR>()>()>()
+                               : cmax<TfGeom<13, 1, KS>::TR, cmax<TfGeom<7, 2, KS>::TR, cmax<TfGeom<4, 4, KS>::TR, TfGeom<2, 8, KS>::TR>()>()>();
+  PLDA_HIP(h, h->zn_cpad.reserve((size_t)padrows * Dinp * 8));
+  double *Cpad = h->zn_cpad.as<double>();
+  pad_matrix_kernel<<<(unsigned)ceil_div((int64_t)padrows * Dinp, 256), 256, 0, h->stream>>>(C, ldc, D, D, Cpad, padrows, Dinp);
+  PLDA_LAUNCH_CHECK(h);
+  const TfQuad qf{m, mD, crr, out_std};
+  const int64_t G = h->num_cus;
+  const int64_t nb = ceil_div(R, (int64_t)128);
+  const int64_t rows_main = std::min(R, nb / G * G * 128);
+  const bool small = D <= 128;
+  if (rows_main > 0)
+    PLDA_TRY(small ? (launch_quadform_t<8, 1, KS>(h, dX, rows_main, D, Cpad, Dinp, lin, q, qf, out_mean))
+                   : (launch_quadform_t<13, 1, KS>(h, dX, rows_main, D, Cpad, Dinp, lin, q, qf, out_mean)));
+  const int64_t Rt = R - rows_main;
+  *used = true;
+  if (Rt <= 0) return PLDA_OK;
+  const double *tX = dX + rows_main * D;
+  const TfQuad qt{m, mD, crr, out_std + rows_main};
+  double *to = out_mean + rows_main;
+  const int64_t per_cu = ceil_div(Rt, G);
+  if (small) {
+    if (per_cu <= 16) return launch_quadform_t<1, 8, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+    if (per_cu <= 32) return launch_quadform_t<2, 4, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+    if (per_cu <= 64) return launch_quadform_t<4, 2, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+    return launch_quadform_t<8, 1, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+  }
+  if (per_cu <= 16) return launch_quadform_t<2, 8, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+  if (per_cu <= 32) return launch_quadform_t<4, 4, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+  if (per_cu <= 64) return launch_quadform_t<7, 2, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
+  return launch_quadform_t<13, 1, KS>(h, tX, Rt, D, Cpad, Dinp, lin, q, qt, to);
 }
 
 }  // namespace plda

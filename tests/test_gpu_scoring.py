@@ -198,7 +198,7 @@ def test_sharded_scorer_on_device_tensors(engine, oracle):
 
 @pytest.mark.parametrize("d,nb,nmodels", [(48, 391, 40), (200, 1000, 64), (206, 650, 4), (207, 600, 5), (208, 700, 3), (230, 520, 7), (10, 2, 4),
                                           (33, 1, 6), (64, 70, 9), (256, 2300, 6)])
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant):
     """MPlda_norm (pldamodule.cpp:196-256).  Arm 0 (default): statistics from the cohort's fp64 moments -- the LLR is
     bilinear in (cohort row, model) plus a bias on each side -- taken in ONE read of the transformed cohort (round 5:
@@ -207,7 +207,8 @@ def test_znorm_statistics_both_arms(oracle, monkeypatch, d, nb, nmodels, variant
     loop; arm 1: every LLR on the fp32 GEMM with the fused sum / sum-of-squares epilogue, held to the 1e-4 of
     north_star.  Shapes straddle the one-read kernel's limit (D + 2 = 208 | 209: beyond it arm 0 writes the shifted rows
     once and the block SYRK reads them once; 256 x 2300 reaches that SYRK), the older (D + 1)-wide SYRK's kernel choice, a cohort of 70 rows (the pilot takes 64) and the degenerate cohorts of one and two rows (std = 0 exactly
-    for one row, as the reference's population std)."""
+    for one row, as the reference's population std).  Arm 3: arm 0 with the model pass as a general GEMM + row kernel (rounds
+    2-5) instead of the transform kernel's shape with the quadratic form in its epilogue (round 6; D <= 208)."""
     monkeypatch.setenv("PLDA_ZNORM_VARIANT", variant)
     from plda_amd import MPlda
     m, x, y = _model(oracle, 16, 1500, d, 30, scale_between=0.5)
@@ -600,3 +601,25 @@ def test_znorm_error_bound_when_the_cohort_spread_is_small(oracle, nt):
     k_in = min(inside.shape[0], nt)
     assert np.abs(ref[:, :k_in]).max() < 10.0 and np.abs(raw).max() > 10.0
     print("znorm bound: max err %.3g, max err/bound %.3g, zstd min %.3g, |raw| max %.3g" % (err.max(), (err / bound).max(), rs.min(), np.abs(raw).max()))
+
+
+@pytest.mark.parametrize("d,nmodels", [(64, 40000), (128, 33100), (200, 36000)])
+def test_znorm_model_pass_main_block_shapes(oracle, d, nmodels):
+    """norm()'s model pass (round 6: x^T C x + lin . x and the mean from the transform kernel's epilogue) with enough models for
+    its persistent main launch (128-row blocks on every CU: 8 column tiles per wave up to D = 128, 13 up to 208) AND a tail
+    launch; every model against the oracle's explicit per-pair loop over a small cohort."""
+    from plda_amd import MPlda
+    m, x, y = _model(oracle, 31, 1200, d, 30, scale_between=0.5)
+    eng = MPlda(0)
+    _load(eng, m)
+    rng = np.random.default_rng(d)
+    bkg = rng.random((90, d))
+    base = np.stack([oracle.transform_ivector(m, r, 1) for r in rng.random((500, d)) + 0.1])
+    models = base[rng.integers(0, 500, nmodels)] * (1.0 + 0.05 * rng.standard_normal((nmodels, 1)))
+    rm, rs = oracle.norm(m, bkg, models)
+    eng.norm(bkg, {int(k): (1, models[k]) for k in range(nmodels)})
+    dm, ds = eng.znorm_stats()
+    zm = np.array([dm[k] for k in range(nmodels)]); zs = np.array([ds[k] for k in range(nmodels)])
+    scale = np.maximum(np.abs(rm), np.abs(rm).mean())
+    assert (np.abs(zm - rm) <= 1e-10 * scale).all(), (np.abs(zm - rm) / scale).max()
+    assert (np.abs(zs - rs) <= 1e-10 * np.maximum(rs, 1e-3 * scale)).all(), (np.abs(zs - rs) / rs).max()
