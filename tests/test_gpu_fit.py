@@ -30,11 +30,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", ["0", "4"])      # the EM form the shape picks | the row form always (tiny D, one-row tiles)
 @pytest.mark.parametrize("seed,n,d,k,skew,between", CASES)
-def test_fit_matches_oracle(oracle, seed, n, d, k, skew, between):
+def test_fit_matches_oracle(oracle, monkeypatch, seed, n, d, k, skew, between, form):
     from plda_amd import MPlda
     x, y = make_data(seed, n, d, k, skew=skew, scale_between=between)
+    monkeypatch.setenv("PLDA_EM_VARIANT", form)
     eng = MPlda(0)
+    monkeypatch.delenv("PLDA_EM_VARIANT")
     assert eng.fit(x, y, 10) is None
     ref = oracle.fit(x, y, 10)
     st = oracle.stats(x, y)
@@ -520,3 +523,35 @@ def test_em_form_follows_the_shape_and_the_forms_agree(oracle, monkeypatch):
     eng = MPlda(0)
     eng.fit(rng.random((4000, D)), y2, 2)
     assert eng.fit_plan() == dict(groups=1, form="moments")
+
+
+def test_row_form_with_one_class_per_group(oracle):
+    """Every speaker has a different utterance count (G = K groups of ONE class: one-row tiles, as many whitenings as
+    speakers), and a single group next to many (a group of one beside a group of hundreds)."""
+    from plda_amd import MPlda
+    rng = np.random.default_rng(3)
+    K, D = 40, 24
+    nk = np.arange(2, 2 + K)
+    y = np.repeat(np.arange(K), nk).astype(np.uint64)
+    x = rng.random((y.shape[0], D)) + 0.3 * rng.standard_normal((K, D))[y.astype(np.int64)]
+    eng = MPlda(0)
+    eng.fit(x, y, 6)
+    assert eng.fit_plan() == dict(groups=K, form="rows")
+    ref = oracle.fit(x, y, 6)
+    it = eng.fit_internals()
+    assert _rel(it["W"], ref["W"]) < 1e-10 and _rel(it["B"], ref["B"]) < 1e-10
+    nk2 = np.concatenate([np.full(300, 4), [9, 10, 11, 12]])
+    y2 = np.repeat(np.arange(nk2.shape[0]), nk2).astype(np.uint64)
+    x2 = rng.random((y2.shape[0], D)) + 0.3 * rng.standard_normal((nk2.shape[0], D))[y2.astype(np.int64)]
+    for form, monkey in (("rows", "4"), ("moments", "3")):
+        import os
+        os.environ["PLDA_EM_VARIANT"] = monkey
+        try:
+            e2 = MPlda(0)
+        finally:
+            del os.environ["PLDA_EM_VARIANT"]
+        e2.fit(x2, y2, 6)
+        assert e2.fit_plan() == dict(groups=5, form=form)
+        r2 = oracle.fit(x2, y2, 6)
+        i2 = e2.fit_internals()
+        assert _rel(i2["W"], r2["W"]) < 1e-10 and _rel(i2["B"], r2["B"]) < 1e-10
