@@ -362,6 +362,8 @@ __global__ void em_row_weights_kernel(const double *__restrict__ gn, const doubl
 //  * Software pipelining across trips did not survive the compiler (round 6; rotating fragment sets by moves, by renamed slots, by
 //    fixed slots between scheduling barriers, and a compile-time recursion over the rounds): the register allocator copies the sets
 //    at the loop's back edge and a copy waits for the load it copies, or the recursion spills.  All four measured slower than this.
+//  * More fragments per trip do not help either (7 chunks = 28 loads in flight, two trips per block at D = 200 instead of four:
+//    em_xtb_kernel 22.2 us and em_rows_kernel 33.3 us, unchanged): the trips' round trips are already covered.
 //  * bload must be BRANCH-FREE (clamped addresses): a guard per load puts every load under its own exec branch with a vmcnt(0)
 //    behind it.  What a clamped load brings in beyond the operands' extent meets zeros of the LDS tile.
 template <int RB, typename BL>
