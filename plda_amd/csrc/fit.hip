@@ -364,10 +364,15 @@ __global__ void em_row_weights_kernel(const double *__restrict__ gn, const doubl
 //    at the loop's back edge and a copy waits for the load it copies, or the recursion spills.  All four measured slower than this.
 //  * More fragments per trip do not help either (7 chunks = 28 loads in flight, two trips per block at D = 200 instead of four:
 //    em_xtb_kernel 22.2 us and em_rows_kernel 33.3 us, unchanged): the trips' round trips are already covered.
-//  * bload must be BRANCH-FREE (clamped addresses): a guard per load puts every load under its own exec branch with a vmcnt(0)
-//    behind it.  What a clamped load brings in beyond the operands' extent meets zeros of the LDS tile.
-template <int RB, typename BL>
-__device__ __forceinline__ void em_block_product(const double *a, int ld, int nch, BL bload, f64x4_fit (&out)[RB]) {
+//  * the loads must be BRANCH-FREE: a guard per load puts every load under its own exec branch with a vmcnt(0) behind it.
+typedef unsigned u32x2_fit __attribute__((ext_vector_type(2)));
+// (right operand: `rs` = a buffer resource over ONE D x D matrix, `voff` = this lane's byte offset (k offset fk, its column; a lane
+//  whose column does not exist carries an offset past the matrix), rowbytes = 8 D.  The k of a fragment rides on the SCALAR offset:
+//  no vector arithmetic per load -- as pointer arithmetic (64-bit multiply, clamp, add per load) the two kernels executed 6.7
+//  vector instructions per MFMA (PMC, round 6) -- and what lies past the matrix reads as zero.)
+template <int RB>
+__device__ __forceinline__ void em_block_product(const double *a, int ld, int nch, const __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                                 int rowbytes, f64x4_fit (&out)[RB]) {
   f64x4_fit acc[RB][2];
 #pragma unroll
   for (int b = 0; b < RB; ++b) acc[b][0] = acc[b][1] = f64x4_fit{0.0, 0.0, 0.0, 0.0};
@@ -375,9 +380,12 @@ __device__ __forceinline__ void em_block_product(const double *a, int ld, int nc
   for (int c = 0; c < nch; c += 4) {
     double q[4][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 4; ++p) {
+      const int k0 = min(16 * (c + p), last);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[p][u] = bload(min(16 * (c + p), last) + 4 * u);
+      for (int u = 0; u < 4; ++u)
+        q[p][u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (k0 + 4 * u) * rowbytes, 0));
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       if (c + p < nch) {
@@ -399,30 +407,37 @@ __device__ __forceinline__ void em_block_product(const double *a, int ld, int nc
 // pieces per load and the whole k extent: 34 us for 36 groups at D = 200.  D <= 512.
 template <int RB>
 __global__ __launch_bounds__(1024) void em_xtb_kernel(const double *__restrict__ T, const double *__restrict__ B, int D,
-                                                      double *__restrict__ X, double *__restrict__ TT) {
+                                                      double *__restrict__ X, double *__restrict__ TT, int split) {
   extern __shared__ __attribute__((aligned(16))) double em_xtb_lds[];
-  const int NT = (D + 15) >> 4, ld = 16 * NT + 4;
-  const int i = NT - 1 - RB * (int)blockIdx.x, g = blockIdx.y, kext = 16 * (i + 1);
+  const int NT = (D + 15) >> 4, ld = 16 * NT + 2;
+  // split == 2: blockIdx.x = 2 tile + half, the column blocks of a row tile are shared by TWO workgroups (the longest tile's 13
+  // blocks on one workgroup's four SIMDs are 4 + 3 + 3 + 3: its 11 us set the kernel's time when few groups leave CUs idle)
+  // (split = 2 when the whole launch is at most ~1.5 workgroups per CU -- 12 groups at D = 200: 20 -> 14 us; with more groups
+  //  the chip is full anyway and the second staging of the tile costs more than the balance gains: 36 groups 22 -> 24 us)
+  const int half = split == 2 ? (int)(blockIdx.x & 1) : 0, tile = split == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  const int jlo = half ? (NT + 1) / 2 : 0, jhi = split == 2 && !half ? (NT + 1) / 2 : NT;
+  const int i = NT - 1 - RB * tile, g = blockIdx.y, kext = 16 * (i + 1);
   const int m0 = 16 * (i - (RB - 1));              // (may be negative for the last workgroup of a group: those rows are skipped)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
   const double *__restrict__ Tg = T + (int64_t)g * D * D;
   double *__restrict__ Xg = X + (int64_t)g * D * D, *__restrict__ TTg = TT + (int64_t)g * D * D;
   double *Ts = em_xtb_lds;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(B), 0, D * D * 8, 0x00020000);
   for (int idx = t; idx < 16 * RB * kext; idx += 1024) {
     const int r = idx / kext, c = idx - r * kext, row = m0 + r;
     Ts[r * ld + c] = (row >= 0 && row < D && c < D) ? Tg[(int64_t)row * D + c] : 0.0;
   }
   __syncthreads();
-  for (int idx = t; idx < 16 * RB * kext; idx += 1024) {
-    const int r = idx & (16 * RB - 1), c = idx / (16 * RB), row = m0 + r;
-    if (row >= 0 && row < D && c < D) TTg[(int64_t)c * D + row] = Ts[r * ld + c];
-  }
-  for (int j = wave; j < NT; j += 16) {
+  if (half == 0)
+    for (int idx = t; idx < 16 * RB * kext; idx += 1024) {
+      const int r = idx & (16 * RB - 1), c = idx / (16 * RB), row = m0 + r;
+      if (row >= 0 && row < D && c < D) TTg[(int64_t)c * D + row] = Ts[r * ld + c];
+    }
+  for (int j = jlo + wave; j < jhi; j += 16) {
     const int col = 16 * j + fi;
     const bool okc = col < D;
-    const double *__restrict__ bcol = B + (okc ? col : D - 1);
     f64x4_fit x[RB];
-    em_block_product<RB>(Ts + fi * ld + fk, ld, i + 1, [&](int k) { return bcol[(int64_t)min(k + fk, D - 1) * D]; }, x);
+    em_block_product<RB>(Ts + fi * ld + fk, ld, i + 1, rsB, okc ? (unsigned)(fk * D + col) * 8u : 0x7fffff00u, D * 8, x);
 #pragma unroll
     for (int b = 0; b < RB; ++b)
 #pragma unroll
@@ -437,21 +452,23 @@ __global__ __launch_bounds__(1024) void em_xtb_kernel(const double *__restrict__
 //   V = M T_g^T  (T_g lower triangular: column block j needs k < 16 (j + 1); read from the TRANSPOSED copy em_xtb_kernel leaves,
 //                 so that a fragment is four 128-byte rows like X_g's and not sixteen 32-byte pieces)          ->  LDS
 //   Y = V X_g,   Z = M - n_g Y,   Wn = sqrt(n_g) Y                                                          ->  global
-// Sixteen waves, a column block each in both phases.  LDS: two [16 RB][16 NT + 4] tiles (the +4 doubles spread the 16 rows of a
-// fragment read over all banks): RB = 2 for D <= 256, RB = 1 up to D = 512.
+// Sixteen waves, a column block each in both phases.  LDS: two [16 RB][16 NT + 2] tiles (pitch = 2 mod 4 doubles: a fragment read -- 16 rows x
+// 2 k per 32-lane group of a ds_read_b64 -- then covers all 64 banks once; with + 4 the rows 8 apart shared banks and 72 % of the
+// kernel's LDS cycles were conflicts, PMC round 6): RB = 2 for D <= 256, RB = 1 up to D = 512.
 template <int RB>
 __global__ __launch_bounds__(1024) void em_rows_kernel(const double *__restrict__ Mg, const int4 *__restrict__ tiles,
                                                        const double *__restrict__ T /*transposed: [k][j]*/, const double *__restrict__ X,
                                                        const double *__restrict__ gn, int D, double *__restrict__ Z,
                                                        double *__restrict__ Wn) {
   extern __shared__ __attribute__((aligned(16))) double em_rows_lds[];
-  const int NT = (D + 15) >> 4, ld = 16 * NT + 4;
+  const int NT = (D + 15) >> 4, ld = 16 * NT + 2;
   double *Ms = em_rows_lds, *Vs = Ms + 16 * RB * ld;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
   const int4 tile = tiles[blockIdx.x];
   const int row0 = tile.x, nrows = tile.y, g = tile.z;
   const double n = gn[g];
-  const double *__restrict__ Tg = T + (int64_t)g * D * D, *__restrict__ Xg = X + (int64_t)g * D * D;
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(T + (int64_t)g * D * D), 0, D * D * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(X + (int64_t)g * D * D), 0, D * D * 8, 0x00020000);
   for (int idx = t; idx < 16 * RB * 16 * NT; idx += 1024) {
     const int r = idx / (16 * NT), c = idx - r * 16 * NT;
     Ms[r * ld + c] = (r < nrows && c < D) ? Mg[(int64_t)(row0 + r) * D + c] : 0.0;
@@ -460,9 +477,8 @@ __global__ __launch_bounds__(1024) void em_rows_kernel(const double *__restrict_
   for (int j = NT - 1 - wave; j >= 0; j -= 16) {       // (the long blocks on the low waves)
     const int col = 16 * j + fi;
     const bool okc = col < D;
-    const double *__restrict__ tcol = Tg + (okc ? col : D - 1);
     f64x4_fit v[RB];
-    em_block_product<RB>(Ms + fi * ld + fk, ld, j + 1, [&](int k) { return tcol[(int64_t)min(k + fk, D - 1) * D]; }, v);
+    em_block_product<RB>(Ms + fi * ld + fk, ld, j + 1, rsT, okc ? (unsigned)(fk * D + col) * 8u : 0x7fffff00u, D * 8, v);
 #pragma unroll
     for (int b = 0; b < RB; ++b)
 #pragma unroll
@@ -473,9 +489,8 @@ __global__ __launch_bounds__(1024) void em_rows_kernel(const double *__restrict_
   for (int j = wave; j < NT; j += 16) {
     const int col = 16 * j + fi;
     const bool okc = col < D;
-    const double *__restrict__ xcol = Xg + (okc ? col : D - 1);
     f64x4_fit y[RB];
-    em_block_product<RB>(Vs + fi * ld + fk, ld, NT, [&](int k) { return xcol[(int64_t)min(k + fk, D - 1) * D]; }, y);
+    em_block_product<RB>(Vs + fi * ld + fk, ld, NT, rsX, okc ? (unsigned)(fk * D + col) * 8u : 0x7fffff00u, D * 8, y);
 #pragma unroll
     for (int b = 0; b < RB; ++b)
 #pragma unroll
@@ -997,7 +1012,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     em_row_weights_kernel<<<(unsigned)ceil_div(GD, 256), 256, 0, h->stream>>>(dgn, dgk, D, GD, kw1, kw2);
     PLDA_LAUNCH_CHECK(h);
     const int NT = (int)ceil_div(D, 16);
-    const size_t rows_lds = (size_t)2 * 16 * RB * (16 * NT + 4) * 8, xtb_lds = (size_t)16 * RB * (16 * NT + 4) * 8;
+    const size_t rows_lds = (size_t)2 * 16 * RB * (16 * NT + 2) * 8, xtb_lds = (size_t)16 * RB * (16 * NT + 2) * 8;
     double *TTg = scr;                    // T_g^T (D <= 512; the blocked whitening's scratch is dead by then)
     if (D <= 512) {
       static DeviceOnce attr;
@@ -1018,11 +1033,12 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       else PLDA_TRY(whiten_groups_f64(h, W, B, dgn, D, Tg, scr, dflag, G));
       PLDA_LAUNCH_CHECK(h);
       if (D <= 512) {
+        const int xsplit = 2 * (int)ceil_div(NT, RB) * G <= h->num_cus * 3 / 2 ? 2 : 1;
         if (RB == 2) {
-          em_xtb_kernel<2><<<dim3((unsigned)ceil_div(NT, 2), (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg);
+          em_xtb_kernel<2><<<dim3(xsplit * (unsigned)ceil_div(NT, 2), (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg, xsplit);
           em_rows_kernel<2><<<(unsigned)ntiles, 1024, rows_lds, h->stream>>>(Mg, dtiles, TTg, Xg, dgn, D, Zr, Wn);
         } else {
-          em_xtb_kernel<1><<<dim3((unsigned)NT, (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg);
+          em_xtb_kernel<1><<<dim3(xsplit * (unsigned)NT, (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg, xsplit);
           em_rows_kernel<1><<<(unsigned)ntiles, 1024, rows_lds, h->stream>>>(Mg, dtiles, TTg, Xg, dgn, D, Zr, Wn);
         }
         PLDA_LAUNCH_CHECK(h);
