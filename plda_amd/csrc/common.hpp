@@ -291,15 +291,15 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
              const double *kw, double beta, double *C, int64_t ldc);
 // in-place lower Cholesky (upper triangle zeroed); *dflag (device int) set to 1 on failure
 // X = L^{-1} for lower-triangular L (row-major); X written fully (upper = 0)
-int gemm_f64_pair(plda_handle *h, int64_t M, int64_t N, int64_t K, const double *A0, int64_t sam0, int64_t sak0,
-                  int64_t strideA0, const double *B0, int64_t sbk0, int64_t sbn0, int64_t strideB0, double *C0,
-                  int64_t ldc0, int64_t strideC0, const double *A1, int64_t sam1, int64_t sak1, int64_t strideA1,
-                  const double *B1, int64_t sbk1, int64_t sbn1, int64_t strideB1, double *C1, int64_t ldc1,
-                  int64_t strideC1, int batch);
+// up to three independent batched products C = A B of one shape in one launch (M, N, K <= 256), else sequentially
+struct GemmSet {
+  const double *A; int64_t sam, sak, strideA;
+  const double *B; int64_t sbk, sbn, strideB;
+  double *C; int64_t ldc, strideC;
+};
+int gemm_f64_multi(plda_handle *h, int64_t M, int64_t N, int64_t K, const GemmSet *sets, int nsets, int batch);
 int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
                     int *dflag, int batch);
-int spd_inverse_via_whitening_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T,
-                                  double *out, int *dflag, int batch);
 // T_g = chol(W + gn[g] B)^-1 (lower triangular) for g < batch; scr: 3 D^2 doubles per group
 int whiten_groups_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T, double *scr,
                       int *dflag, int batch);

@@ -273,51 +273,42 @@ __global__ void gather_center_kernel(const double *__restrict__ means, const dou
   out[idx] = means[(int64_t)cls[r] * D + d] - mu[d];
 }
 
-// A_g = W + n_g B (and, for the refinement step of Q, a copy of B per group)
-__global__ void em_group_A_kernel(const double *__restrict__ W, const double *__restrict__ B,
-                                  const double *__restrict__ gn, int64_t DD, double *__restrict__ A,
-                                  double *__restrict__ Bcopy) {
-  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (idx >= DD) return;
-  const double b = B[idx];
-  A[(int64_t)blockIdx.y * DD + idx] = fma(gn[blockIdx.y], b, W[idx]);
-  if (Bcopy) Bcopy[(int64_t)blockIdx.y * DD + idx] = b;
-}
-
-// M-step from the per-group matrices (i <= j computes both (i,j) and (j,i), then symmetrises):
-//   W_stats = S + sum_g [ K_g Mx_g + C_g - n_g (QC_g + QC_g^T) + n_g^2 QCQ_g ]
-//   B_stats =     sum_g [ (K_g / n_g) Mx_g + n_g QCQ_g ]
-// next: the buffers of Mx and QCQ are free once this thread has read its two entries of them, and the next iteration
-// wants A_g = W + n_g B and a copy of B in exactly these buffers (the residual of its refinement step): written here
-// instead of by a launch of em_group_A_kernel.
-__global__ void em_group_mstep_kernel(const double *__restrict__ S, const double *__restrict__ Csum, double *Mx,
-                                      const double *__restrict__ QC, double *QCQ, const double *__restrict__ gn,
-                                      const double *__restrict__ gk, int G, int D, double cntW, double cntB,
-                                      double *__restrict__ W, double *__restrict__ B, bool next) {
+// Grouped EM, MOMENT form (few groups of many classes; fit_em_device chooses).  Inside a group every class shares A_g = W + n_g B;
+// with T_g its whitening factor (T_g A_g T_g^T = I, A_g^-1 = T_g^T T_g), X_g = T_g B and the group's second moments
+// C_g = sum_k m_k m_k^T (computed once):
+//   Q_g = B A_g^-1 = X_g^T T_g,   Q_g C_g = X_g^T (T_g C_g),   Q_g C_g Q_g^T = X_g^T (T_g C_g T_g^T) X_g,   Mx_g = B - n_g X_g^T X_g
+//   W_stats = S + sum_g [ K_g Mx_g + C_g - n_g (QC_g + QC_g^T) + n_g^2 QCQ_g ],     B_stats = sum_g [ (K_g / n_g) Mx_g + n_g QCQ_g ]
+// Seven D^3 products per group in FOUR dependent launches (X | T C  ->  X^T(T C) | (T C) T^T | X^T X  ->  (T C T^T) X  ->  X^T (..)),
+// nothing K-sized.  Round 6: every product is a T-form -- Q_g is never formed, nothing is multiplied by an explicit A_g^-1 -- so
+// the error is sqrt(cond(A_g)) eps, not cond(A_g) eps, and the refinement step of rounds 3-5 (Q += (B - Q A) A^-1: two more
+// dependent launches, and a third for T^T T) is gone: 8 launches -> 6 per iteration, 106 -> ~95 us at D = 200, G = 1.  Against
+// the x87 EM (N = 149, D = 200, cond(W) = 3e8) W 1.4e-14, B 2.5e-13 (with the refinement step: 3e-14, 2e-13; the reference's
+// own formulation 4e-12, 6e-9).
+// i <= j computes both (i, j) and (j, i), then symmetrises like Kaldi's CopyToSp.
+__global__ void em_moment_mstep_kernel(const double *__restrict__ S, const double *__restrict__ Csum, const double *__restrict__ XtX,
+                                       const double *__restrict__ QC, const double *__restrict__ QCQ, const double *__restrict__ gn,
+                                       const double *__restrict__ gk, int G, int D, double sumK, double cw, double cntW, double cntB,
+                                       double *__restrict__ W, double *__restrict__ B) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D * D) return;
   const int i = idx / D, j = idx % D;
   if (i > j) return;
   const size_t ij = (size_t)i * D + j, ji = (size_t)j * D + i, DD = (size_t)D * D;
-  double wij = S[ij] + Csum[ij], wji = S[ji] + Csum[ji], bij = 0.0, bji = 0.0;
+  const double b_ij = B[ij], b_ji = B[ji];
+  double wij = S[ij] + fma(sumK, b_ij, Csum[ij]), wji = S[ji] + fma(sumK, b_ji, Csum[ji]);
+  double bij = cw * b_ij, bji = cw * b_ji;
   for (int g = 0; g < G; ++g) {
     const double n = gn[g], k = gk[g];
-    const double *mx = Mx + g * DD, *qc = QC + g * DD, *qcq = QCQ + g * DD;
+    const double *xx = XtX + g * DD, *qc = QC + g * DD, *qcq = QCQ + g * DD;
     const double cross = n * (qc[ij] + qc[ji]);
-    wij += k * mx[ij] - cross + n * n * qcq[ij];
-    wji += k * mx[ji] - cross + n * n * qcq[ji];
-    bij += (k / n) * mx[ij] + n * qcq[ij];
-    bji += (k / n) * mx[ji] + n * qcq[ji];
+    wij += -k * n * xx[ij] - cross + n * n * qcq[ij];
+    wji += -k * n * xx[ji] - cross + n * n * qcq[ji];
+    bij += -k * xx[ij] + n * qcq[ij];
+    bji += -k * xx[ji] + n * qcq[ji];
   }
   const double w = 0.5 * (wij / cntW + wji / cntW), b = 0.5 * (bij / cntB + bji / cntB);
   W[ij] = w; W[ji] = w;
   B[ij] = b; B[ji] = b;
-  if (next)
-    for (int g = 0; g < G; ++g) {
-      const double a = fma(gn[g], b, w);
-      Mx[g * DD + ij] = a; Mx[g * DD + ji] = a;
-      QCQ[g * DD + ij] = b; QCQ[g * DD + ji] = b;
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -536,15 +527,6 @@ __global__ void em_rows_mstep_kernel(const double *__restrict__ S, const double 
 __global__ void set_identity2_kernel(double *W, double *B, int D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < D * D) { const double v = (idx / D == idx % D) ? 1.0 : 0.0; W[idx] = v; B[idx] = v; }
-}
-
-// (W + n_g B)^-1 of the EM's FIRST iteration: W = B = I there (Kaldi's PldaEstimator starts from unit covariances,
-// set_identity2_kernel above), so the inverse is I / (1 + n_g) -- a 70 us factorisation of a multiple of the identity
-// otherwise.  grid (ceil(D^2 / 256), groups)
-__global__ void em_first_inverse_kernel(const double *__restrict__ gn, int D, int64_t stride, double *__restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= D * D) return;
-  out[(int64_t)blockIdx.y * stride + idx] = (idx / D == idx % D) ? 1.0 / (1.0 + gn[blockIdx.y]) : 0.0;
 }
 
 // offset = -T mean (Plda::ComputeDerivedVars), one wave per output row
@@ -977,7 +959,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
   const unsigned gKD = (unsigned)ceil_div(K * (int64_t)D, 256);
   set_identity2_kernel<<<gDD, 256, 0, h->stream>>>(W, B, D);
   PLDA_LAUNCH_CHECK(h);
-  const size_t group_bytes = (size_t)G * DD * 8 * 5;
+  const size_t group_bytes = (size_t)G * DD * 8 * 9;      // (the moment form's nine matrices per group; the row form takes five)
   const bool grouped = h->em_variant != 1 && group_bytes <= ((size_t)24 << 30) && G <= 16384;
   h->em_groups = grouped ? G : 0;
   // Two closed forms of the grouped EM.  The moment form (rounds 2-5) runs seven D^3 products per group and iteration on per-group
@@ -995,7 +977,7 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       for (int64_t r = goff[g]; r < goff[g + 1]; r += 16 * RB)
         pin_tiles[ntiles++] = make_int4((int)r, (int)std::min<int64_t>(16 * RB, goff[g + 1] - r), g, 0);
     PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3 + (size_t)K * 4 + ntiles * 16 + 64));
-    PLDA_HIP(h, h->w[6].reserve(group_bytes + DD * 8 * 2 + (size_t)G * 16 + (size_t)GD * 16 + 64));
+    PLDA_HIP(h, h->w[6].reserve((size_t)G * DD * 8 * 5 + DD * 8 * 2 + (size_t)G * 16 + (size_t)GD * 16 + 64));
     double *Mg = h->w[5].as<double>(), *Zr = Mg + (size_t)K * D, *Wn = Zr + (size_t)K * D;
     int4 *dtiles = reinterpret_cast<int4 *>(Wn + (size_t)K * D);
     int *dcls = reinterpret_cast<int *>(dtiles + ntiles);
@@ -1064,13 +1046,14 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       }
     }
   } else if (grouped) {
+    // ---- moment form (header of em_moment_mstep_kernel) ----
     PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 + (size_t)K * 4 + 64));
     PLDA_HIP(h, h->w[6].reserve(group_bytes + DD * 8 + (size_t)G * 16 + 64));
     double *Mg = h->w[5].as<double>();
     int *dcls = reinterpret_cast<int *>(Mg + (size_t)K * D);
-    double *Cg = h->w[6].as<double>(), *b0 = Cg + (size_t)G * DD, *b1 = b0 + (size_t)G * DD,
-           *b2 = b1 + (size_t)G * DD, *b3 = b2 + (size_t)G * DD, *Csum = b3 + (size_t)G * DD, *dgn = Csum + DD,
-           *dgk = dgn + G;
+    const size_t GDD = (size_t)G * DD;
+    double *Cg = h->w[6].as<double>(), *Tg = Cg + GDD, *Xg = Tg + GDD, *P1 = Xg + GDD, *P2 = P1 + GDD, *QC = P2 + GDD, *XtX = QC + GDD,
+           *Rg = XtX + GDD, *QCQ = Rg + GDD, *Csum = QCQ + GDD, *dgn = Csum + DD, *dgk = dgn + G;
     int *dflag = h->fit_flag.as<int>();          // (its own buffer: the export kernel that ends the fit reads it)
     std::copy(gn.begin(), gn.end(), pin_gn);
     std::copy(gk.begin(), gk.end(), pin_gk);
@@ -1087,44 +1070,22 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
     else PLDA_TRY(gemm_f64(h, D, D, K, 1.0, Mg, 1, D, Mg, D, 1, nullptr, 0.0, Csum, D));
     const int64_t sDD = (int64_t)DD;
     for (int it = 0; it < iters; ++it) {
-      // inv = A^-1 ; Q = B A^-1 ; b1 = Mx = W Q^T ; QC = Q C_g (over inv) ; b3 = QCQ = QC Q^T
-      double *inv = b2, *Q = b0;
-      if (it == 0) {
-        if (D > 256) { inv = b0; Q = b2; }
-        em_first_inverse_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(dgn, D, sDD, inv);
-        PLDA_LAUNCH_CHECK(h);
-      } else if (D <= 256) {
-        // registers, one CU per group
-        PLDA_TRY(spd_inverse_via_whitening_f64(h, W, B, dgn, D, Q, inv, dflag, G));   // (Q is free until the next line)
-      } else {
-        // A^-1 = T^T T from the blocked whitening; A is dead once T exists, so the inverse replaces it in b0,
-        // and b1 .. b3 (contiguous) are the 3 D^2 doubles of scratch per group
-        inv = b0; Q = b2;
-        em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b0, nullptr);
-        PLDA_LAUNCH_CHECK(h);
-        PLDA_TRY(spd_inverse_blocked(h, b0, D, D, sDD, inv, D, sDD, b1, 3 * sDD, dflag, G));
-      }
-      double *QC = inv;
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, B, D, 1, 0, inv, D, 1, sDD, nullptr, 0.0, Q, D, sDD, G));
-      // One step of iterative refinement on Q A = B:  Q += (B - Q A) A^-1  (b1 = A, b3 = residual; both free here).
-      // An explicit inverse is accurate relative to ITS norm: when A has tiny eigenvalues (fewer samples than
-      // dimensions: the directions without data shrink with every iteration) that norm is huge and the O(1) block
-      // of A^-1 that acts on the class means carries an absolute error eps * ||A^-1||.  The residual B - Q A is
-      // made of O(1) numbers, so the step restores that block; what it adds in the tiny directions is multiplied
-      // by the tiny parts of W and B afterwards.  Against a long-double EM (N = 149, D = 200, six iterations,
-      // cond(W) = 3e8): W 3.5e-10 -> 3e-14, B 3.4e-8 -> 2e-13 (the reference's own formulation: 7e-13, 3e-10).
-      // (b1 = A_g and b3 = B for the residual: written by the M-step of the previous iteration, D <= 256)
-      if (it == 0 || D > 256) {
-        em_group_A_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(W, B, dgn, sDD, b1, b3);
-        PLDA_LAUNCH_CHECK(h);
-      }
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, -1.0, Q, D, 1, sDD, b1, D, 1, sDD, nullptr, 1.0, b3, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, b3, D, 1, sDD, inv, D, 1, sDD, nullptr, 1.0, Q, D, sDD, G));
-      // b1 = Mx = W Q^T and QC = Q C_g: independent, one launch
-      PLDA_TRY(gemm_f64_pair(h, D, D, D, W, D, 1, 0, Q, 1, D, sDD, b1, D, sDD, Q, D, 1, sDD, Cg, D, 1, sDD, QC, D, sDD, G));
-      PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, QC, D, 1, sDD, Q, 1, D, sDD, nullptr, 0.0, b3, D, sDD, G));
-      em_group_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, b1, QC, b3, dgn, dgk, G, D, cntW, cntB, W, B,
-                                                        D <= 256 && it + 1 < iters);
+      if (it == 0) em_first_T_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(dgn, D, sDD, Tg);
+      else PLDA_TRY(whiten_groups_f64(h, W, B, dgn, D, Tg, P2 /* 3 G D^2 of scratch: P2 | QC | XtX, dead between iterations */, dflag, G));
+      PLDA_LAUNCH_CHECK(h);
+      // (A(m, k) = A[m sam + k sak], B(k, n) = B[k sbk + n sbn])
+      const GemmSet s1[2] = {{Tg, D, 1, sDD, B, D, 1, 0, Xg, D, sDD},            // X  = T B
+                             {Tg, D, 1, sDD, Cg, D, 1, sDD, P1, D, sDD}};        // P1 = T C_g
+      PLDA_TRY(gemm_f64_multi(h, D, D, D, s1, 2, G));
+      const GemmSet s2[3] = {{Xg, 1, D, sDD, P1, D, 1, sDD, QC, D, sDD},         // QC  = X^T P1     (= Q C_g, Q = B A^-1 = X^T T)
+                             {P1, D, 1, sDD, Tg, 1, D, sDD, P2, D, sDD},         // P2  = P1 T^T     (= T C_g T^T, the whitened moments)
+                             {Xg, 1, D, sDD, Xg, D, 1, sDD, XtX, D, sDD}};       // XtX = X^T X      (Mx = B - n XtX)
+      PLDA_TRY(gemm_f64_multi(h, D, D, D, s2, 3, G));
+      const GemmSet s3[1] = {{P2, D, 1, sDD, Xg, D, 1, sDD, Rg, D, sDD}};        // R   = P2 X
+      PLDA_TRY(gemm_f64_multi(h, D, D, D, s3, 1, G));
+      const GemmSet s4[1] = {{Xg, 1, D, sDD, Rg, D, 1, sDD, QCQ, D, sDD}};       // QCQ = X^T R      (= Q C_g Q^T)
+      PLDA_TRY(gemm_f64_multi(h, D, D, D, s4, 1, G));
+      em_moment_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, Csum, XtX, QC, QCQ, dgn, dgk, G, D, (double)K, class_weight, cntW, cntB, W, B);
       PLDA_LAUNCH_CHECK(h);
     }
     // the flag of the EM's factorisations travels with the model export that ends the fit (round 4: read here, the

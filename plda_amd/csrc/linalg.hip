@@ -870,15 +870,15 @@ struct Tile16Operands {
   double *C;
   int64_t sam, sak, sbk, sbn, ldc, strideA, strideB, strideC;
 };
-// blockIdx.z < batch0: product z of the first set of operands, else product z - batch0 of the second (two independent
-// products of the same shape in one launch: gemm_f64_pair)
+// blockIdx.z = set * batch0 + product: up to three independent sets of batched products of the same shape in one launch
+// (gemm_f64_multi: the EM's independent D^3 products)
 __global__ __launch_bounds__(256) void gemm_f64_tile16_kernel(int M, int N, int K, Tile16Operands o0, Tile16Operands o1,
-                                                              int batch0) {
+                                                              int batch0, Tile16Operands o2 = Tile16Operands{}) {
   __shared__ double part[4][256];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fi = lane & 15, fk = lane >> 4;
-  const bool second = (int)blockIdx.z >= batch0;
-  const Tile16Operands &o = second ? o1 : o0;
-  const int64_t z = second ? (int)blockIdx.z - batch0 : (int)blockIdx.z;
+  const int set = (int)blockIdx.z / batch0;
+  const Tile16Operands &o = set == 0 ? o0 : set == 1 ? o1 : o2;
+  const int64_t z = (int)blockIdx.z - set * batch0;
   const double *__restrict__ A = o.A + z * o.strideA, *__restrict__ B = o.B + z * o.strideB;
   double *__restrict__ C = o.C + z * o.strideC;
   const int64_t sam = o.sam, sak = o.sak, sbk = o.sbk, sbn = o.sbn, ldc = o.ldc;
@@ -1021,26 +1021,28 @@ int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, cons
   return gemm_f64_batched(h, M, N, K, alpha, A, sam, sak, 0, B, sbk, sbn, 0, kw, beta, C, ldc, 0, 1);
 }
 
-// Two independent batched products of the same shape, C0 = A0 B0 and C1 = A1 B1 (alpha = 1, beta = 0; no k-weights), in ONE
-// launch where the small-product kernel applies (M, N, K <= 256: the EM's W Q^T and Q C_g), else one after the other.
-int gemm_f64_pair(plda_handle *h, int64_t M, int64_t N, int64_t K, const double *A0, int64_t sam0, int64_t sak0,
-                  int64_t strideA0, const double *B0, int64_t sbk0, int64_t sbn0, int64_t strideB0, double *C0,
-                  int64_t ldc0, int64_t strideC0, const double *A1, int64_t sam1, int64_t sak1, int64_t strideA1,
-                  const double *B1, int64_t sbk1, int64_t sbn1, int64_t strideB1, double *C1, int64_t ldc1,
-                  int64_t strideC1, int batch) {
-  if (M <= 256 && N <= 256 && K <= 256 && K > 0 && M > 0 && N > 0 && batch > 0 && 2 * batch <= 65535 &&
+// Up to three independent batched products of the same shape (alpha = 1, beta = 0), in ONE launch where the small-product
+// kernel applies (M, N, K <= 256), else one after the other.
+int gemm_f64_multi(plda_handle *h, int64_t M, int64_t N, int64_t K, const GemmSet *sets, int nsets, int batch) {
+  if (nsets < 1 || nsets > 3) return fail(h, PLDA_E_INVAL, "gemm_f64_multi: 1..3 sets");
+  if (M <= 256 && N <= 256 && K <= 256 && K > 0 && M > 0 && N > 0 && batch > 0 && nsets * batch <= 65535 &&
       h->gemm64_variant != 5 && h->gemm64_variant != 4) {
-    const dim3 tgrid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)(2 * batch));
-    const Tile16Operands o0{1.0, 0.0, A0, B0, C0, sam0, sak0, sbk0, sbn0, ldc0, strideA0, strideB0, strideC0};
-    const Tile16Operands o1{1.0, 0.0, A1, B1, C1, sam1, sak1, sbk1, sbn1, ldc1, strideA1, strideB1, strideC1};
-    gemm_f64_tile16_kernel<<<tgrid, 256, 0, h->stream>>>((int)M, (int)N, (int)K, o0, o1, batch);
+    Tile16Operands o[3];
+    for (int i = 0; i < 3; ++i) {
+      const GemmSet &g = sets[i < nsets ? i : 0];
+      o[i] = Tile16Operands{1.0, 0.0, g.A, g.B, g.C, g.sam, g.sak, g.sbk, g.sbn, g.ldc, g.strideA, g.strideB, g.strideC};
+    }
+    const dim3 tgrid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)(nsets * batch));
+    gemm_f64_tile16_kernel<<<tgrid, 256, 0, h->stream>>>((int)M, (int)N, (int)K, o[0], o[1], batch, o[2]);
     PLDA_LAUNCH_CHECK(h);
     return PLDA_OK;
   }
-  PLDA_TRY(gemm_f64_batched(h, M, N, K, 1.0, A0, sam0, sak0, strideA0, B0, sbk0, sbn0, strideB0, nullptr, 0.0, C0, ldc0,
-                            strideC0, batch));
-  return gemm_f64_batched(h, M, N, K, 1.0, A1, sam1, sak1, strideA1, B1, sbk1, sbn1, strideB1, nullptr, 0.0, C1, ldc1,
-                          strideC1, batch);
+  for (int i = 0; i < nsets; ++i) {
+    const GemmSet &g = sets[i];
+    PLDA_TRY(gemm_f64_batched(h, M, N, K, 1.0, g.A, g.sam, g.sak, g.strideA, g.B, g.sbk, g.sbn, g.strideB, nullptr, 0.0, g.C, g.ldc,
+                              g.strideC, batch));
+  }
+  return PLDA_OK;
 }
 
 // fp64 reciprocal / reciprocal square root: hardware estimate refined by Newton steps to full
@@ -1438,18 +1440,6 @@ int spd_inverse_small(plda_handle *h, const double *W, const double *B, const do
 int spd_inverse_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *out,
                     int *dflag, int batch) {
   return spd_inverse_small(h, W, B, gn, D, D, 0, out, D, (int64_t)D * D, dflag, batch);
-}
-
-// (W + n_g B)^-1 = T^T T with T = chol(W + n_g B)^-1 from the whitening form of the block-sweep kernel (64 < D <= 256):
-// the forward elimination alone is 65 us at D = 200 where the full sweep is 82, and T^T T is one 5 us GEMM.  `T` is
-// scratch of the same shape as `out`.  Other sizes: the sweep.
-int spd_inverse_via_whitening_f64(plda_handle *h, const double *W, const double *B, const double *gn, int D, double *T,
-                                  double *out, int *dflag, int batch) {
-  if (!(h->sweep_variant == 0 && D > 64 && D <= 256)) return spd_inverse_f64(h, W, B, gn, D, out, dflag, batch);
-  const int64_t sDD = (int64_t)D * D;
-  PLDA_TRY(spd_block_mfma(h, 1, W, B, gn, D, D, 0, T, D, sDD, dflag, batch));
-  // (m, k) of T^T = T[k][m]
-  return gemm_f64_batched(h, D, D, D, 1.0, T, 1, D, sDD, T, D, 1, sDD, nullptr, 0.0, out, D, sDD, batch);
 }
 
 // Cholesky factor in registers (D <= 256), same ownership as the sweep kernel: thread (ty, tx) of the 32 x 32

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_fit.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -4
+rm -rf gpurun_out/fitgroups_r6
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fitgroups_r6 -o t -- python scripts/fit_groups_probe.py 2>&1 | grep -v "^[WE]2026" | tail -5
+f=$(find gpurun_out/fitgroups_r6 -name "*kernel_trace.csv" | head -1)
+echo "G=1:"; python scripts/em_iter_trace.py $f 10 | cut -c1-90
+PLDA_EM_VARIANT=3 python scripts/fit_groups_probe.py 2>&1 | tail -4
