@@ -60,6 +60,9 @@ struct CountSet { int G = 0; int32_t vals[CS_MAX] = {}; };
 struct Bt4Table { int btM = -1, btN = -1, colwalk = 0; DevBuf tab; int qbase[8] = {}, qlen[8] = {}; uint64_t used = 0; };
 }  // namespace plda
 
+// a chunk of rows of ONE source and its coefficients in the EM's two rank-k sums (linalg.hip: em_rank_sums_mstep_f64)
+struct SyrkChunk { const double *rows; int nrows; int pad; double c1, c2; };
+
 struct plda_handle {
   std::recursive_mutex mu;   // taken by every C-ABI entry point (api.hip)
   int device = 0;
@@ -188,6 +191,8 @@ struct plda_handle {
 
   // ---- general scratch (fit / transform / znorm) ----
   plda::DevBuf w[16];
+  plda::DevBuf em_chunks;                       // the row-form EM's chunk table (device) ...
+  std::vector<SyrkChunk> em_chunks_host;        // ... and its host copy, alive while the upload is in flight
   plda::DevBuf eigdc;            // eig_dc.hip workspace
   plda::DevBuf zn_rows, zn_y, zn_small, zn_cpad;   // z-norm statistics by moments (score.hip; zn_cpad: the padded covariance of the model pass, transform.hip)
   int znorm_variant = 0;         // PLDA_ZNORM_VARIANT=1: every LLR on the fused fp32 GEMM (A/B arm); 2: moments in five passes
@@ -281,10 +286,13 @@ int gemm_f64_batched(plda_handle *h, int64_t M, int64_t N, int64_t K, double alp
 // C = X^T diag(kw) X + w2 X2^T X2 (one launch for D <= 208)
 int syrk_pair_f64(plda_handle *h, int D, int64_t K1, const double *X, int64_t ldx, const double *kw, int64_t K2,
                   const double *X2, int64_t ldx2, double w2, double *C, int64_t ldc);
-// the row-form EM's two rank-k sums + M-step in two launches (D <= 208; *used = false otherwise)
-int em_syrk2_mstep_f64(plda_handle *h, int D, int64_t K1, const double *X, const double *kw1, const double *kw2, int64_t K2,
-                       const double *Z, const double *Wn, const double *S, double sumK, double cw, double cntW, double cntB,
-                       double *W, double *B, bool *used);
+// the row-form EM's two rank-k sums + M-step in two launches (D <= 208; *used = false otherwise): a table of row chunks with
+// their coefficients in the two sums (built once per fit), Bout != Bin
+int em_rank_chunk_bound(int G, int D, int64_t K, int cus);
+int em_rank_chunks(int G, int D, int64_t K, int cus, const double *X, const double *gn, const double *gk, const double *Z,
+                   const double *Wn, SyrkChunk *out);
+int em_rank_sums_mstep_f64(plda_handle *h, int D, const SyrkChunk *chunks, int nchunks, const double *S, double sumK, double cw,
+                           double cntW, double cntB, double *W, const double *Bin, double *Bout, bool *used);
 int syrk_znorm_f64(plda_handle *h, int D0, int64_t K, const double *X, const double *zc, const double *zs, double *C, bool *used);
 int gemm_f64(plda_handle *h, int64_t M, int64_t N, int64_t K, double alpha, const double *A,
              int64_t sam, int64_t sak, const double *B, int64_t sbk, int64_t sbn,

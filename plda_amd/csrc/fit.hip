@@ -977,12 +977,12 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
       for (int64_t r = goff[g]; r < goff[g + 1]; r += 16 * RB)
         pin_tiles[ntiles++] = make_int4((int)r, (int)std::min<int64_t>(16 * RB, goff[g + 1] - r), g, 0);
     PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 * 3 + (size_t)K * 4 + ntiles * 16 + 64));
-    PLDA_HIP(h, h->w[6].reserve((size_t)G * DD * 8 * 5 + DD * 8 * 2 + (size_t)G * 16 + (size_t)GD * 16 + 64));
+    PLDA_HIP(h, h->w[6].reserve((size_t)G * DD * 8 * 5 + DD * 8 * 3 + (size_t)G * 16 + (size_t)GD * 16 + 64));
     double *Mg = h->w[5].as<double>(), *Zr = Mg + (size_t)K * D, *Wn = Zr + (size_t)K * D;
     int4 *dtiles = reinterpret_cast<int4 *>(Wn + (size_t)K * D);
     int *dcls = reinterpret_cast<int *>(dtiles + ntiles);
     double *Tg = h->w[6].as<double>(), *Xg = Tg + (size_t)G * DD, *scr = Xg + (size_t)G * DD, *P1 = scr + 3 * (size_t)G * DD,
-           *P2 = P1 + DD, *dgn = P2 + DD, *dgk = dgn + G, *kw1 = dgk + G, *kw2 = kw1 + GD;
+           *P2 = P1 + DD, *Balt = P2 + DD, *dgn = Balt + DD, *dgk = dgn + G, *kw1 = dgk + G, *kw2 = kw1 + GD;
     int *dflag = h->fit_flag.as<int>();          // (its own buffer: the export kernel that ends the fit reads it)
     std::copy(gn.begin(), gn.end(), pin_gn);
     std::copy(gk.begin(), gk.end(), pin_gk);
@@ -1010,22 +1010,35 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
         attr.done(h->device);
       }
     }
+    // the chunk table of the two rank-k sums (D <= 208): fixed pointers, built once
+    const SyrkChunk *dchunks = nullptr;
+    int nchunks = 0;
+    if (D <= 208) {
+      std::vector<SyrkChunk> &hc = h->em_chunks_host;      // (kept in the handle: the upload below may still be reading it)
+      // (about one chunk per CU: with 1.5 or 2 per CU -- smaller chunks, two workgroups resident -- the iteration is 8 % slower)
+      hc.resize((size_t)em_rank_chunk_bound(G, D, K, h->num_cus));
+      nchunks = em_rank_chunks(G, D, K, h->num_cus, Xg, gn.data(), gk.data(), Zr, Wn, hc.data());
+      PLDA_HIP(h, h->em_chunks.reserve((size_t)nchunks * sizeof(SyrkChunk)));
+      PLDA_HIP(h, hipMemcpyAsync(h->em_chunks.p, hc.data(), (size_t)nchunks * sizeof(SyrkChunk), hipMemcpyHostToDevice, h->stream));
+      dchunks = h->em_chunks.as<SyrkChunk>();
+    }
+    double *Bcur = B, *Bnext = Balt;
     for (int it = 0; it < iters; ++it) {
       if (it == 0) em_first_T_kernel<<<dim3(gDD, G), 256, 0, h->stream>>>(dgn, D, sDD, Tg);
-      else PLDA_TRY(whiten_groups_f64(h, W, B, dgn, D, Tg, scr, dflag, G));
+      else PLDA_TRY(whiten_groups_f64(h, W, Bcur, dgn, D, Tg, scr, dflag, G));
       PLDA_LAUNCH_CHECK(h);
       if (D <= 512) {
         const int xsplit = 2 * (int)ceil_div(NT, RB) * G <= h->num_cus * 3 / 2 ? 2 : 1;
         if (RB == 2) {
-          em_xtb_kernel<2><<<dim3(xsplit * (unsigned)ceil_div(NT, 2), (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg, xsplit);
+          em_xtb_kernel<2><<<dim3(xsplit * (unsigned)ceil_div(NT, 2), (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, Bcur, D, Xg, TTg, xsplit);
           em_rows_kernel<2><<<(unsigned)ntiles, 1024, rows_lds, h->stream>>>(Mg, dtiles, TTg, Xg, dgn, D, Zr, Wn);
         } else {
-          em_xtb_kernel<1><<<dim3(xsplit * (unsigned)NT, (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, B, D, Xg, TTg, xsplit);
+          em_xtb_kernel<1><<<dim3(xsplit * (unsigned)NT, (unsigned)G), 1024, xtb_lds, h->stream>>>(Tg, Bcur, D, Xg, TTg, xsplit);
           em_rows_kernel<1><<<(unsigned)ntiles, 1024, rows_lds, h->stream>>>(Mg, dtiles, TTg, Xg, dgn, D, Zr, Wn);
         }
         PLDA_LAUNCH_CHECK(h);
       } else {
-        PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, Tg, D, 1, sDD, B, D, 1, 0, nullptr, 0.0, Xg, D, sDD, G));
+        PLDA_TRY(gemm_f64_batched(h, D, D, D, 1.0, Tg, D, 1, sDD, Bcur, D, 1, 0, nullptr, 0.0, Xg, D, sDD, G));
         for (int g = 0; g < G; ++g) {
           const int64_t kg = goff[g + 1] - goff[g];
           const double *rows = Mg + (size_t)goff[g] * D;
@@ -1037,14 +1050,17 @@ int fit_em_device(plda_handle *h, int64_t K, int D, int iters) {
         PLDA_LAUNCH_CHECK(h);
       }
       bool fused = false;
-      PLDA_TRY(em_syrk2_mstep_f64(h, D, GD, Xg, kw1, kw2, K, Zr, Wn, S, (double)K, class_weight, cntW, cntB, W, B, &fused));
-      if (!fused) {
+      PLDA_TRY(em_rank_sums_mstep_f64(h, D, dchunks, nchunks, S, (double)K, class_weight, cntW, cntB, W, Bcur, Bnext, &fused));
+      if (fused) {
+        std::swap(Bcur, Bnext);
+      } else {
         PLDA_TRY(syrk_pair_f64(h, D, GD, Xg, D, kw1, K, Zr, D, 1.0, P1, D));
         PLDA_TRY(syrk_pair_f64(h, D, GD, Xg, D, kw2, K, Wn, D, 1.0, P2, D));
-        em_rows_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, P1, P2, D, (double)K, class_weight, cntW, cntB, W, B);
+        em_rows_mstep_kernel<<<gDD, 256, 0, h->stream>>>(S, P1, P2, D, (double)K, class_weight, cntW, cntB, W, Bcur);
         PLDA_LAUNCH_CHECK(h);
       }
     }
+    if (Bcur != B) PLDA_HIP(h, hipMemcpyAsync(B, Bcur, DD * 8, hipMemcpyDeviceToDevice, h->stream));   // (the M-step alternates two buffers)
   } else if (grouped) {
     // ---- moment form (header of em_moment_mstep_kernel) ----
     PLDA_HIP(h, h->w[5].reserve((size_t)K * D * 8 + (size_t)K * 4 + 64));

@@ -423,20 +423,19 @@ __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t
                                                        int64_t ldx, const double *__restrict__ kw, int64_t K1,
                                                        const double *__restrict__ X2, int64_t ldx2, double w2,
                                                        double *__restrict__ part, const double *__restrict__ zc,
-                                                       const double *__restrict__ zs, const double *__restrict__ kw_y1 = nullptr,
-                                                       const double *__restrict__ X2_y1 = nullptr, int64_t part_y1 = 0) {
+                                                       const double *__restrict__ zs, const SyrkChunk *__restrict__ chunks = nullptr) {
   __shared__ double Xs[2][GK * TRI_LD];
   __shared__ double Ws[2][GK];
   __shared__ double Rs[2][GK * 4];
-  // blockIdx.y == 1: a second product over the same first row set in the same launch -- other weights, other second set,
-  // partial slabs `part_y1` doubles further on (the EM's two sums, em_syrk2_mstep_f64)
-  if (blockIdx.y) { kw = kw_y1; X2 = X2_y1; part += part_y1; }
   const int D0 = ZN ? D - 2 : D;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
-  const int64_t kbeg = (int64_t)blockIdx.x * kchunk;
-  const int64_t kend = min(K, kbeg + kchunk);
+  int64_t kbeg = (int64_t)blockIdx.x * kchunk;
+  int64_t kend = min(K, kbeg + kchunk);
+  // chunks != nullptr: workgroup x multiplies the rows of chunk x of a table (its own row pointer and count, unit weights; the
+  // EM's rank-k sums, em_rank_sums_mstep_f64: the chunks' coefficients are applied by the reduction)
+  if (chunks) { X = chunks[blockIdx.x].rows; kbeg = 0; kend = chunks[blockIdx.x].nrows; K1 = kend; kw = nullptr; }
   // tile rows of this wave: lo = wave (wave + 1 tiles), hi = nt - 1 - wave (nt - wave tiles) when it is a different row
   const int lo = wave, hi = nt - 1 - wave;
   const int cnt_lo = lo <= hi ? lo + 1 : 0, cnt_hi = hi > lo ? hi + 1 : 0;
@@ -619,15 +618,19 @@ __global__ __launch_bounds__(1024) void syrk_tri_reduce_kernel(const double *__r
   if (gr != gcol) *c2 = v2;
 }
 
-// The reduction above for the EM's two sums at once, with the M-step as its epilogue (em_rows_mstep_kernel's formula):
-//   W = (S + sumK B + P1) / cntW,   B = (cw B + P2) / cntB,     P1, P2 = the two sums of partial slabs (part, part + part_y1)
-// Every element (and its mirror) is read and written by one thread only, so B is updated in place.
-__global__ __launch_bounds__(1024) void em_syrk_reduce_mstep_kernel(const double *__restrict__ part, int64_t part_y1, int splits,
-                                                                    int D, const double *__restrict__ S, double sumK, double cw,
-                                                                    double cntW, double cntB, double *__restrict__ W,
-                                                                    double *__restrict__ B) {
-  __shared__ double qs[2][4][256];
+// The reduction above for the EM's two rank-k sums, with the M-step as its epilogue (em_rows_mstep_kernel's formula).  The
+// slabs are products of row CHUNKS (chunk s: coefficients c1_s, c2_s):   P_y = sum_s c_y[s] slab_s,  and
+//   blockIdx.y == 0:  W    = (S + sumK Bin + P_1) / cntW          blockIdx.y == 1:  Bout = (cw Bin + P_2) / cntB
+// -- one workgroup per tile AND sum (182 at D = 200: the single-sum-pair form kept 91 of 256 CUs busy for 23 us on 48 MB of
+// slabs); Bout is another buffer than Bin because the W half reads Bin while the B half writes.
+__global__ __launch_bounds__(1024) void em_rank_reduce_mstep_kernel(const double *__restrict__ part, const SyrkChunk *__restrict__ chunks,
+                                                                    int splits, int D, const double *__restrict__ S, double sumK,
+                                                                    double cw, double cntW, double cntB, double *__restrict__ W,
+                                                                    const double *__restrict__ Bin, double *__restrict__ Bout) {
+  __shared__ double qs[4][256];
+  __shared__ double cs[1024];
   const int nt = (D + 15) / 16, ntri = nt * (nt + 1) / 2;
+  const int y = blockIdx.y;
   int tr = 0, tcol = (int)blockIdx.x;
   while (tcol > tr) { tcol -= tr + 1; ++tr; }
   const int e = threadIdx.x & 255, q = threadIdx.x >> 8;
@@ -636,61 +639,85 @@ __global__ __launch_bounds__(1024) void em_syrk_reduce_mstep_kernel(const double
   const bool live = gr < D && gcol < D && gcol <= gr;
   const int per = (splits + 3) >> 2, z0 = q * per, z1 = min(splits, z0 + per);
   const int64_t zs = (int64_t)ntri * 256;
-#pragma unroll
-  for (int y = 0; y < 2; ++y) {
-    const double *p = part + y * part_y1 + (int64_t)blockIdx.x * 256 + e;
-    double s16[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s16[u] = 0.0;
+  const double *p = part + (int64_t)blockIdx.x * 256 + e;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int zb = 0; zb < splits; zb += 1024) {          // the coefficients of this sum, 1024 chunks at a time, through LDS
+    __syncthreads();
+    if (zb + (int)threadIdx.x < splits) cs[threadIdx.x] = y ? chunks[zb + threadIdx.x].c2 : chunks[zb + threadIdx.x].c1;
+    __syncthreads();
     if (live) {
-      int z = z0;
-      for (; z + 16 <= z1; z += 16) {
+      const int za = max(z0, zb), zc = min(z1, zb + 1024);
+      int z = za;
+      for (; z + 16 <= zc; z += 16) {
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s16[u] += p[(int64_t)(z + u) * zs];
+        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(z + u) * zs];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] = fma(cs[z + u - zb], v[u], acc[u & 3]);
       }
-      for (int u = 0; z < z1; ++z, ++u) s16[u] += p[(int64_t)z * zs];
+      for (; z < zc; ++z) acc[z & 3] = fma(cs[z - zb], p[(int64_t)z * zs], acc[z & 3]);
     }
-    qs[y][q][e] = (((s16[0] + s16[1]) + (s16[2] + s16[3])) + ((s16[4] + s16[5]) + (s16[6] + s16[7]))) +
-                  (((s16[8] + s16[9]) + (s16[10] + s16[11])) + ((s16[12] + s16[13]) + (s16[14] + s16[15])));
   }
+  qs[q][e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
   if (q != 0 || !live) return;
-  const double p1 = (qs[0][0][e] + qs[0][1][e]) + (qs[0][2][e] + qs[0][3][e]);
-  const double p2 = (qs[1][0][e] + qs[1][1][e]) + (qs[1][2][e] + qs[1][3][e]);
+  const double pv = (qs[0][e] + qs[1][e]) + (qs[2][e] + qs[3][e]);
   const size_t ij = (size_t)gr * D + gcol, ji = (size_t)gcol * D + gr;
-  const double bij = B[ij], bji = B[ji];
-  const double wij = S[ij] + fma(sumK, bij, p1), wji = S[ji] + fma(sumK, bji, p1);
-  const double vij = fma(cw, bij, p2), vji = fma(cw, bji, p2);
-  const double w = 0.5 * (wij / cntW + wji / cntW), b = 0.5 * (vij / cntB + vji / cntB);
-  W[ij] = w; W[ji] = w;
-  B[ij] = b; B[ji] = b;
+  const double bij = Bin[ij], bji = Bin[ji];
+  if (y == 0) {
+    const double wij = S[ij] + fma(sumK, bij, pv), wji = S[ji] + fma(sumK, bji, pv);
+    const double w = 0.5 * (wij / cntW + wji / cntW);
+    W[ij] = w; W[ji] = w;
+  } else {
+    const double vij = fma(cw, bij, pv), vji = fma(cw, bji, pv);
+    const double b = 0.5 * (vij / cntB + vji / cntB);
+    Bout[ij] = b; Bout[ji] = b;
+  }
 }
 
 // The grouped EM's two rank-k sums and its M-step (fit.hip, row form), D <= 208:
-//   P1 = X^T diag(kw1) X + Z^T Z,   P2 = X^T diag(kw2) X + Wn^T Wn      (X: K1 stacked rows; Z, Wn: K2 rows each)
-// in ONE launch of the triangle kernel (blockIdx.y picks the sum) and one reduction that applies the M-step.  The rows are cut
-// into chunks of >= 64 (syrk_pair_f64's 128-row chunks left 3/4 of the chip idle at 5 000 rows).
-// *used = false: D > 208, the caller takes two syrk_pair_f64 and its own M-step.
-int em_syrk2_mstep_f64(plda_handle *h, int D, int64_t K1, const double *X, const double *kw1, const double *kw2, int64_t K2,
-                       const double *Z, const double *Wn, const double *S, double sumK, double cw, double cntW, double cntB,
-                       double *W, double *B, bool *used) {
+//   P1 = sum_g (-K_g n_g) X_g^T X_g + Z^T Z,     P2 = sum_g (-K_g) X_g^T X_g + Wn^T Wn
+// Every product of rows is taken ONCE: the rows are cut into chunks that never cross a group of X (`chunks`, built once per fit by
+// em_rank_chunks), one workgroup of the triangle kernel per chunk, and the reduction weights chunk s by (c1_s, c2_s) -- X's
+// chunks enter both sums, Z's only the first, Wn's only the second.  (Round 6a ran the stacked X rows through the kernel twice, with
+// row weights, 555 k MFMAs instead of 392 k at C2's skewed labels.)  *used = false: D > 208, the caller takes two syrk_pair_f64
+// and its own M-step.
+int em_rank_sums_mstep_f64(plda_handle *h, int D, const SyrkChunk *chunks, int nchunks, const double *S, double sumK, double cw,
+                           double cntW, double cntB, double *W, const double *Bin, double *Bout, bool *used) {
   *used = false;
-  if (D > TRI_NT * 16 || !(h->gemm64_variant == 0 || h->gemm64_variant == 6)) return PLDA_OK;
+  if (D > TRI_NT * 16 || !(h->gemm64_variant == 0 || h->gemm64_variant == 6) || nchunks < 1) return PLDA_OK;
   const int nt = (int)ceil_div(D, 16), ntri = nt * (nt + 1) / 2;
-  const int64_t K = K1 + K2;
-  // 128 chunks per sum at most: the 256 workgroups of the two sums are ONE round on the chip's 256 CUs (136 + 136 were two)
-  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(128, ceil_div(K, 64)));
-  const int64_t kchunk = round_up(ceil_div(K, splits), GK);
-  splits = (int)ceil_div(K, kchunk);
-  const int64_t part_y1 = (int64_t)splits * ntri * 256;
-  PLDA_HIP(h, h->w[15].reserve((size_t)2 * part_y1 * 8));
+  PLDA_HIP(h, h->w[15].reserve((size_t)nchunks * ntri * 256 * 8));
   double *part = h->w[15].as<double>();
-  syrk_tri_kernel<false><<<dim3((unsigned)splits, 2), 512, 0, h->stream>>>(D, K, kchunk, X, D, kw1, K1, Z, D, 1.0, part, nullptr,
-                                                                           nullptr, kw2, Wn, part_y1);
-  em_syrk_reduce_mstep_kernel<<<(unsigned)ntri, 1024, 0, h->stream>>>(part, part_y1, splits, D, S, sumK, cw, cntW, cntB, W, B);
+  syrk_tri_kernel<false><<<(unsigned)nchunks, 512, 0, h->stream>>>(D, 0, 0, nullptr, D, nullptr, 0, nullptr, D, 1.0, part, nullptr,
+                                                                   nullptr, chunks);
+  em_rank_reduce_mstep_kernel<<<dim3((unsigned)ntri, 2), 1024, 0, h->stream>>>(part, chunks, nchunks, D, S, sumK, cw, cntW, cntB, W, Bin, Bout);
   PLDA_LAUNCH_CHECK(h);
   *used = true;
   return PLDA_OK;
+}
+
+// The chunk table of em_rank_sums_mstep_f64 (host side; `out` has room for em_rank_chunk_bound entries): rows per chunk so that
+// the launch is about one workgroup per CU, the groups of X cut into equal parts.
+int em_rank_chunk_bound(int G, int D, int64_t K, int cus) {
+  const int64_t R = (int64_t)G * D + 2 * K;
+  const int rc = (int)std::max<int64_t>(32, round_up(ceil_div(R, cus), 16));
+  return (int)((int64_t)G * ceil_div(D, rc) + 2 * ceil_div(K, rc));
+}
+int em_rank_chunks(int G, int D, int64_t K, int cus, const double *X, const double *gn, const double *gk, const double *Z,
+                   const double *Wn, SyrkChunk *out) {
+  const int64_t R = (int64_t)G * D + 2 * K;
+  const int rc = (int)std::max<int64_t>(32, round_up(ceil_div(R, cus), 16));
+  int n = 0;
+  const int nx = (int)ceil_div(D, rc);
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < nx; ++c) {
+      const int r0 = (int)((int64_t)D * c / nx), r1 = (int)((int64_t)D * (c + 1) / nx);
+      out[n++] = SyrkChunk{X + ((int64_t)g * D + r0) * D, r1 - r0, 0, -gk[g] * gn[g], -gk[g]};
+    }
+  for (int64_t r = 0; r < K; r += rc) out[n++] = SyrkChunk{Z + r * D, (int)std::min<int64_t>(rc, K - r), 0, 1.0, 0.0};
+  for (int64_t r = 0; r < K; r += rc) out[n++] = SyrkChunk{Wn + r * D, (int)std::min<int64_t>(rc, K - r), 0, 0.0, 1.0};
+  return n;
 }
 
 #include "syrk_blk.inc"

@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 itn = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ms = [i for i, r in enumerate(rows) if any(m in r["Kernel_Name"] for m in ("em_rows_mstep_kernel", "em_moment_mstep_kernel", "em_syrk_reduce_mstep_kernel"))]
+ms = [i for i, r in enumerate(rows) if any(m in r["Kernel_Name"] for m in ("em_rows_mstep_kernel", "em_moment_mstep_kernel", "em_rank_reduce_mstep_kernel"))]
 per_fit = 10
 a, b = ms[len(ms) - back * per_fit + itn - 1], ms[len(ms) - back * per_fit + itn]
 t0 = int(rows[a]["End_Timestamp"])
