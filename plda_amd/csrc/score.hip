@@ -1070,13 +1070,18 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 
   unsigned long long t_arr = 0, t_lv = 0;
   int tseq = 0, st = 0;
+  // (the asm memory clobbers around every raw s_barrier of this file: llvm.amdgcn.s.barrier is IntrNoMem, so the optimiser may move
+  //  plain LDS loads across it -- it did in syrk_blk.inc, a one-in-a-thousand wrong block, round 6.  Here the compiler had kept the
+  //  last step's fragment reads in front of the barrier; with the clobbers it has to, and the code is the same but for three
+  //  scalar instructions.)
   auto early_barrier = [&]() {
     if (TL) t_arr = __builtin_amdgcn_s_memtime();
     // (the builtin, not inline asm: the compiler's waitcnt pass must see this drain, or it keeps the
     //  bias DMA -- a FLAT-encoded global_load_lds -- "pending" forever and turns every later LDS wait
     //  of the epilogue into lgkmcnt(0))
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     if (TL) {
       t_lv = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0 && lane == 0 && tseq < 8 && st < 16) {
@@ -1096,8 +1101,9 @@ __global__ __launch_bounds__(512, 2) void trials_gemm_bt2_kernel(
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
   dma_advance();
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(0x0070);
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) dma_piece(jj);
   dma_advance();

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(512) void transform_dma_kernel(const double *__rest
       if (NSTG >= 3 && prev_real && !stores_pending) __builtin_amdgcn_s_waitcnt(0x0070 | PPW);   // vmcnt(PPW) lgkmcnt(0)
       else __builtin_amdgcn_s_waitcnt(0x0070);                                                   // vmcnt(0) lgkmcnt(0)
       stores_pending = false;
-      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
       prev_real = dok;
       issue();
       const char *const sbase = reinterpret_cast<const char *>(tf_lds) + cbuf * SB;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512) void transform_dma_kernel(const double *__rest
         for (int r = 0; r < 4; ++r) red[ch * ROWS + rg * 16 + fk + 4 * r] = part[r];
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0) only: the DMA stays in flight across this barrier
-      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double sum = 0.0;
@@ -799,7 +799,7 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
 #pragma unroll
   for (int s = 0; s < NBUF - 1; ++s) dma_group(gi + s * gstep, s, gi + s * gstep < ng);
   __builtin_amdgcn_s_waitcnt(0x0070);
-  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
 
   // ---- the three parts of a group's work (m: its index in this workgroup's sequence, g: its global index) ----
   // MFMAs of k-steps [K0, K1) of group m into ac; with DMA: the pieces of the group `ahead` further on, one every 8 k-steps
@@ -943,7 +943,7 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
       stamp(m, 2);
       __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): the operands requested in this step are in LDS
       stamp(m, 3);
-      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
       stamp(m, 4);
       epi2(acc, m, gi);
       stamp(m, 5);
@@ -959,7 +959,7 @@ __device__ __forceinline__ void treg_wave(const TregArgs &A, TF_LDS_AS char *con
       stamp(m, 6);
       __builtin_amdgcn_s_waitcnt(0x0070);
       stamp(m, 7);
-      __builtin_amdgcn_s_barrier();           // B(m)
+      asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");           // B(m)
       stamp(m, 0);
       const int64_t gn = gi + gstep;
       if (gn >= ng) { epi2(acc, m, gi); break; }

@@ -1,3 +1,7 @@
+# The round's profile set: scripts/gpu_profile.sh for C2 (rocprofv3 kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes, SQ counters of
+# the trials GEMM), then the EM's kernels: kernel trace + stats of scripts/fit_groups_probe.py and one EM iteration kernel by kernel
+# (scripts/em_iter_trace.py) for the row form (G = 40, 36, 12) and the moment form (G = 1).
+# usage (GPU box, through gpurun): bash scripts/gpu_profile_em.sh ; copy the summaries into profiles/ afterwards
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 ROUND=r06 CONFIG=C2 bash scripts/gpu_profile.sh > gpurun_out/prof_r06_C2.log 2>&1

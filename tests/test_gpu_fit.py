@@ -490,7 +490,19 @@ def test_statistics_pass_block_scatter_kernel(oracle, d, n, k):
     S = scatter.cpu().numpy()
     assert np.array_equal(counts.cpu().numpy(), st["counts"])
     assert np.abs(means.cpu().numpy() - st["means"]).max() <= 1e-13 * np.abs(st["means"]).max()
-    assert np.abs(S - st["scatter"]).max() <= 1e-11 * np.abs(st["scatter"]).max(), np.abs(S - st["scatter"]).max() / np.abs(st["scatter"]).max()
+    err = np.abs(S - st["scatter"])
+    if not err.max() <= 1e-11 * np.abs(st["scatter"]).max():
+        # diagnostics for a failure that has only ever shown up inside the whole suite: which 64 x 64 blocks are off, and whether
+        # the same handle gives the right answer the second time
+        nb = (d + 63) // 64
+        blocks = [(r, c, float(err[64 * r:64 * r + 64, 64 * c:64 * c + 64].max())) for r in range(nb) for c in range(nb)
+                  if err[64 * r:64 * r + 64, 64 * c:64 * c + 64].max() > 1e-11 * np.abs(st["scatter"]).max()]
+        eng.fit_stats_dev(dX.data_ptr(), n, d, dy.data_ptr(), k)
+        eng.fit_get_stats_dev(means.data_ptr(), counts.data_ptr(), scatter.data_ptr())
+        torch.cuda.synchronize()
+        again = float(np.abs(scatter.cpu().numpy() - st["scatter"]).max())
+        raise AssertionError("scatter off by %.3g relative; blocks (row, col, max err): %s; second run on the same handle: %.3g abs"
+                             % (err.max() / np.abs(st["scatter"]).max(), blocks[:40], again))
     assert np.array_equal(S, S.T)
     eng.set_stream(None)
 
@@ -555,3 +567,42 @@ def test_row_form_with_one_class_per_group(oracle):
         r2 = oracle.fit(x2, y2, 6)
         i2 = e2.fit_internals()
         assert _rel(i2["W"], r2["W"]) < 1e-10 and _rel(i2["B"], r2["B"]) < 1e-10
+
+
+def test_statistics_pass_is_bit_reproducible():
+    """The block scatter kernel (208 < D <= 512) on fresh handles, many times, with another handle's problem run and freed
+    in between: every scatter equals the first bit for bit.  (Round 6: the compiler had moved a stage's last fragment reads
+    below the stage's raw s_barrier -- llvm.amdgcn.s.barrier is IntrNoMem -- where another wave's LDS DMA could already be
+    overwriting the buffer; one 64 x 64 block came out wrong about once in a thousand launches, on some boxes, after some
+    predecessors.  scripts/stress_scatter.py is the long form of this test.)"""
+    import torch
+    from plda_amd import MPlda
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(6512)
+    d, n, k = 512, 6000, 100
+    y = rng.integers(0, k, n); y[:k] = np.arange(k)
+    x = rng.random((n, d)) + 0.5 * rng.standard_normal((k, d))[y]
+    dX = torch.from_numpy(x).to(dev); dy = torch.from_numpy(y.astype(np.int64)).to(dev)
+    first = None
+    for r in range(120):
+        other = MPlda(0)
+        n2, d2, k2 = int(rng.integers(500, 6000)), int(rng.choice([200, 256, 384, 512])), int(rng.integers(5, 200))
+        y2 = rng.integers(0, k2, n2); y2[:k2] = np.arange(k2)
+        x2 = torch.from_numpy(1e3 * rng.standard_normal((n2, d2))).to(dev); dy2 = torch.from_numpy(y2.astype(np.int64)).to(dev)
+        other.fit_stats_dev(x2.data_ptr(), n2, d2, dy2.data_ptr(), k2)
+        other.synchronize()
+        del other, x2, dy2
+        eng = MPlda(0)
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        eng.fit_stats_dev(dX.data_ptr(), n, d, dy.data_ptr(), k)
+        means = torch.empty((k, d), dtype=torch.float64, device=dev)
+        counts = torch.empty((k,), dtype=torch.int64, device=dev)
+        S = torch.empty((d, d), dtype=torch.float64, device=dev)
+        eng.fit_get_stats_dev(means.data_ptr(), counts.data_ptr(), S.data_ptr())
+        torch.cuda.synchronize()
+        s = S.cpu().numpy()
+        eng.set_stream(None)
+        if first is None:
+            first = s
+        else:
+            assert np.array_equal(first, s), (r, float(np.abs(s - first).max()))
