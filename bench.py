@@ -127,8 +127,10 @@ def skewed_labels(N, K, lo=5, hi=60, seed=2):
     rng = np.random.default_rng(seed)
     nk = rng.integers(lo, hi + 1, K).astype(np.float64)
     nk = np.maximum(1, np.floor(nk * N / nk.sum())).astype(np.int64)
+    while nk.sum() > N:                                  # (few rows per speaker: the floor of 1 overshoots; take from the largest)
+        nk[np.argmax(nk)] -= 1
     nk[: N - nk.sum()] += 1
-    return np.repeat(np.arange(K), nk)[:N].astype(np.uint64), nk
+    return np.repeat(np.arange(K), nk).astype(np.uint64), nk
 
 
 def fit_skewed(eng, dX, N, D, K, iters, X_host, with_cpu):

@@ -210,3 +210,16 @@ def test_bench_line_names_rccl_only_when_rccl_ran():
     rc = [dict(transport="rccl", nranks=8, rank=r, device=r, pci_bus_id="0000:%02x:00.0" % r, rccl_version=22606) for r in range(8)]
     m = bench.describe_ranks(rc)
     assert m["comm_nranks"] == m["rccl_nranks"] == 8 and m["rccl_version"] == 22606 and m["distinct_devices"] == 8
+
+
+def test_bench_skewed_labels_are_dense_and_exact():
+    """bench.py's `fit_skewed` labelling (C2's rows with unequal speaker counts): exactly N rows, every speaker present, also
+    when there are barely more rows than speakers (the --rows overrides of the self-launch tests)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    for n, k in ((100000, 5000), (20000, 5000), (5000, 5000), (6001, 5000), (1200000, 7200)):
+        y, nk = bench.skewed_labels(n, k)
+        assert y.shape[0] == n and int(nk.sum()) == n and nk.min() >= 1
+        assert np.array_equal(np.unique(y), np.arange(k, dtype=y.dtype))
+    y, nk = bench.skewed_labels(100000, 5000)
+    assert len(np.unique(nk)) == 36 and nk.min() >= 5 - 1 and nk.max() <= 60 + 2      # BASELINE.md C2's "skewed-n_k variant"
