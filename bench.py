@@ -139,7 +139,7 @@ def fit_skewed(eng, dX, N, D, K, iters, X_host, with_cpu):
     import torch
     y, nk = skewed_labels(N, K)
     dy = torch.from_numpy(y.astype(np.int64)).to(dX.device)
-    res = {"labels": "n_k in [5, 60], seed 2 (skewed_labels)", "distinct_counts_G": int(len(np.unique(nk))), "N": N, "D": D, "K": K}
+    res = {"labels": "n_k drawn from [5, 60] and rescaled to the N rows (C2: 3 .. 38 per speaker), seed 2 (skewed_labels)", "distinct_counts_G": int(len(np.unique(nk))), "N": N, "D": D, "K": K}
     one = None
     if with_cpu:
         eng.fit_dev(dX.data_ptr(), N, D, dy.data_ptr(), K, 1)
