@@ -418,6 +418,11 @@ constexpr int TRI_LD = TRI_NT * 16 + 16;   // LDS row stride in doubles
 // behind the stage's barrier (one more barrier per stage).  One read of the rows gives the second moments, the column sums
 // (the constant column) and the count -- rounds 2-4 made five passes (rows, column sums, centring, SYRK reading twice).
 // zc: [ca (D0) | w (D0) | g (D0) | L]  (znorm_coef_kernel);  zs: the pilot shift p [D0 + 1].
+// Tried in round 6 and dropped: a BALANCED tile plan -- every tile row cut into parts of at most six tiles, the parts dealt to the
+// eight waves largest first (11-13 tiles per wave, 22-24 per SIMD at nt = 13, where the assignment below gives 28 : 28 : 21 : 14),
+// each part with its own column fragments read from LDS.  Same results, NOT faster: K2 0.159 ms at 100k x 200 (0.156), 0.39 of the
+// peak at 1M rows (0.39), norm() 0.88 ms (0.86), the EM's rank-k sums 2 % slower -- 242-256 registers, 33-48 scalar spills and one
+// more fragment read per six MFMAs cost what the balance gains; the kernel is not bound by its busiest SIMD's MFMAs.
 template <bool ZN>
 __global__ __launch_bounds__(512) void syrk_tri_kernel(int D, int64_t K, int64_t kchunk, const double *__restrict__ X,
                                                        int64_t ldx, const double *__restrict__ kw, int64_t K1,
