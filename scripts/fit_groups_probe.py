@@ -1,6 +1,6 @@
 """fit on device-resident data when the speakers have DIFFERENT utterance counts (real data; SURVEY.md section 8d's second C2
 labelling: n_k in [5, 60]): statistics / EM / GetOutput ms and EM iterations/s against the number G of distinct counts.
-usage: [PLDA_EM_VARIANT=3] python scripts/fit_groups_probe.py   (3: the per-group second-moment form of rounds 2-5)"""
+usage: [PLDA_EM_VARIANT=3|4] python scripts/fit_groups_probe.py   (3 / 4: the moment / the row form of the grouped EM always)"""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 N, D, K = 100000, 200, 5000
 rng = np.random.default_rng(2)
 X = torch.from_numpy(rng.random((N, D))).to(dev)
-print("PLDA_EM_VARIANT =", os.environ.get("PLDA_EM_VARIANT", "0 (row form)"))
+print("PLDA_EM_VARIANT =", os.environ.get("PLDA_EM_VARIANT", "0 (form chosen by shape)"))
 for name, lo, hi in (("uniform 20", 20, 20), ("n_k in [15, 25]", 15, 25), ("n_k in [5, 60]", 5, 60), ("n_k in [1, 200]", 1, 200)):
     if lo == hi:
         y = np.arange(N) % K
